@@ -1,0 +1,336 @@
+// fc_api.hip -- fully connected head blocks: Linear -> {BatchNorm1d | LayerNorm | none} -> ReLU -> dropout
+// (models/pointnet_pp_vonMises.py:32-35, pointnet_pp_8dir.py:81-85, pointnet_pp_mvM.py:82-83,91-122).
+//
+// The matrix products run on the same fused MFMA GEMM / dW kernels as the set-abstraction layers;
+// the row/column normalisation passes here touch only M x N elements (M = batch), so they are plain
+// wave-per-row / lane-per-column kernels with float64 accumulation.
+#include "kernels.h"
+
+namespace pnpp {
+
+#define PNPP_TRY(expr)                 \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != PNPP_OK) return rc_; \
+    } while (0)
+
+// y = dropout(relu(z*scale + shift))   (BatchNorm) or   y = dropout(relu(z + b))   (no norm)
+__global__ void __launch_bounds__(256) fc_apply_cols_kernel(const float *__restrict__ z, const float *__restrict__ scale,
+                                                            const float *__restrict__ shift, const uint8_t *__restrict__ mask,
+                                                            float drop_scale, int relu, int M, int N, float *__restrict__ y) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int n = (int)(i % N);
+        float v = fmaf(z[i], scale ? scale[n] : 1.f, shift[n]);
+        if (relu) v = fmaxf(v, 0.f);
+        if (mask) v = mask[i] ? v * drop_scale : 0.f;
+        y[i] = v;
+    }
+}
+
+// LayerNorm over the feature axis of u = z + b; one 256-thread block per row
+__global__ void __launch_bounds__(256) fc_apply_ln_kernel(const float *__restrict__ z, const float *__restrict__ b,
+                                                          const float *__restrict__ nw, const float *__restrict__ nb,
+                                                          const uint8_t *__restrict__ mask, float drop_scale, int relu, int N,
+                                                          float eps, float *__restrict__ y, float *__restrict__ mean,
+                                                          float *__restrict__ istd) {
+    __shared__ double red[2][4];
+    const int m = blockIdx.x;
+    const float *zr = z + (size_t)m * N;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const double u = (double)zr[n] + (double)b[n];
+        s1 += u;
+        s2 += u * u;
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) s1 += shfl_xor_f64(s1, k), s2 += shfl_xor_f64(s2, k);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s1, red[1][threadIdx.x >> 6] = s2;
+    __syncthreads();
+    s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double mu = s1 / N;
+    double var = s2 / N - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    if (threadIdx.x == 0) mean[m] = (float)mu, istd[m] = (float)is;
+    const float muf = (float)mu, isf = (float)is;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float v = ((zr[n] + b[n]) - muf) * isf * nw[n] + nb[n];
+        if (relu) v = fmaxf(v, 0.f);
+        if (mask) v = mask[(size_t)m * N + n] ? v * drop_scale : 0.f;
+        y[(size_t)m * N + n] = v;
+    }
+}
+
+// ---- backward, BatchNorm1d / none: block = 32 columns x 8 row lanes --------------------------------
+// g = dy * dropout * relu'; BN: dz = gamma*istd*(g - mean(g) - xhat*mean(g*xhat)); none: dz = g
+__global__ void __launch_bounds__(256)
+fc_bwd_cols_kernel(const float *__restrict__ dy, const float *__restrict__ z, const uint8_t *__restrict__ mask,
+                   float drop_scale, int relu, int bn, const float *__restrict__ scale, const float *__restrict__ shift,
+                   const float *__restrict__ mean, const float *__restrict__ istd, const float *__restrict__ bias, int M, int N,
+                   int training, float *__restrict__ dz, float *__restrict__ dnw, float *__restrict__ dnb,
+                   float *__restrict__ db) {
+    __shared__ double red[8][2][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + cl;
+    const bool ok = n < N;
+    float sc = 1.f, sh = 0.f, mu = 0.f, is = 1.f;
+    if (ok) {
+        if (bn) sc = scale[n], sh = shift[n], mu = mean[n], is = istd[n];
+        else sh = bias[n];
+    }
+    double s1 = 0.0, s2 = 0.0;
+    if (ok)
+        for (int m = rl; m < M; m += 8) {
+            const size_t i = (size_t)m * N + n;
+            const float zz = z[i];
+            float g = dy[i];
+            if (mask) g = mask[i] ? g * drop_scale : 0.f;
+            if (relu && !(fmaf(zz, sc, sh) > 0.f)) g = 0.f;
+            s1 += (double)g;
+            s2 += (double)g * (double)((zz - mu) * is);
+        }
+    red[rl][0][cl] = s1;
+    red[rl][1][cl] = s2;
+    __syncthreads();
+    s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1 += red[i][0][cl], s2 += red[i][1][cl];
+    if (!ok) return;
+    const float c1 = (bn && training) ? (float)(s1 / M) : 0.f, c2 = (bn && training) ? (float)(s2 / M) : 0.f;
+    for (int m = rl; m < M; m += 8) {
+        const size_t i = (size_t)m * N + n;
+        const float zz = z[i];
+        float g = dy[i];
+        if (mask) g = mask[i] ? g * drop_scale : 0.f;
+        if (relu && !(fmaf(zz, sc, sh) > 0.f)) g = 0.f;
+        dz[i] = bn ? sc * (g - c1 - (zz - mu) * is * c2) : g;
+    }
+    if (rl == 0) {
+        if (bn) {
+            if (dnw) dnw[n] = (float)s2;
+            if (dnb) dnb[n] = (float)s1;
+            if (db) db[n] = training ? 0.f : (float)((double)sc * s1);
+        } else if (db) {
+            db[n] = (float)s1;
+        }
+    }
+}
+
+// ---- backward, LayerNorm: one block per row writes dz and g; column sums in a second kernel ---------
+__global__ void __launch_bounds__(256)
+fc_bwd_ln_rows_kernel(const float *__restrict__ dy, const float *__restrict__ z, const float *__restrict__ b,
+                      const float *__restrict__ nw, const float *__restrict__ nb, const uint8_t *__restrict__ mask,
+                      float drop_scale, int relu, const float *__restrict__ mean, const float *__restrict__ istd, int N,
+                      float *__restrict__ dz, float *__restrict__ gbuf) {
+    __shared__ double red[2][4];
+    const int m = blockIdx.x;
+    const float mu = mean[m], is = istd[m];
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const size_t i = (size_t)m * N + n;
+        const float xh = ((z[i] + b[n]) - mu) * is;
+        float g = dy[i];
+        if (mask) g = mask[i] ? g * drop_scale : 0.f;
+        if (relu && !(xh * nw[n] + nb[n] > 0.f)) g = 0.f;
+        gbuf[i] = g;
+        const double gh = (double)g * (double)nw[n];
+        s1 += gh;
+        s2 += gh * (double)xh;
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) s1 += shfl_xor_f64(s1, k), s2 += shfl_xor_f64(s2, k);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s1, red[1][threadIdx.x >> 6] = s2;
+    __syncthreads();
+    const float c1 = (float)(((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / N);
+    const float c2 = (float)(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / N);
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const size_t i = (size_t)m * N + n;
+        const float xh = ((z[i] + b[n]) - mu) * is;
+        dz[i] = is * (gbuf[i] * nw[n] - c1 - xh * c2);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+fc_bwd_ln_cols_kernel(const float *__restrict__ gbuf, const float *__restrict__ dz, const float *__restrict__ z,
+                      const float *__restrict__ b, const float *__restrict__ mean, const float *__restrict__ istd, int M, int N,
+                      float *__restrict__ dnw, float *__restrict__ dnb, float *__restrict__ db) {
+    __shared__ double red[8][3][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + cl;
+    double a = 0.0, c = 0.0, e = 0.0;
+    if (n < N)
+        for (int m = rl; m < M; m += 8) {
+            const size_t i = (size_t)m * N + n;
+            const float xh = ((z[i] + b[n]) - mean[m]) * istd[m];
+            a += (double)gbuf[i] * (double)xh;
+            c += (double)gbuf[i];
+            e += (double)dz[i];
+        }
+    red[rl][0][cl] = a, red[rl][1][cl] = c, red[rl][2][cl] = e;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        a = c = e = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a += red[i][0][cl], c += red[i][1][cl], e += red[i][2][cl];
+        if (dnw) dnw[n] = (float)a;
+        if (dnb) dnb[n] = (float)c;
+        if (db) db[n] = (float)e;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct FcSaved {
+    float *z, *mean, *istd, *scale, *shift;
+    size_t bytes;
+};
+static FcSaved fc_saved_layout(const pnpp_fc_desc *d, void *base) {
+    Carver cv(base);
+    FcSaved s;
+    const int mx = d->M > d->N ? d->M : d->N;
+    s.z = cv.take<float>((size_t)d->M * d->N);
+    s.mean = cv.take<float>(mx);
+    s.istd = cv.take<float>(mx);
+    s.scale = cv.take<float>(d->N);
+    s.shift = cv.take<float>(d->N);
+    s.bytes = cv.bytes();
+    return s;
+}
+struct FcScratch {
+    float *wt, *dz, *gbuf, *dwslab;
+    double *slab;
+    size_t bytes;
+};
+static FcScratch fc_scratch_layout(const pnpp_fc_desc *d, void *base) {
+    Carver cv(base);
+    FcScratch s;
+    s.wt = cv.take<float>((size_t)d->K * d->N);
+    s.slab = cv.take<double>((size_t)kMaxStatBlocks * 2 * d->N);
+    s.dz = cv.take<float>((size_t)d->M * d->N);
+    s.gbuf = cv.take<float>((size_t)d->M * d->N);
+    int nsplit, kp_pad;
+    dw_plan(d->M, d->N, d->K, &nsplit, &kp_pad);
+    s.dwslab = cv.take<float>((size_t)nsplit * d->N * kp_pad);
+    s.bytes = cv.bytes();
+    return s;
+}
+
+static int fc_check(const pnpp_fc_desc *d) {
+    PNPP_REQUIRE(d, PNPP_ERR_ARG, "fc: null descriptor");
+    PNPP_REQUIRE(d->M > 0 && d->K > 0 && d->N > 0, PNPP_ERR_ARG, "fc: non-positive size M=%d K=%d N=%d", d->M, d->K, d->N);
+    PNPP_REQUIRE(d->K % 4 == 0 && d->N % 4 == 0, PNPP_ERR_ARG, "fc: K=%d and N=%d must be multiples of 4", d->K, d->N);
+    PNPP_REQUIRE(d->norm >= PNPP_NORM_NONE && d->norm <= PNPP_NORM_LAYER, PNPP_ERR_ARG, "fc: bad norm kind %d", d->norm);
+    return PNPP_OK;
+}
+
+static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hipStream_t st) {
+    PNPP_TRY(fc_check(d));
+    PNPP_REQUIRE(a && a->x && a->w && a->b && a->y && a->saved && a->scratch, PNPP_ERR_ARG, "fc_forward: null pointer");
+    if (d->norm != PNPP_NORM_NONE) PNPP_REQUIRE(a->nw && a->nb, PNPP_ERR_ARG, "fc_forward: norm affine parameters are null");
+    if (d->norm == PNPP_NORM_BATCH) PNPP_REQUIRE(a->rm && a->rv, PNPP_ERR_ARG, "fc_forward: running statistics are null");
+    const FcSaved sv = fc_saved_layout(d, a->saved);
+    const FcScratch sc = fc_scratch_layout(d, a->scratch);
+
+    PrepItem it{a->w, sc.wt, nullptr, d->N, d->K, d->K, -1};
+    PNPP_TRY(launch_prep_weights(&it, 1, st));
+    AOperand A;
+    A.mode = A_PLAIN;
+    A.a = a->x;
+    A.lda = d->K;
+    Epilogue E;
+    E.c = sv.z;
+    E.ldc = d->N;
+    const size_t total = (size_t)d->M * d->N;
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (d->norm == PNPP_NORM_BATCH) {
+        int nslab = 0;
+        if (d->training) {
+            PNPP_REQUIRE(d->M > 1, PNPP_ERR_ARG, "Expected more than 1 value per channel when training");  // torch's message
+            E.mode = E_STORE_STATS;
+            E.slab = sc.slab;
+            PNPP_TRY(launch_gemm(A, sc.wt, d->N, d->M, d->N, d->K, E, &nslab, st));
+        } else {
+            E.mode = E_STORE;
+            PNPP_TRY(launch_gemm(A, sc.wt, d->N, d->M, d->N, d->K, E, nullptr, st));
+        }
+        PNPP_TRY(launch_bn_finalize_fwd(sc.slab, nslab, d->N, (double)d->M, a->b, a->nw, a->nb, a->rm, a->rv, d->momentum, d->eps,
+                                        d->training, sv.mean, sv.istd, sv.scale, sv.shift, st));
+        hipLaunchKernelGGL(fc_apply_cols_kernel, dim3(grid), dim3(256), 0, st, sv.z, sv.scale, sv.shift, a->mask, d->drop_scale,
+                           d->relu, d->M, d->N, a->y);
+    } else {
+        E.mode = E_STORE;
+        PNPP_TRY(launch_gemm(A, sc.wt, d->N, d->M, d->N, d->K, E, nullptr, st));
+        if (d->norm == PNPP_NORM_LAYER) {
+            hipLaunchKernelGGL(fc_apply_ln_kernel, dim3(d->M), dim3(256), 0, st, sv.z, a->b, a->nw, a->nb, a->mask, d->drop_scale,
+                               d->relu, d->N, d->eps, a->y, sv.mean, sv.istd);
+        } else {
+            hipLaunchKernelGGL(fc_apply_cols_kernel, dim3(grid), dim3(256), 0, st, sv.z, (const float *)nullptr, a->b, a->mask,
+                               d->drop_scale, d->relu, d->M, d->N, a->y);
+        }
+    }
+    PNPP_CHECK_LAUNCH("fc_forward");
+    return PNPP_OK;
+}
+
+static int fc_backward_impl(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, hipStream_t st) {
+    PNPP_TRY(fc_check(d));
+    PNPP_REQUIRE(a && a->x && a->w && a->b && a->dy && a->saved && a->scratch && a->dw && a->db, PNPP_ERR_ARG,
+                 "fc_backward: null pointer");
+    if (d->norm != PNPP_NORM_NONE) PNPP_REQUIRE(a->nw && a->nb, PNPP_ERR_ARG, "fc_backward: norm affine parameters are null");
+    const FcSaved sv = fc_saved_layout(d, const_cast<void *>(a->saved));
+    const FcScratch sc = fc_scratch_layout(d, a->scratch);
+
+    // 1. dz = d loss / d (x W^T)  (M x N) and the parameter gradients of the normalisation
+    if (d->norm == PNPP_NORM_LAYER) {
+        hipLaunchKernelGGL(fc_bwd_ln_rows_kernel, dim3(d->M), dim3(256), 0, st, a->dy, sv.z, a->b, a->nw, a->nb, a->mask,
+                           d->drop_scale, d->relu, sv.mean, sv.istd, d->N, sc.dz, sc.gbuf);
+        hipLaunchKernelGGL(fc_bwd_ln_cols_kernel, dim3(cdiv(d->N, 32)), dim3(256), 0, st, sc.gbuf, sc.dz, sv.z, a->b, sv.mean,
+                           sv.istd, d->M, d->N, a->dnw, a->dnb, a->db);
+    } else {
+        const int bn = d->norm == PNPP_NORM_BATCH;
+        hipLaunchKernelGGL(fc_bwd_cols_kernel, dim3(cdiv(d->N, 32)), dim3(256), 0, st, a->dy, sv.z, a->mask, d->drop_scale,
+                           d->relu, bn, sv.scale, sv.shift, sv.mean, sv.istd, a->b, d->M, d->N, d->training, sc.dz, a->dnw,
+                           a->dnb, a->db);
+    }
+    PNPP_CHECK_LAUNCH("fc_backward");
+
+    // 2. dW = dz^T x
+    AOperand dz;
+    dz.mode = A_PLAIN;
+    dz.a = sc.dz;
+    dz.lda = d->N;
+    AOperand x;
+    x.mode = A_PLAIN;
+    x.a = a->x;
+    x.lda = d->K;
+    int nsplit, kp_pad;
+    dw_plan(d->M, d->N, d->K, &nsplit, &kp_pad);
+    PNPP_TRY(launch_dw(dz, d->N, x, d->K, d->M, sc.dwslab, nsplit, kp_pad, st));
+    PNPP_TRY(launch_slab_reduce(sc.dwslab, nsplit, d->N, kp_pad, d->K, -1, a->dw, d->K, st));
+
+    // 3. dx = dz W
+    if (a->dx) {
+        Epilogue E;
+        E.mode = E_STORE;
+        E.c = a->dx;
+        E.ldc = d->K;
+        PNPP_TRY(launch_gemm(dz, a->w, d->K, d->M, d->K, d->N, E, nullptr, st));
+    }
+    return PNPP_OK;
+}
+
+}  // namespace pnpp
+
+using namespace pnpp;
+
+extern "C" size_t pnpp_fc_saved_bytes(const pnpp_fc_desc *d) { return fc_check(d) == PNPP_OK ? fc_saved_layout(d, nullptr).bytes : 0; }
+extern "C" size_t pnpp_fc_scratch_bytes(const pnpp_fc_desc *d) {
+    return fc_check(d) == PNPP_OK ? fc_scratch_layout(d, nullptr).bytes : 0;
+}
+extern "C" int pnpp_fc_forward(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, void *stream) {
+    return fc_forward_impl(d, a, as_stream(stream));
+}
+extern "C" int pnpp_fc_backward(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, void *stream) {
+    return fc_backward_impl(d, a, as_stream(stream));
+}

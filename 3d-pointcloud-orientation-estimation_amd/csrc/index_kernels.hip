@@ -1,0 +1,468 @@
+// index_kernels.hip -- sampling / neighbour search / gather kernels for gfx950 (MI355X).
+//
+// Everything here is integer-, compare- or copy-bound (HBM/LDS bound, no MFMA): the design rules
+// are coalesced xyz reads, candidate tiles staged once per workgroup in LDS (SoA, conflict-free),
+// one 64-lane wavefront per query, and wave shuffles for the selection reductions.
+//
+// Bit-exactness: the float32 arithmetic below reproduces the evaluation order of the reference's
+// CPU PyTorch path (oracle/index_ops.c is the CPU restatement).  This file is
+// compiled with -ffp-contract=off and uses explicit fmaf where -- and only where -- ATen fuses.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace pnpp {
+
+// ---------------------------------------------------------------------------------------------
+// exact float32 recipes
+// ---------------------------------------------------------------------------------------------
+// models/base.py:25-26  torch.sum(p**2, -1): (x^2 + y^2) + z^2, unfused
+__device__ __forceinline__ float sq3_exact(float x, float y, float z) {
+    float s = __fmul_rn(x, x);
+    s = __fadd_rn(s, __fmul_rn(y, y));
+    s = __fadd_rn(s, __fmul_rn(z, z));
+    return s;
+}
+// models/base.py:24-26  -2*matmul (K=3 sgemm: fma chain) then += |a|^2 then += |b|^2
+__device__ __forceinline__ float pair_dist_exact(float ax, float ay, float az, float bx, float by, float bz, float sa,
+                                                 float sb) {
+    float dot = __fmaf_rn(az, bz, __fmaf_rn(ay, by, __fmul_rn(ax, bx)));
+    float d = __fmul_rn(-2.0f, dot);
+    d = __fadd_rn(d, sa);
+    d = __fadd_rn(d, sb);
+    return d;
+}
+// PointNet++Demo.py:25,63  torch.sum((a-b)**2, -1): direct form, unfused
+__device__ __forceinline__ float direct_dist_exact(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+    float d = __fmul_rn(dx, dx);
+    d = __fadd_rn(d, __fmul_rn(dy, dy));
+    d = __fadd_rn(d, __fmul_rn(dz, dz));
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// square_distance: one thread per output element, n fastest (coalesced 4-byte stores)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) square_distance_kernel(const float *__restrict__ src,
+                                                              const float *__restrict__ dst, int S, int N,
+                                                              float *__restrict__ out) {
+    const int b = blockIdx.z, s = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float *a = src + ((size_t)b * S + s) * 3;
+    const float *q = dst + ((size_t)b * N + n) * 3;
+    const float ax = a[0], ay = a[1], az = a[2];
+    const float bx = q[0], by = q[1], bz = q[2];
+    out[((size_t)b * S + s) * N + n] = pair_dist_exact(ax, ay, az, bx, by, bz, sq3_exact(ax, ay, az), sq3_exact(bx, by, bz));
+}
+
+// ---------------------------------------------------------------------------------------------
+// kNN grouping (models/base.py:29-35): one wavefront per query centre.
+//   * the cloud is staged tile by tile (TILE points) into LDS as x[],y[],z[],|p|^2[] (SoA);
+//   * every lane forms 64-bit keys (sortable(d) << 32 | n) for TILE/64 candidates in registers;
+//   * the current best-k list rides along as up to two extra candidates per lane;
+//   * k rounds of "wave-min, owner retires its key" emit the neighbours in ascending (d, n).
+// ---------------------------------------------------------------------------------------------
+constexpr int KNN_TILE = 1024;
+constexpr int KNN_CPL = KNN_TILE / 64;  // candidates per lane per tile
+constexpr int KNN_KMAX = 128;
+constexpr unsigned long long KEY_MAX = ~0ull;
+
+__global__ void __launch_bounds__(256) knn_kernel(const float *__restrict__ new_xyz, const float *__restrict__ xyz, int S,
+                                                  int N, int k, int32_t *__restrict__ idx) {
+    __shared__ float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE], sn[KNN_TILE];
+    __shared__ unsigned long long best[4][KNN_KMAX];
+
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + wave;
+    const bool active = q < S;  // wave-uniform
+    float ax = 0.f, ay = 0.f, az = 0.f, sa = 0.f;
+    if (active) {
+        const float *a = new_xyz + ((size_t)b * S + q) * 3;
+        ax = a[0], ay = a[1], az = a[2];
+        sa = sq3_exact(ax, ay, az);
+    }
+    best[wave][lane] = KEY_MAX;
+    best[wave][lane + 64] = KEY_MAX;
+
+    const float *cloud = xyz + (size_t)b * N * 3;
+    for (int t0 = 0; t0 < N; t0 += KNN_TILE) {
+        __syncthreads();  // previous tile fully consumed (also orders the best[] initialisation)
+        const int cnt = min(KNN_TILE, N - t0);
+        // coalesced stage: 3*cnt consecutive floats, de-interleaved into SoA
+        for (int i = threadIdx.x; i < cnt * 3; i += 256) {
+            float v = cloud[(size_t)t0 * 3 + i];
+            int p = i / 3, c = i - p * 3;
+            (c == 0 ? sx : c == 1 ? sy : sz)[p] = v;
+        }
+        __syncthreads();
+        for (int p = threadIdx.x; p < cnt; p += 256) sn[p] = sq3_exact(sx[p], sy[p], sz[p]);
+        __syncthreads();
+        if (!active) continue;
+
+        unsigned long long key[KNN_CPL + 2];
+#pragma unroll
+        for (int j = 0; j < KNN_CPL; ++j) {
+            const int p = j * 64 + lane;
+            if (p < cnt) {
+                float d = pair_dist_exact(ax, ay, az, sx[p], sy[p], sz[p], sa, sn[p]);
+                key[j] = ((unsigned long long)f32_sortable(d) << 32) | (unsigned)(t0 + p);
+            } else {
+                key[j] = KEY_MAX;
+            }
+        }
+        key[KNN_CPL] = best[wave][lane];
+        key[KNN_CPL + 1] = best[wave][lane + 64];
+
+        unsigned long long lmin = KEY_MAX;
+#pragma unroll
+        for (int j = 0; j < KNN_CPL + 2; ++j) lmin = key[j] < lmin ? key[j] : lmin;
+
+        for (int it = 0; it < k; ++it) {
+            const unsigned long long w = wave_min_u64(lmin);
+            if (lane == 0) best[wave][it] = w;  // safe: old best[] already copied into registers
+            if (lmin == w && w != KEY_MAX) {    // keys are unique (index in the low word): one owner
+                unsigned long long m2 = KEY_MAX;
+#pragma unroll
+                for (int j = 0; j < KNN_CPL + 2; ++j) {
+                    if (key[j] == w) key[j] = KEY_MAX;
+                    m2 = key[j] < m2 ? key[j] : m2;
+                }
+                lmin = m2;
+            }
+        }
+        // lanes re-read best[] at the top of the next tile; make lane 0's writes visible to the wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    if (active) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int32_t *o = idx + ((size_t)b * S + q) * k;
+        for (int j = lane; j < k; j += 64) o[j] = (int32_t)(unsigned)(best[wave][j] & 0xffffffffu);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// farthest point sampling (PointNet++Demo.py:8-29): one workgroup per cloud.
+// xyz and the running min-distance live in LDS; one barrier per round (double-buffered wave maxima).
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__global__ void __launch_bounds__(T) fps_kernel(const float *__restrict__ xyz, int N, int npoint,
+                                                const int32_t *__restrict__ start, int32_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *sx = lds, *sy = lds + N, *sz = lds + 2 * N, *sd = lds + 3 * N;
+    __shared__ unsigned long long wmax[2][T / 64];
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *cloud = xyz + (size_t)b * N * 3;
+    for (int i = tid; i < N * 3; i += T) {
+        float v = cloud[i];
+        int p = i / 3, c = i - p * 3;
+        (c == 0 ? sx : c == 1 ? sy : sz)[p] = v;
+    }
+    for (int p = tid; p < N; p += T) sd[p] = 1e10f;
+    __syncthreads();
+
+    int far = start[b];
+    for (int it = 0; it < npoint; ++it) {
+        if (tid == 0) out[(size_t)b * npoint + it] = far;
+        const float cx = sx[far], cy = sy[far], cz = sz[far];
+        unsigned long long bestk = 0;  // (dist bits << 32) | (~n): larger distance first, then lower index
+        for (int p = tid; p < N; p += T) {
+            float d = direct_dist_exact(sx[p], sy[p], sz[p], cx, cy, cz);
+            float cur = sd[p];
+            if (d < cur) {
+                cur = d;
+                sd[p] = d;
+            }
+            unsigned long long kk = ((unsigned long long)f32_sortable(cur) << 32) | (unsigned)(0xffffffffu - (unsigned)p);
+            bestk = kk > bestk ? kk : bestk;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            unsigned long long o = shfl_xor_u64(bestk, m);
+            bestk = o > bestk ? o : bestk;
+        }
+        if (lane == 0) wmax[it & 1][wave] = bestk;
+        __syncthreads();
+        unsigned long long g = 0;
+#pragma unroll
+        for (int w = 0; w < T / 64; ++w) {
+            unsigned long long o = wmax[it & 1][w];
+            g = o > g ? o : g;
+        }
+        far = (int)(0xffffffffu - (unsigned)(g & 0xffffffffu));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// radius ball query (PointNet++Demo.py:49-70): one wavefront per centre, ascending index scan,
+// ballot + prefix popcount compaction, early exit once nsample hits were written.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ball_query_kernel(const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+                                                         int S, int N, float r2, int nsample, int32_t *__restrict__ idx) {
+    __shared__ float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE];
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + wave;
+    const bool active = q < S;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    int32_t *o = nullptr;
+    if (active) {
+        const float *a = new_xyz + ((size_t)b * S + q) * 3;
+        ax = a[0], ay = a[1], az = a[2];
+        o = idx + ((size_t)b * S + q) * nsample;
+    }
+    int cnt = 0, first = N;  // wave-uniform
+    const float *cloud = xyz + (size_t)b * N * 3;
+    for (int t0 = 0; t0 < N; t0 += KNN_TILE) {
+        __syncthreads();
+        const int tc = min(KNN_TILE, N - t0);
+        for (int i = threadIdx.x; i < tc * 3; i += 256) {
+            float v = cloud[(size_t)t0 * 3 + i];
+            int p = i / 3, c = i - p * 3;
+            (c == 0 ? sx : c == 1 ? sy : sz)[p] = v;
+        }
+        __syncthreads();
+        if (!active || cnt >= nsample) continue;
+        for (int c0 = 0; c0 < tc && cnt < nsample; c0 += 64) {
+            const int p = c0 + lane;
+            bool in = false;
+            if (p < tc) {
+                float d = direct_dist_exact(ax, ay, az, sx[p], sy[p], sz[p]);
+                in = !(d > r2);
+            }
+            const unsigned long long m = __ballot(in);
+            if (m == 0ull) continue;
+            if (first == N) first = t0 + c0 + (__ffsll((long long)m) - 1);
+            const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+            if (in && pos < nsample) o[pos] = t0 + p;
+            cnt += __popcll(m);
+        }
+    }
+    if (active) {
+        cnt = min(cnt, nsample);
+        for (int j = cnt + lane; j < nsample; j += 64) o[j] = first;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-side centre sampling: uniform random ordered subset (replaces B host randperm calls).
+// key(n) = Philox4x32-10(counter = (n, b, stream_lo, stream_hi), key = seed); rank by (key, n);
+// out[rank] = n for rank < npoint.  O(N^2) compares per cloud against an LDS-resident key table
+// (broadcast reads), fully deterministic.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned philox_key(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+        unsigned n1 = (unsigned)p1;
+        unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        unsigned n3 = (unsigned)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+__global__ void __launch_bounds__(256) sample_random_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_lo,
+                                                            unsigned str_hi, int N, int npoint, int32_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned keys[];
+    const int b = blockIdx.y;
+    for (int n = threadIdx.x; n < N; n += 256) keys[n] = philox_key((unsigned)n, (unsigned)b, str_lo, str_hi, seed_lo, seed_hi);
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const unsigned mine = keys[n];
+    int rank = 0;
+    for (int m = 0; m < N; ++m) {
+        const unsigned o = keys[m];
+        rank += (o < mine) || (o == mine && m < n);
+    }
+    if (rank < npoint) out[(size_t)b * npoint + rank] = n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// index_points (models/base.py:4-18): row gather, 16-byte vectors when C % 4 == 0
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float *__restrict__ points, const int32_t *__restrict__ idx,
+                                                          int N, int C, int M, size_t total_vec, int vec,
+                                                          float *__restrict__ out) {
+    const int cv = C / vec;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / cv;
+        const int c = (int)(i - row * cv) * vec;
+        const int b = (int)(row / M);
+        const int n = idx[row];
+        const float *s = points + ((size_t)b * N + n) * C + c;
+        float *d = out + row * C + c;
+        if (vec == 4) {
+            *reinterpret_cast<float4 *>(d) = *reinterpret_cast<const float4 *>(s);
+        } else {
+            *d = *s;
+        }
+    }
+}
+
+// backward of the gather: one wavefront per destination row (b,n); the cloud's M indices are scanned
+// in order, so duplicate contributions are added in a fixed order (bitwise reproducible, no atomics).
+__global__ void __launch_bounds__(64) scatter_rows_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ idx,
+                                                              int N, int C, int M, float *__restrict__ dpoints) {
+    const int b = blockIdx.y, n = blockIdx.x, lane = threadIdx.x;
+    const int32_t *ib = idx + (size_t)b * M;
+    const float *db = dout + (size_t)b * M * C;
+    for (int c0 = 0; c0 < C; c0 += 64 * 8) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int m0 = 0; m0 < M; m0 += 64) {
+            const int m = m0 + lane;
+            unsigned long long hit = __ballot(m < M && ib[m] == n);
+            while (hit) {
+                const int p = __ffsll((long long)hit) - 1;
+                hit &= hit - 1;
+                const float *r = db + (size_t)(m0 + p) * C + c0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = j * 64 + lane;
+                    if (c0 + c < C) acc[j] += r[c];
+                }
+            }
+        }
+        float *d = dpoints + ((size_t)b * N + n) * C + c0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = j * 64 + lane;
+            if (c0 + c < C) d[c] += acc[j];
+        }
+    }
+}
+
+// gather of centre coordinates new_xyz[b,s,:] = xyz[b, centre[b,s], :]
+__global__ void __launch_bounds__(256) gather_centres_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ centre,
+                                                             int N, int S, int total, float *__restrict__ new_xyz) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / S;
+    const int n = centre[i];
+    const float *s = xyz + ((size_t)b * N + n) * 3;
+    new_xyz[(size_t)i * 3 + 0] = s[0];
+    new_xyz[(size_t)i * 3 + 1] = s[1];
+    new_xyz[(size_t)i * 3 + 2] = s[2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers (internal C++ API, used by the C ABI and by the set-abstraction orchestrator)
+// ---------------------------------------------------------------------------------------------
+int launch_knn(const float *new_xyz, const float *xyz, int B, int S, int N, int k, int32_t *idx, hipStream_t st) {
+    PNPP_REQUIRE(new_xyz && xyz && idx, PNPP_ERR_ARG, "knn: null pointer");
+    PNPP_REQUIRE(B > 0 && S > 0 && N > 0 && k > 0, PNPP_ERR_ARG, "knn: non-positive size (B=%d S=%d N=%d k=%d)", B, S, N, k);
+    PNPP_REQUIRE(k <= N, PNPP_ERR_RANGE, "selected index k out of range (k=%d > N=%d)", k, N);
+    PNPP_REQUIRE(k <= KNN_KMAX, PNPP_ERR_ARG, "knn: nsample=%d exceeds the supported maximum %d", k, KNN_KMAX);
+    PNPP_REQUIRE(B <= 65535, PNPP_ERR_ARG, "knn: batch %d exceeds grid limit", B);
+    hipLaunchKernelGGL(knn_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, st, new_xyz, xyz, S, N, k, idx);
+    PNPP_CHECK_LAUNCH("knn");
+    return PNPP_OK;
+}
+
+int launch_gather_centres(const float *xyz, const int32_t *centre, int B, int N, int S, float *new_xyz, hipStream_t st) {
+    const int total = B * S;
+    hipLaunchKernelGGL(gather_centres_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, xyz, centre, N, S, total, new_xyz);
+    PNPP_CHECK_LAUNCH("gather_centres");
+    return PNPP_OK;
+}
+
+int launch_scatter_rows_bwd(const float *dout, const int32_t *idx, int B, int N, int C, int M, float *dpoints, hipStream_t st) {
+    PNPP_REQUIRE(B <= 65535, PNPP_ERR_ARG, "index_points_bwd: batch %d exceeds grid limit", B);
+    hipLaunchKernelGGL(scatter_rows_bwd_kernel, dim3(N, B), dim3(64), 0, st, dout, idx, N, C, M, dpoints);
+    PNPP_CHECK_LAUNCH("index_points_bwd");
+    return PNPP_OK;
+}
+
+}  // namespace pnpp
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+using namespace pnpp;
+
+extern "C" int pnpp_square_distance(const float *src, const float *dst, int B, int S, int N, float *out, void *stream) {
+    PNPP_REQUIRE(src && dst && out, PNPP_ERR_ARG, "square_distance: null pointer");
+    PNPP_REQUIRE(B > 0 && S > 0 && N > 0, PNPP_ERR_ARG, "square_distance: non-positive size");
+    PNPP_REQUIRE(B <= 65535 && S <= 65535, PNPP_ERR_ARG, "square_distance: B or S exceeds grid limit");
+    hipLaunchKernelGGL(square_distance_kernel, dim3(cdiv(N, 256), S, B), dim3(256), 0, as_stream(stream), src, dst, S, N, out);
+    PNPP_CHECK_LAUNCH("square_distance");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_knn(const float *new_xyz, const float *xyz, int B, int S, int N, int k, int32_t *idx, void *stream) {
+    return launch_knn(new_xyz, xyz, B, S, N, k, idx, as_stream(stream));
+}
+
+extern "C" int pnpp_fps(const float *xyz, int B, int N, int npoint, const int32_t *start, int32_t *out, void *stream) {
+    PNPP_REQUIRE(xyz && start && out, PNPP_ERR_ARG, "fps: null pointer");
+    PNPP_REQUIRE(B > 0 && N > 0 && npoint > 0, PNPP_ERR_ARG, "fps: non-positive size");
+    const size_t lds = (size_t)N * 4 * sizeof(float);
+    PNPP_REQUIRE(lds <= 160 * 1024 - 1024, PNPP_ERR_ARG, "fps: N=%d does not fit the 160 KiB LDS of one CU", N);
+    hipStream_t st = as_stream(stream);
+    if (N <= 4096) {
+        auto kfn = fps_kernel<256>;
+        if (lds > 48 * 1024) hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kfn, dim3(B), dim3(256), lds, st, xyz, N, npoint, start, out);
+    } else {
+        auto kfn = fps_kernel<1024>;
+        hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kfn, dim3(B), dim3(1024), lds, st, xyz, N, npoint, start, out);
+    }
+    PNPP_CHECK_LAUNCH("fps");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_ball_query(const float *new_xyz, const float *xyz, int B, int S, int N, float radius, int nsample,
+                               int32_t *idx, void *stream) {
+    PNPP_REQUIRE(new_xyz && xyz && idx, PNPP_ERR_ARG, "ball_query: null pointer");
+    PNPP_REQUIRE(B > 0 && S > 0 && N > 0 && nsample > 0, PNPP_ERR_ARG, "ball_query: non-positive size");
+    PNPP_REQUIRE(B <= 65535, PNPP_ERR_ARG, "ball_query: batch exceeds grid limit");
+    const float r2 = (float)((double)radius * (double)radius);  // Demo.py:65: python float squared, compared in float32
+    hipLaunchKernelGGL(ball_query_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, as_stream(stream), new_xyz, xyz, S, N, r2,
+                       nsample, idx);
+    PNPP_CHECK_LAUNCH("ball_query");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_sample_random(uint64_t seed, uint64_t stream_id, int B, int N, int npoint, int32_t *out, void *stream) {
+    PNPP_REQUIRE(out, PNPP_ERR_ARG, "sample_random: null pointer");
+    PNPP_REQUIRE(B > 0 && N > 0 && npoint > 0, PNPP_ERR_ARG, "sample_random: non-positive size");
+    PNPP_REQUIRE(npoint <= N, PNPP_ERR_RANGE, "sample_random: npoint=%d > N=%d", npoint, N);
+    PNPP_REQUIRE((size_t)N * 4 <= 128 * 1024, PNPP_ERR_ARG, "sample_random: N=%d too large", N);
+    PNPP_REQUIRE(B <= 65535, PNPP_ERR_ARG, "sample_random: batch exceeds grid limit");
+    const size_t lds = (size_t)N * sizeof(unsigned);
+    if (lds > 48 * 1024)
+        hipFuncSetAttribute((const void *)sample_random_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(sample_random_kernel, dim3(cdiv(N, 256), B), dim3(256), lds, as_stream(stream), (unsigned)seed,
+                       (unsigned)(seed >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32), N, npoint, out);
+    PNPP_CHECK_LAUNCH("sample_random");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_index_points(const float *points, const int32_t *idx, int B, int N, int C, int M, float *out, void *stream) {
+    PNPP_REQUIRE(points && idx && out, PNPP_ERR_ARG, "index_points: null pointer");
+    PNPP_REQUIRE(B > 0 && N > 0 && C > 0 && M > 0, PNPP_ERR_ARG, "index_points: non-positive size");
+    const int vec = (C % 4 == 0 && ((uintptr_t)points % 16 == 0) && ((uintptr_t)out % 16 == 0)) ? 4 : 1;
+    const size_t total = (size_t)B * M * (C / vec);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), points, idx, N, C, M, total, vec, out);
+    PNPP_CHECK_LAUNCH("index_points");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_index_points_bwd(const float *dout, const int32_t *idx, int B, int N, int C, int M, float *dpoints,
+                                     void *stream) {
+    PNPP_REQUIRE(dout && idx && dpoints, PNPP_ERR_ARG, "index_points_bwd: null pointer");
+    PNPP_REQUIRE(B > 0 && N > 0 && C > 0 && M > 0, PNPP_ERR_ARG, "index_points_bwd: non-positive size");
+    return launch_scatter_rows_bwd(dout, idx, B, N, C, M, dpoints, as_stream(stream));
+}

@@ -1,0 +1,90 @@
+// kernels.h -- internal launcher interface between the kernel translation units and the C ABI.
+#pragma once
+#include "common.h"
+
+namespace pnpp {
+
+// ---- index_kernels.hip ----
+int launch_knn(const float *new_xyz, const float *xyz, int B, int S, int N, int k, int32_t *idx, hipStream_t st);
+int launch_gather_centres(const float *xyz, const int32_t *centre, int B, int N, int S, float *new_xyz, hipStream_t st);
+int launch_scatter_rows_bwd(const float *dout, const int32_t *idx, int B, int N, int C, int M, float *dpoints, hipStream_t st);
+
+// ---- gemm_kernels.hip ----
+// How the A operand (activation rows) of a fused GEMM is produced on the fly.
+enum AMode {
+    A_PLAIN = 0,   // A[row][k]
+    A_BNRELU = 1,  // relu(A[row][k] * scale[k] + shift[k])           (BatchNorm apply + ReLU of the previous layer)
+    A_GATHER = 2,  // [points[b, idx[row], :D] | xyz[b, idx[row]] - new_xyz[row / K] | 0]   (grouping, features first)
+    A_CONCAT = 3,  // [points[row, :D] | xyz[row] | 0]                                     (group_all)
+    A_DZ = 4       // g[c] * (dy[row][c] - c1[c] - (Z[row][c] - mu[c]) * istd[c] * c2[c])  (BatchNorm backward)
+};
+
+struct AOperand {
+    int mode = A_PLAIN;
+    const float *a = nullptr;  // PLAIN/BNRELU: matrix; GATHER/CONCAT: points; DZ: dy
+    int lda = 0;
+    const float *scale = nullptr, *shift = nullptr;  // BNRELU
+    const float *xyz = nullptr, *new_xyz = nullptr;  // GATHER/CONCAT
+    const int32_t *idx = nullptr;                    // GATHER
+    int D = 0, N = 0, S = 0, K = 0;                  // GATHER/CONCAT geometry (N points, S centres per cloud, K neighbours)
+    const float *z = nullptr;                        // DZ: pre-BN activations of the same layer
+    const float *cst = nullptr;                      // DZ: [5][C] = g, mu, istd, c1, c2
+    int C = 0;                                       // DZ: channel count (row pitch of cst)
+};
+
+// What happens to each accumulator element.
+enum EMode {
+    E_STORE = 0,        // C[row][col] = acc
+    E_STORE_STATS = 1,  // + per-column sum / sum of squares (float64 partials -> slab)
+    E_MASK_STATS = 2    // v = acc * [scale*Zp+shift > 0]; C = v; stats: sum v, sum v * xhat(Zp)
+};
+
+struct Epilogue {
+    int mode = E_STORE;
+    float *c = nullptr;
+    int ldc = 0;
+    double *slab = nullptr;  // [gridDim.x][2][Nout]
+    const float *zp = nullptr;  // MASK_STATS: previous layer's pre-BN activations, pitch ldc
+    const float *scale = nullptr, *shift = nullptr, *mu = nullptr, *istd = nullptr;
+};
+
+// C[M x Nout] = A'[M x Kd] * Bm[Kd x Nout] (Bm row-major, pitch ldb).  Returns the number of
+// statistic slabs written (gridDim.x) through *nslab when the epilogue collects statistics.
+int launch_gemm(const AOperand &A, const float *Bm, int ldb, int M, int Nout, int Kd, const Epilogue &E, int *nslab,
+                hipStream_t st);
+
+// dW[Nc x Kp] = dZ^T[Nc x M] * A2[M x Kp], split over `nsplit` row ranges into slab[nsplit][Nc][kp_pad].
+// dz is produced as in A_DZ (or read directly when dz.mode == A_PLAIN); A2 by its own AOperand.
+int launch_dw(const AOperand &dz, int Nc, const AOperand &a2, int Kp, int M, float *slab, int nsplit, int kp_pad,
+              hipStream_t st);
+// picks the split count / padded pitch launch_dw will use (so callers can size the slab)
+void dw_plan(int M, int Nc, int Kp, int *nsplit, int *kp_pad);
+// out[c][perm(k)] = sum_s slab[s][c][k]; perm_D < 0: identity; else feature-first -> xyz-first column order.
+int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kvalid, int perm_D, float *out, int ldo,
+                       hipStream_t st);
+
+struct PrepItem {
+    const float *w;  // (Cout, Cin) row-major
+    float *wt;       // out (Kd, Cout): transposed, features-first for layer 0
+    float *wperm;    // out (Cout, Kd) or nullptr: features-first copy (layer 0 only)
+    int Cout, Cin, Kd, perm_D;  // perm_D < 0: no permutation
+};
+int launch_prep_weights(const PrepItem *items, int n, hipStream_t st);
+
+int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, const float *bias, const float *gamma,
+                           const float *beta, float *rm, float *rv, float momentum, float eps, int training, float *mean,
+                           float *istd, float *scale, float *shift, hipStream_t st);
+int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, int training, const float *gamma,
+                           const float *mean, const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias,
+                           hipStream_t st);
+
+int launch_pool_fwd(const float *z, const float *scale, const float *shift, int G, int K, int C, float *out, int32_t *arg,
+                    hipStream_t st);
+// expands the pooled gradient to dense dy (G*K x C) and collects the BatchNorm-backward column sums
+int launch_pool_bwd(const float *dout, const int32_t *arg, const float *z, const float *scale, const float *shift,
+                    const float *mean, const float *istd, int G, int K, int C, float *dy, double *slab, int *nslab,
+                    hipStream_t st);
+
+int launch_fill_zero(void *p, size_t bytes, hipStream_t st);
+
+}  // namespace pnpp

@@ -1,0 +1,450 @@
+// loss_kernels.hip -- output heads, von-Mises KL losses (value + analytic gradient in one launch),
+// soft-label cross entropy, and the flat-buffer optimiser glue.
+//
+// These are O(batch) scalar kernels: latency-bound, one thread per sample.  All transcendental
+// work is done in float64 (fp64 VALU is cheap on CDNA4 and B is tiny) and rounded once to float32.
+//
+// Bessel functions: exponentially scaled I0e / I1e by the Cephes Chebyshev expansions (the same
+// tables ATen's torch.special.i0/i1 evaluate, BSD-licensed Cephes Math Library constants);
+// log I0(k) = k + log(i0e(k)) never overflows, A(k) = I1/I0 = i1e/i0e, A'(k) = 1 - A^2 - A/k.
+#include "kernels.h"
+
+namespace pnpp {
+
+__device__ const double kI0eA[30] = {
+    -4.41534164647933937950E-18, 3.33079451882223809783E-17,  -2.43127984654795469359E-16, 1.71539128555513303061E-15,
+    -1.16853328779934516808E-14, 7.67618549860493561688E-14,  -4.85644678311192946090E-13, 2.95505266312963983461E-12,
+    -1.72682629144155570723E-11, 9.67580903537323691224E-11,  -5.18979560163526290666E-10, 2.65982372468238665035E-9,
+    -1.30002500998624804212E-8,  6.04699502254191894932E-8,   -2.67079385394061173391E-7,  1.11738753912010371815E-6,
+    -4.41673835845875056359E-6,  1.64484480707288970893E-5,   -5.75419501008210370398E-5,  1.88502885095841655729E-4,
+    -5.76375574538582365885E-4,  1.63947561694133579842E-3,   -4.32430999505057594430E-3,  1.05464603945949983183E-2,
+    -2.37374148058994688156E-2,  4.93052842396707084878E-2,   -9.49010970480476444210E-2,  1.71620901522208775349E-1,
+    -3.04682672343198398683E-1,  6.76795274409476084995E-1};
+__device__ const double kI0eB[25] = {
+    -7.23318048787475395456E-18, -4.83050448594418207126E-18, 4.46562142029675999901E-17,  3.46122286769746109310E-17,
+    -2.82762398051658348494E-16, -3.42548561967721913462E-16, 1.77256013305652638360E-15,  3.81168066935262242075E-15,
+    -9.55484669882830764870E-15, -4.15056934728722208663E-14, 1.54008621752140982691E-14,  3.85277838274214270114E-13,
+    7.18012445138366623367E-13,  -1.79417853150680611778E-12, -1.32158118404477131188E-11, -3.14991652796324136454E-11,
+    1.18891471078464383424E-11,  4.94060238822496958910E-10,  3.39623202570838634515E-9,   2.26666899049817806459E-8,
+    2.04891858946906374183E-7,   2.89137052083475648297E-6,   6.88975834691682398426E-5,   3.36911647825569408990E-3,
+    8.04490411014108831608E-1};
+__device__ const double kI1eA[29] = {
+    2.77791411276104639959E-18, -2.11142121435816608115E-17, 1.55363195773620046921E-16, -1.10559694773538630805E-15,
+    7.60068429473540693410E-15, -5.04218550472791168711E-14, 3.22379336594557470981E-13, -1.98397439776494371520E-12,
+    1.17361862988909016308E-11, -6.66348972350202774223E-11, 3.62559028155211703701E-10, -1.88724975172282928790E-9,
+    9.38153738649577178388E-9,  -4.44505912879632808065E-8,  2.00329475355213526229E-7,  -8.56872026469545474066E-7,
+    3.47025130813767847674E-6,  -1.32731636560394358279E-5,  4.78156510755005422638E-5,  -1.61760815825896745588E-4,
+    5.12285956168575772895E-4,  -1.51357245063125314899E-3,  4.15642294431288815669E-3,  -1.05640848946261981558E-2,
+    2.47264490306265168283E-2,  -5.29459812080949914269E-2,  1.02643658689847095384E-1,  -1.76416518357834055153E-1,
+    2.52587186443633654823E-1};
+__device__ const double kI1eB[25] = {
+    7.51729631084210481353E-18,  4.41434832307170791151E-18,  -4.65030536848935832153E-17, -3.20952592199342395980E-17,
+    2.96262899764595013876E-16,  3.30820231092092828324E-16,  -1.88035477551078244854E-15, -3.81440307243700780478E-15,
+    1.04202769841288027642E-14,  4.27244001671195135429E-14,  -2.10154184277266431302E-14, -4.08355111109219731823E-13,
+    -7.19855177624590851209E-13, 2.03562854414708950722E-12,  1.41258074366137813316E-11,  3.25260358301548823856E-11,
+    -1.89749581235054123450E-11, -5.58974346219658380687E-10, -3.83538038596423702205E-9,  -2.63146884688951950684E-8,
+    -2.51223623787020892529E-7,  -3.88256480887769039346E-6,  -1.10588938762623716291E-4,  -9.76109749136146840777E-3,
+    7.78576235018280120474E-1};
+
+__device__ __forceinline__ double chbevl(double x, const double *c, int n) {
+    double b0 = c[0], b1 = 0.0, b2 = 0.0;
+    for (int i = 1; i < n; ++i) {
+        b2 = b1;
+        b1 = b0;
+        b0 = x * b1 - b2 + c[i];
+    }
+    return 0.5 * (b0 - b2);
+}
+__device__ __forceinline__ double i0e(double x) {  // x >= 0
+    return x <= 8.0 ? chbevl(0.5 * x - 2.0, kI0eA, 30) : chbevl(32.0 / x - 2.0, kI0eB, 25) / sqrt(x);
+}
+__device__ __forceinline__ double i1e(double x) {  // x >= 0
+    return x <= 8.0 ? chbevl(0.5 * x - 2.0, kI1eA, 29) * x : chbevl(32.0 / x - 2.0, kI1eB, 25) / sqrt(x);
+}
+__device__ __forceinline__ double log_i0(double k) { return k + log(i0e(k)); }
+__device__ __forceinline__ double bessel_ratio(double k) { return i1e(k) / i0e(k); }
+__device__ __forceinline__ double bessel_ratio_prime(double k, double A) {
+    return k > 1e-8 ? 1.0 - A * A - A / k : 0.5;
+}
+
+constexpr double kPi = 3.14159265358979323846;
+
+// ---- single-peak KL, train_single_peak_vonMises_KL.py:23-28 --------------------------------------
+__device__ __forceinline__ void kl_single_eval(double mp, double kp, double mq, double kq, double &kl, double &dmu,
+                                               double &dk) {
+    const double d = mp - mq;
+    const double A = bessel_ratio(kp);
+    const double base = log_i0(kq) - log_i0(kp);
+    if (kp <= 1e-6) {  // a1 := 0 branch of line 26: only -log I0(kappa_p) depends on the prediction
+        kl = base;
+        dmu = 0.0;
+        dk = -A;
+    } else {
+        const double cd = cos(d), sd = sin(d);
+        kl = base + kp * A - kq * A * cd;
+        dmu = kq * A * sd;
+        dk = bessel_ratio_prime(kp, A) * (kp - kq * cd);
+    }
+}
+
+__global__ void __launch_bounds__(256) vm_kl_single_kernel(const float *__restrict__ mu_p, const float *__restrict__ kappa_p,
+                                                           const float *__restrict__ mu_q, const float *__restrict__ kappa_q,
+                                                           int n, float *__restrict__ kl, float *__restrict__ dmu,
+                                                           float *__restrict__ dkappa) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double v, a, b;
+    kl_single_eval((double)mu_p[i], (double)kappa_p[i], (double)mu_q[i], (double)kappa_q[i], v, a, b);
+    kl[i] = (float)v;
+    if (dmu) dmu[i] = (float)a;
+    if (dkappa) dkappa[i] = (float)b;
+}
+
+// fc3 output -> (mu, kappa) -> KL -> d/d(fc3 output); pointnet_pp_vonMises.py:36-37 fused with the loss
+__global__ void __launch_bounds__(256) vm_head_kl_kernel(const float *__restrict__ o, const float *__restrict__ mu_gt,
+                                                         const float *__restrict__ kappa_gt, int B, float *__restrict__ mu,
+                                                         float *__restrict__ kappa, float *__restrict__ loss_vec,
+                                                         float *__restrict__ d_o) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const double o0 = (double)o[2 * i], o1 = (double)o[2 * i + 1];
+    const double th = tanh(o0);
+    const float mu_f = (float)(th * kPi);                              // torch.tanh(out[:,0]) * np.pi
+    const double sp = o1 > 20.0 ? o1 : log1p(exp(o1));                 // F.softplus (beta 1, threshold 20)
+    const float kap_f = (float)sp;
+    mu[i] = mu_f;
+    kappa[i] = kap_f;
+    if (!loss_vec) return;
+    double v, a, b;
+    kl_single_eval((double)mu_f, (double)kap_f, (double)mu_gt[i], (double)kappa_gt[i], v, a, b);
+    loss_vec[i] = (float)v;
+    if (d_o) {
+        const double sig = o1 > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-o1));
+        d_o[2 * i] = (float)(a * kPi * (1.0 - th * th));
+        d_o[2 * i + 1] = (float)(b * sig);
+    }
+}
+
+__global__ void __launch_bounds__(256) vm_head_bwd_kernel(const float *__restrict__ o, const float *__restrict__ dmu,
+                                                          const float *__restrict__ dkappa, int B, float *__restrict__ d_o) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const double o0 = (double)o[2 * i], o1 = (double)o[2 * i + 1];
+    const double th = tanh(o0);
+    const double sig = o1 > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-o1));
+    d_o[2 * i] = (float)((double)dmu[i] * kPi * (1.0 - th * th));
+    d_o[2 * i + 1] = (float)((double)dkappa[i] * sig);
+}
+
+// ---- multi-peak KL + matching, train_multi_peaks_vonMises_KL.py:38-81 ----------------------------
+constexpr int MATCH_KMAX = 8;
+
+__device__ __forceinline__ void kl_multi_eval(double mp, double kp_raw, double mq, double kq_raw, double &kl, double &dmu,
+                                              double &dk) {
+    const double kp = fmin(fmax(kp_raw, 1e-6), 500.0), kq = fmin(fmax(kq_raw, 1e-6), 500.0);
+    double d = fmod(mp - mq + kPi, 2.0 * kPi);  // python %: result takes the sign of the divisor
+    if (d < 0.0) d += 2.0 * kPi;
+    d -= kPi;
+    const double A = bessel_ratio(kp);
+    const double cd = cos(d), sd = sin(d);
+    kl = (log_i0(kq) - log_i0(kp)) + A * (kp - kq * cd);
+    dmu = A * kq * sd;
+    const bool pass = kp_raw >= 1e-6 && kp_raw <= 500.0;  // clamp backward
+    dk = pass ? bessel_ratio_prime(kp, A) * (kp - kq * cd) : 0.0;
+}
+
+__global__ void __launch_bounds__(64) vm_match_loss_kernel(const float *__restrict__ mu, const float *__restrict__ kappa,
+                                                           const float *__restrict__ w, const float *__restrict__ vm_gt,
+                                                           const int32_t *__restrict__ K_gt, int B, int maxK,
+                                                           float *__restrict__ loss_vec, float *__restrict__ dmu,
+                                                           float *__restrict__ dkappa, float *__restrict__ dw,
+                                                           int32_t *__restrict__ assign) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    int K = K_gt[b];
+    if (K > maxK) K = maxK;
+    for (int i = 0; i < maxK; ++i) {
+        if (dmu) dmu[b * maxK + i] = 0.f;
+        if (dkappa) dkappa[b * maxK + i] = 0.f;
+        if (dw) dw[b * maxK + i] = 0.f;
+        if (assign) assign[b * maxK + i] = -1;
+    }
+    if (K <= 0) {
+        loss_vec[b] = 0.f;
+        return;
+    }
+    // cost matrix, rounded to float32 like the reference's cost tensor (line 66-73), with its gradients
+    float cost[MATCH_KMAX][MATCH_KMAX];
+    float gmu[MATCH_KMAX][MATCH_KMAX], gk[MATCH_KMAX][MATCH_KMAX];
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) {
+            double v, a, c;
+            kl_multi_eval((double)mu[b * maxK + i], (double)kappa[b * maxK + i], (double)vm_gt[(b * maxK + j) * 3 + 0],
+                          (double)vm_gt[(b * maxK + j) * 3 + 1], v, a, c);
+            float vf = (float)v;
+            if (!(fabsf(vf) <= 3.0e38f)) {  // nan_to_num(nan/+-inf -> 1e6): constant, no gradient
+                vf = 1e6f;
+                a = 0.0;
+                c = 0.0;
+            }
+            cost[i][j] = vf;
+            gmu[i][j] = (float)a;
+            gk[i][j] = (float)c;
+        }
+    // exhaustive optimal assignment in lexicographic permutation order, first optimum kept
+    int perm[MATCH_KMAX], bestp[MATCH_KMAX];
+    for (int i = 0; i < K; ++i) perm[i] = i;
+    double best = 1e300;
+    while (true) {
+        double t = 0.0;
+        for (int i = 0; i < K; ++i) t += (double)cost[i][perm[i]];
+        if (t < best) {
+            best = t;
+            for (int i = 0; i < K; ++i) bestp[i] = perm[i];
+        }
+        int i = K - 2;  // next lexicographic permutation
+        while (i >= 0 && perm[i] > perm[i + 1]) --i;
+        if (i < 0) break;
+        int j = K - 1;
+        while (perm[j] < perm[i]) --j;
+        int tmp = perm[i];
+        perm[i] = perm[j];
+        perm[j] = tmp;
+        for (int l = i + 1, r = K - 1; l < r; ++l, --r) {
+            tmp = perm[l];
+            perm[l] = perm[r];
+            perm[r] = tmp;
+        }
+    }
+    // loss_b = sum w_i c_i / (sum w_i + 1e-8)   (float32 arithmetic order of lines 77-80, evaluated in double)
+    double sw = 0.0, swc = 0.0;
+    for (int i = 0; i < K; ++i) {
+        sw += (double)w[b * maxK + i];
+        swc += (double)w[b * maxK + i] * (double)cost[i][bestp[i]];
+    }
+    const double S = sw + 1e-8;
+    loss_vec[b] = (float)(swc / S);
+    for (int i = 0; i < K; ++i) {
+        const double wi = (double)w[b * maxK + i];
+        const int j = bestp[i];
+        if (assign) assign[b * maxK + i] = j;
+        if (dw) dw[b * maxK + i] = (float)(((double)cost[i][j] * S - swc) / (S * S));
+        if (dmu) dmu[b * maxK + i] = (float)(wi / S * (double)gmu[i][j]);
+        if (dkappa) dkappa[b * maxK + i] = (float)(wi / S * (double)gk[i][j]);
+    }
+}
+
+// ---- multi-peak output head, pointnet_pp_mvM.py:91-125 ---------------------------------------------
+__global__ void __launch_bounds__(64) mvm_head_kernel(const float *__restrict__ pi_raw, const float *__restrict__ mu_raw,
+                                                      const float *__restrict__ kappa_raw, int B, int K, float temp,
+                                                      float kappa_max, float *__restrict__ mu, float *__restrict__ kappa,
+                                                      float *__restrict__ weight) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double mx = -1e300;
+    for (int k = 0; k < K; ++k) mx = fmax(mx, (double)pi_raw[b * K + k] / (double)temp);
+    double se = 0.0;
+    for (int k = 0; k < K; ++k) se += exp((double)pi_raw[b * K + k] / (double)temp - mx);
+    for (int k = 0; k < K; ++k) {
+        weight[b * K + k] = (float)(exp((double)pi_raw[b * K + k] / (double)temp - mx) / se);
+        const float c0 = mu_raw[(b * K + k) * 2], s0 = mu_raw[(b * K + k) * 2 + 1];
+        const float nrm = fmaxf(sqrtf(c0 * c0 + s0 * s0), 1e-4f);  // F.normalize(eps=1e-4)
+        float c = c0 / nrm, s = s0 / nrm;
+        if (sqrtf(c * c + s * s) < 1e-3f) c = 1.f, s = 0.f;        // degenerate direction -> mu = 0
+        mu[b * K + k] = (float)atan2((double)s, (double)c);
+        const double kr = (double)kappa_raw[b * K + k];
+        const double sp = (kr > 20.0 ? kr : log1p(exp(kr))) + 1e-6;
+        kappa[b * K + k] = (float)fmin(sp, (double)kappa_max);
+    }
+}
+
+__global__ void __launch_bounds__(64)
+mvm_head_bwd_kernel(const float *__restrict__ pi_raw, const float *__restrict__ mu_raw, const float *__restrict__ kappa_raw,
+                    const float *__restrict__ weight, const float *__restrict__ dmu, const float *__restrict__ dkappa,
+                    const float *__restrict__ dweight, int B, int K, float temp, float kappa_max,
+                    float *__restrict__ dpi_raw, float *__restrict__ dmu_raw, float *__restrict__ dkappa_raw) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    (void)pi_raw;
+    double dot = 0.0;
+    for (int k = 0; k < K; ++k) dot += (double)weight[b * K + k] * (double)dweight[b * K + k];
+    for (int k = 0; k < K; ++k) {
+        const double wk = (double)weight[b * K + k];
+        dpi_raw[b * K + k] = (float)(wk * ((double)dweight[b * K + k] - dot) / (double)temp);
+        // atan2(s, c) with (c, s) = r / max(|r|, eps)
+        const double r0 = (double)mu_raw[(b * K + k) * 2], r1 = (double)mu_raw[(b * K + k) * 2 + 1];
+        const double n = sqrt(r0 * r0 + r1 * r1);
+        const double den = fmax(n, 1e-4);
+        const double c = r0 / den, s = r1 / den;
+        const double n2 = c * c + s * s;
+        double g0 = 0.0, g1 = 0.0;
+        if (sqrt(n2) >= 1e-3) {
+            const double gm = (double)dmu[b * K + k];
+            const double dc = -s / n2 * gm, ds = c / n2 * gm;  // d atan2 / d(c, s)
+            if (n >= 1e-4) {                                   // u = r/|r|: (I - u u^T)/|r|
+                const double proj = dc * c + ds * s;
+                g0 = (dc - c * proj) / n;
+                g1 = (ds - s * proj) / n;
+            } else {                                           // u = r/eps
+                g0 = dc / 1e-4;
+                g1 = ds / 1e-4;
+            }
+        }
+        dmu_raw[(b * K + k) * 2] = (float)g0;
+        dmu_raw[(b * K + k) * 2 + 1] = (float)g1;
+        const double kr = (double)kappa_raw[b * K + k];
+        const double sp = (kr > 20.0 ? kr : log1p(exp(kr))) + 1e-6;
+        const double sig = kr > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-kr));
+        dkappa_raw[b * K + k] = (float)(sp <= (double)kappa_max ? (double)dkappa[b * K + k] * sig : 0.0);
+    }
+}
+
+// ---- soft-label cross entropy, train_8dir_KL.py:60-68 ----------------------------------------------
+__global__ void __launch_bounds__(64) soft_ce_kernel(const float *__restrict__ logits, const float *__restrict__ p, int B,
+                                                     int C, float *__restrict__ loss_vec, float *__restrict__ dlogits) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float *l = logits + (size_t)b * C, *pt = p + (size_t)b * C;
+    double mx = -1e300;
+    for (int c = 0; c < C; ++c) mx = fmax(mx, (double)l[c]);
+    double se = 0.0, sp = 0.0;
+    for (int c = 0; c < C; ++c) se += exp((double)l[c] - mx), sp += (double)pt[c];
+    const double lse = mx + log(se);
+    double acc = 0.0;
+    for (int c = 0; c < C; ++c) acc -= (double)pt[c] * ((double)l[c] - lse);
+    loss_vec[b] = (float)acc;
+    if (dlogits)
+        for (int c = 0; c < C; ++c) dlogits[(size_t)b * C + c] = (float)(exp((double)l[c] - lse) * sp - (double)pt[c]);
+}
+
+// ---- flat-buffer Adam (torch.optim.Adam defaults: no amsgrad, no weight decay) ---------------------
+__global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, size_t n, float lr_over_bc1, float inv_sqrt_bc2,
+                                                   float b1, float b2, float eps, float gscale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+__global__ void __launch_bounds__(256) sumsq_partial_kernel(const float *__restrict__ x, size_t n, double *__restrict__ part) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += (double)x[i] * (double)x[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += shfl_xor_f64(acc, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(64) sumsq_final_kernel(const double *__restrict__ part, int nb, double *__restrict__ out) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 64) acc += part[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += shfl_xor_f64(acc, m);
+    if (threadIdx.x == 0) out[0] = acc;
+}
+
+}  // namespace pnpp
+
+using namespace pnpp;
+
+extern "C" int pnpp_vm_kl_single(const float *mu_p, const float *kappa_p, const float *mu_q, const float *kappa_q, int n,
+                                 float *kl, float *dmu, float *dkappa, void *stream) {
+    PNPP_REQUIRE(mu_p && kappa_p && mu_q && kappa_q && kl, PNPP_ERR_ARG, "vm_kl_single: null pointer");
+    PNPP_REQUIRE(n > 0, PNPP_ERR_ARG, "vm_kl_single: n must be positive");
+    hipLaunchKernelGGL(vm_kl_single_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), mu_p, kappa_p, mu_q, kappa_q,
+                       n, kl, dmu, dkappa);
+    PNPP_CHECK_LAUNCH("vm_kl_single");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_vm_head_kl(const float *o, const float *mu_gt, const float *kappa_gt, int B, float *mu, float *kappa,
+                               float *loss_vec, float *d_o, void *stream) {
+    PNPP_REQUIRE(o && mu && kappa, PNPP_ERR_ARG, "vm_head_kl: null pointer");
+    PNPP_REQUIRE(!loss_vec || (mu_gt && kappa_gt), PNPP_ERR_ARG, "vm_head_kl: loss requested without ground truth");
+    PNPP_REQUIRE(B > 0, PNPP_ERR_ARG, "vm_head_kl: B must be positive");
+    hipLaunchKernelGGL(vm_head_kl_kernel, dim3(cdiv(B, 256)), dim3(256), 0, as_stream(stream), o, mu_gt, kappa_gt, B, mu, kappa,
+                       loss_vec, d_o);
+    PNPP_CHECK_LAUNCH("vm_head_kl");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_vm_head_bwd(const float *o, const float *dmu, const float *dkappa, int B, float *d_o, void *stream) {
+    PNPP_REQUIRE(o && dmu && dkappa && d_o, PNPP_ERR_ARG, "vm_head_bwd: null pointer");
+    PNPP_REQUIRE(B > 0, PNPP_ERR_ARG, "vm_head_bwd: B must be positive");
+    hipLaunchKernelGGL(vm_head_bwd_kernel, dim3(cdiv(B, 256)), dim3(256), 0, as_stream(stream), o, dmu, dkappa, B, d_o);
+    PNPP_CHECK_LAUNCH("vm_head_bwd");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_vm_match_loss(const float *mu, const float *kappa, const float *w, const float *vm_gt,
+                                  const int32_t *K_gt, int B, int maxK, float *loss_vec, float *dmu, float *dkappa, float *dw,
+                                  int32_t *assign, void *stream) {
+    PNPP_REQUIRE(mu && kappa && w && vm_gt && K_gt && loss_vec, PNPP_ERR_ARG, "vm_match_loss: null pointer");
+    PNPP_REQUIRE(B > 0 && maxK > 0, PNPP_ERR_ARG, "vm_match_loss: non-positive size");
+    PNPP_REQUIRE(maxK <= MATCH_KMAX, PNPP_ERR_ARG, "vm_match_loss: max_K=%d exceeds the supported maximum %d", maxK, MATCH_KMAX);
+    hipLaunchKernelGGL(vm_match_loss_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), mu, kappa, w, vm_gt, K_gt, B,
+                       maxK, loss_vec, dmu, dkappa, dw, assign);
+    PNPP_CHECK_LAUNCH("vm_match_loss");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_mvm_head(const float *pi_raw, const float *mu_raw, const float *kappa_raw, int B, int K, float temp,
+                             float kappa_max, float *mu, float *kappa, float *weight, void *stream) {
+    PNPP_REQUIRE(pi_raw && mu_raw && kappa_raw && mu && kappa && weight, PNPP_ERR_ARG, "mvm_head: null pointer");
+    PNPP_REQUIRE(B > 0 && K > 0, PNPP_ERR_ARG, "mvm_head: non-positive size");
+    hipLaunchKernelGGL(mvm_head_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), pi_raw, mu_raw, kappa_raw, B, K, temp,
+                       kappa_max, mu, kappa, weight);
+    PNPP_CHECK_LAUNCH("mvm_head");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_mvm_head_bwd(const float *pi_raw, const float *mu_raw, const float *kappa_raw, const float *weight,
+                                 const float *dmu, const float *dkappa, const float *dweight, int B, int K, float temp,
+                                 float kappa_max, float *dpi_raw, float *dmu_raw, float *dkappa_raw, void *stream) {
+    PNPP_REQUIRE(pi_raw && mu_raw && kappa_raw && weight && dmu && dkappa && dweight && dpi_raw && dmu_raw && dkappa_raw,
+                 PNPP_ERR_ARG, "mvm_head_bwd: null pointer");
+    PNPP_REQUIRE(B > 0 && K > 0, PNPP_ERR_ARG, "mvm_head_bwd: non-positive size");
+    hipLaunchKernelGGL(mvm_head_bwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), pi_raw, mu_raw, kappa_raw, weight,
+                       dmu, dkappa, dweight, B, K, temp, kappa_max, dpi_raw, dmu_raw, dkappa_raw);
+    PNPP_CHECK_LAUNCH("mvm_head_bwd");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_soft_ce(const float *logits, const float *p, int B, int C, float *loss_vec, float *dlogits, void *stream) {
+    PNPP_REQUIRE(logits && p && loss_vec, PNPP_ERR_ARG, "soft_ce: null pointer");
+    PNPP_REQUIRE(B > 0 && C > 0, PNPP_ERR_ARG, "soft_ce: non-positive size");
+    hipLaunchKernelGGL(soft_ce_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), logits, p, B, C, loss_vec, dlogits);
+    PNPP_CHECK_LAUNCH("soft_ce");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, int step, float lr,
+                              float beta1, float beta2, float eps, float grad_scale, void *stream) {
+    PNPP_REQUIRE(param && grad && exp_avg && exp_avg_sq, PNPP_ERR_ARG, "adam_step: null pointer");
+    PNPP_REQUIRE(n > 0 && step > 0, PNPP_ERR_ARG, "adam_step: n and step must be positive");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale);
+    PNPP_CHECK_LAUNCH("adam_step");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_sumsq(const float *x, size_t n, double *out, void *scratch, size_t scratch_bytes, void *stream) {
+    PNPP_REQUIRE(x && out && scratch, PNPP_ERR_ARG, "sumsq: null pointer");
+    int nb = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    if (nb < 1) nb = 1;
+    PNPP_REQUIRE(scratch_bytes >= (size_t)nb * sizeof(double), PNPP_ERR_WORKSPACE, "sumsq: scratch needs %zu bytes",
+                 (size_t)nb * sizeof(double));
+    double *part = static_cast<double *>(scratch);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, as_stream(stream), x, n, part);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), part, nb, out);
+    PNPP_CHECK_LAUNCH("sumsq");
+    return PNPP_OK;
+}

@@ -1,0 +1,313 @@
+// sa_api.hip -- host-side orchestration of PointNetSetAbstraction forward / backward and of the
+// fully connected head blocks, on top of the fused kernels (gemm_kernels.hip, index_kernels.hip).
+//
+// Reference: models/pointnet_pp_8dir.py:21-43 (forward), its autograd graph and the
+// heads models/pointnet_pp_vonMises.py:32-35 / pointnet_pp_mvM.py:82-83.
+//
+// Everything is stream-ordered: these functions only enqueue work on `stream`; they never allocate,
+// free, copy to the host or synchronise (they can be captured into a hipGraph).
+#include <stdarg.h>
+
+#include "kernels.h"
+
+namespace pnpp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define PNPP_TRY(expr)                 \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != PNPP_OK) return rc_; \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// set abstraction
+// ---------------------------------------------------------------------------------------------
+struct SaGeom {
+    int M, G, Kd0, maxC, L;
+    int Cin[PNPP_MAX_LAYERS];  // reduction dim of layer l in state_dict terms (D+3 for l = 0)
+    int Kd[PNPP_MAX_LAYERS];   // padded reduction dim used by the kernels
+};
+
+static int sa_geom(const pnpp_sa_desc *d, SaGeom *g) {
+    PNPP_REQUIRE(d, PNPP_ERR_ARG, "sa: null descriptor");
+    PNPP_REQUIRE(d->B > 0 && d->N > 0 && d->S > 0 && d->K > 0 && d->D >= 0, PNPP_ERR_ARG,
+                 "sa: bad geometry B=%d N=%d S=%d K=%d D=%d", d->B, d->N, d->S, d->K, d->D);
+    PNPP_REQUIRE(d->L >= 1 && d->L <= PNPP_MAX_LAYERS, PNPP_ERR_ARG, "sa: unsupported layer count %d", d->L);
+    if (d->group_all) PNPP_REQUIRE(d->S == 1 && d->K == d->N, PNPP_ERR_ARG, "sa: group_all needs S == 1 and K == N");
+    PNPP_REQUIRE((long long)d->B * d->S * d->K < (1ll << 31), PNPP_ERR_ARG, "sa: B*S*K overflows int32");
+    g->L = d->L;
+    g->M = d->B * d->S * d->K;
+    g->G = d->B * d->S;
+    g->Kd0 = (d->D + 3 + 3) & ~3;
+    g->maxC = 0;
+    for (int l = 0; l < d->L; ++l) {
+        PNPP_REQUIRE(d->C[l] > 0 && d->C[l] % 32 == 0, PNPP_ERR_ARG,
+                     "sa: mlp channel %d (=%d) must be a positive multiple of 32 for the MFMA path", l, d->C[l]);
+        g->maxC = d->C[l] > g->maxC ? d->C[l] : g->maxC;
+        g->Cin[l] = l == 0 ? d->D + 3 : d->C[l - 1];
+        g->Kd[l] = l == 0 ? g->Kd0 : d->C[l - 1];
+    }
+    return PNPP_OK;
+}
+
+struct SaSaved {
+    int32_t *idx;
+    float *new_xyz;
+    float *z[PNPP_MAX_LAYERS];
+    float *mean[PNPP_MAX_LAYERS], *istd[PNPP_MAX_LAYERS], *scale[PNPP_MAX_LAYERS], *shift[PNPP_MAX_LAYERS];
+    int32_t *arg;
+    size_t bytes;
+};
+
+static SaSaved sa_saved_layout(const pnpp_sa_desc *d, const SaGeom &g, void *base) {
+    Carver cv(base);
+    SaSaved s;
+    s.idx = cv.take<int32_t>(d->group_all ? 0 : (size_t)g.M);
+    s.new_xyz = cv.take<float>((size_t)g.G * 3);
+    for (int l = 0; l < d->L; ++l) {
+        s.z[l] = cv.take<float>((size_t)g.M * d->C[l]);
+        s.mean[l] = cv.take<float>(d->C[l]);
+        s.istd[l] = cv.take<float>(d->C[l]);
+        s.scale[l] = cv.take<float>(d->C[l]);
+        s.shift[l] = cv.take<float>(d->C[l]);
+    }
+    s.arg = cv.take<int32_t>((size_t)g.G * d->C[d->L - 1]);
+    s.bytes = cv.bytes();
+    return s;
+}
+
+struct SaScratch {
+    float *wt[PNPP_MAX_LAYERS];
+    float *wperm0;
+    double *slab;
+    float *dy[2];
+    float *cst;
+    float *dwslab;
+    size_t bytes;
+};
+
+static SaScratch sa_scratch_layout(const pnpp_sa_desc *d, const SaGeom &g, void *base) {
+    Carver cv(base);
+    SaScratch s;
+    for (int l = 0; l < d->L; ++l) s.wt[l] = cv.take<float>((size_t)g.Kd[l] * d->C[l]);
+    s.wperm0 = cv.take<float>((size_t)d->C[0] * g.Kd0);
+    s.slab = cv.take<double>((size_t)kMaxStatBlocks * 2 * g.maxC);
+    const int wide = g.maxC > d->D ? g.maxC : d->D;
+    s.dy[0] = cv.take<float>((size_t)g.M * wide);
+    s.dy[1] = cv.take<float>((size_t)g.M * wide);
+    s.cst = cv.take<float>((size_t)5 * g.maxC);
+    size_t dwmax = 0;
+    for (int l = 0; l < d->L; ++l) {
+        int nsplit, kp_pad;
+        dw_plan(g.M, d->C[l], g.Cin[l], &nsplit, &kp_pad);
+        const size_t need = (size_t)nsplit * d->C[l] * kp_pad;
+        dwmax = need > dwmax ? need : dwmax;
+    }
+    s.dwslab = cv.take<float>(dwmax);
+    s.bytes = cv.bytes();
+    return s;
+}
+
+static AOperand layer0_operand(const pnpp_sa_desc *d, const float *xyz, const float *points, const SaSaved &sv) {
+    AOperand A;
+    A.mode = d->group_all ? A_CONCAT : A_GATHER;
+    A.a = points;
+    A.xyz = xyz;
+    A.new_xyz = sv.new_xyz;
+    A.idx = sv.idx;
+    A.D = d->D;
+    A.N = d->N;
+    A.S = d->S;
+    A.K = d->K;
+    return A;
+}
+
+static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hipStream_t st) {
+    SaGeom g;
+    PNPP_TRY(sa_geom(d, &g));
+    PNPP_REQUIRE(a && a->xyz && a->new_xyz && a->out && a->saved && a->scratch, PNPP_ERR_ARG, "sa_forward: null pointer");
+    PNPP_REQUIRE(d->D == 0 || a->points, PNPP_ERR_ARG, "sa_forward: D=%d but points is null", d->D);
+    PNPP_REQUIRE(d->group_all || a->centre_idx, PNPP_ERR_ARG, "sa_forward: centre_idx is null");
+    for (int l = 0; l < d->L; ++l)
+        PNPP_REQUIRE(a->conv_w[l] && a->conv_b[l] && a->bn_w[l] && a->bn_b[l] && a->bn_rm[l] && a->bn_rv[l], PNPP_ERR_ARG,
+                     "sa_forward: null parameter pointer in layer %d", l);
+    const SaSaved sv = sa_saved_layout(d, g, a->saved);
+    const SaScratch sc = sa_scratch_layout(d, g, a->scratch);
+
+    // 1. centres and neighbours (pointnet_pp_8dir.py:23-31)
+    if (d->group_all) {
+        PNPP_TRY(launch_fill_zero(a->new_xyz, (size_t)g.G * 3 * sizeof(float), st));
+        PNPP_TRY(launch_fill_zero(sv.new_xyz, (size_t)g.G * 3 * sizeof(float), st));
+    } else {
+        PNPP_REQUIRE(d->S <= d->N, PNPP_ERR_RANGE, "sa_forward: npoint=%d > N=%d", d->S, d->N);
+        PNPP_TRY(launch_gather_centres(a->xyz, a->centre_idx, d->B, d->N, d->S, a->new_xyz, st));
+        PNPP_TRY(launch_gather_centres(a->xyz, a->centre_idx, d->B, d->N, d->S, sv.new_xyz, st));
+        if (a->neighbour_idx) {
+            hipError_t e = hipMemcpyAsync(sv.idx, a->neighbour_idx, (size_t)g.M * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+            PNPP_REQUIRE(e == hipSuccess, PNPP_ERR_LAUNCH, "sa_forward: neighbour copy failed: %s", hipGetErrorString(e));
+        } else {
+            PNPP_TRY(launch_knn(sv.new_xyz, a->xyz, d->B, d->S, d->N, d->K, sv.idx, st));
+        }
+    }
+
+    // 2. weights -> [reduction][out] layout, features-first for layer 0
+    PrepItem items[PNPP_MAX_LAYERS];
+    for (int l = 0; l < d->L; ++l)
+        items[l] = PrepItem{a->conv_w[l], sc.wt[l], nullptr, d->C[l], g.Cin[l], g.Kd[l], l == 0 ? d->D : -1};
+    PNPP_TRY(launch_prep_weights(items, d->L, st));
+
+    // 3. conv -> BN -> ReLU chain; BN apply + ReLU of layer l-1 happen inside layer l's operand loader
+    for (int l = 0; l < d->L; ++l) {
+        AOperand A;
+        if (l == 0) {
+            A = layer0_operand(d, a->xyz, a->points, sv);
+        } else {
+            A.mode = A_BNRELU;
+            A.a = sv.z[l - 1];
+            A.lda = d->C[l - 1];
+            A.scale = sv.scale[l - 1];
+            A.shift = sv.shift[l - 1];
+        }
+        Epilogue E;
+        E.c = sv.z[l];
+        E.ldc = d->C[l];
+        int nslab = 0;
+        if (d->training) {
+            E.mode = E_STORE_STATS;
+            E.slab = sc.slab;
+            PNPP_TRY(launch_gemm(A, sc.wt[l], d->C[l], g.M, d->C[l], g.Kd[l], E, &nslab, st));
+            PNPP_TRY(launch_bn_finalize_fwd(sc.slab, nslab, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
+                                            a->bn_rm[l], a->bn_rv[l], d->momentum, d->eps, 1, sv.mean[l], sv.istd[l],
+                                            sv.scale[l], sv.shift[l], st));
+        } else {
+            E.mode = E_STORE;
+            PNPP_TRY(launch_bn_finalize_fwd(nullptr, 0, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
+                                            a->bn_rm[l], a->bn_rv[l], d->momentum, d->eps, 0, sv.mean[l], sv.istd[l],
+                                            sv.scale[l], sv.shift[l], st));
+            PNPP_TRY(launch_gemm(A, sc.wt[l], d->C[l], g.M, d->C[l], g.Kd[l], E, nullptr, st));
+        }
+    }
+
+    // 4. max over the neighbourhood (pointnet_pp_8dir.py:42-43)
+    const int Lm = d->L - 1;
+    PNPP_TRY(launch_pool_fwd(sv.z[Lm], sv.scale[Lm], sv.shift[Lm], g.G, d->K, d->C[Lm], a->out, sv.arg, st));
+    return PNPP_OK;
+}
+
+static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hipStream_t st) {
+    SaGeom g;
+    PNPP_TRY(sa_geom(d, &g));
+    PNPP_REQUIRE(a && a->xyz && a->dout && a->saved && a->scratch, PNPP_ERR_ARG, "sa_backward: null pointer");
+    for (int l = 0; l < d->L; ++l)
+        PNPP_REQUIRE(a->conv_w[l] && a->bn_w[l] && a->d_conv_w[l] && a->d_conv_b[l] && a->d_bn_w[l] && a->d_bn_b[l], PNPP_ERR_ARG,
+                     "sa_backward: null pointer in layer %d", l);
+    const bool want_dpoints = d->D > 0 && a->dpoints != nullptr;
+    if (want_dpoints) PNPP_REQUIRE(d->D % 4 == 0, PNPP_ERR_ARG, "sa_backward: feature width D=%d must be a multiple of 4", d->D);
+    const SaSaved sv = sa_saved_layout(d, g, const_cast<void *>(a->saved));
+    const SaScratch sc = sa_scratch_layout(d, g, a->scratch);
+
+    if (want_dpoints) {  // features-first row-major copy of W0 for the dX GEMM
+        PrepItem it{a->conv_w[0], sc.wt[0], sc.wperm0, d->C[0], g.Cin[0], g.Kd[0], d->D};
+        PNPP_TRY(launch_prep_weights(&it, 1, st));
+    }
+
+    const int Lm = d->L - 1;
+    int cur = 0, nslab = 0;
+    PNPP_TRY(launch_pool_bwd(a->dout, sv.arg, sv.z[Lm], sv.scale[Lm], sv.shift[Lm], sv.mean[Lm], sv.istd[Lm], g.G, d->K,
+                             d->C[Lm], sc.dy[cur], sc.slab, &nslab, st));
+    for (int l = Lm; l >= 0; --l) {
+        const int C = d->C[l];
+        PNPP_TRY(launch_bn_finalize_bwd(sc.slab, nslab, C, (double)g.M, d->training, a->bn_w[l], sv.mean[l], sv.istd[l], sc.cst,
+                                        a->d_bn_w[l], a->d_bn_b[l], a->d_conv_b[l], st));
+        AOperand dz;
+        dz.mode = A_DZ;
+        dz.a = sc.dy[cur];
+        dz.lda = C;
+        dz.z = sv.z[l];
+        dz.cst = sc.cst;
+        dz.C = C;
+
+        AOperand a2;
+        if (l == 0) {
+            a2 = layer0_operand(d, a->xyz, a->points, sv);
+        } else {
+            a2.mode = A_BNRELU;
+            a2.a = sv.z[l - 1];
+            a2.lda = d->C[l - 1];
+            a2.scale = sv.scale[l - 1];
+            a2.shift = sv.shift[l - 1];
+        }
+        // dW_l = dZ_l^T * A_l
+        int nsplit, kp_pad;
+        dw_plan(g.M, C, g.Cin[l], &nsplit, &kp_pad);
+        PNPP_TRY(launch_dw(dz, C, a2, g.Cin[l], g.M, sc.dwslab, nsplit, kp_pad, st));
+        PNPP_TRY(launch_slab_reduce(sc.dwslab, nsplit, C, kp_pad, g.Cin[l], l == 0 ? d->D : -1, a->d_conv_w[l], g.Cin[l], st));
+
+        if (l > 0) {
+            // dY_{l-1} = (dZ_l * W_l) masked by ReLU'(layer l-1), with layer l-1's BN-backward sums
+            Epilogue E;
+            E.mode = E_MASK_STATS;
+            E.c = sc.dy[cur ^ 1];
+            E.ldc = d->C[l - 1];
+            E.slab = sc.slab;
+            E.zp = sv.z[l - 1];
+            E.scale = sv.scale[l - 1];
+            E.shift = sv.shift[l - 1];
+            E.mu = sv.mean[l - 1];
+            E.istd = sv.istd[l - 1];
+            PNPP_TRY(launch_gemm(dz, a->conv_w[l], d->C[l - 1], g.M, d->C[l - 1], C, E, &nslab, st));
+            cur ^= 1;
+        } else if (want_dpoints) {
+            Epilogue E;
+            E.mode = E_STORE;
+            E.ldc = d->D;
+            if (d->group_all) {  // rows are the points themselves
+                E.c = a->dpoints;
+                PNPP_TRY(launch_gemm(dz, sc.wperm0, g.Kd0, g.M, d->D, C, E, nullptr, st));
+            } else {
+                E.c = sc.dy[cur ^ 1];
+                PNPP_TRY(launch_gemm(dz, sc.wperm0, g.Kd0, g.M, d->D, C, E, nullptr, st));
+                PNPP_TRY(launch_fill_zero(a->dpoints, (size_t)d->B * d->N * d->D * sizeof(float), st));
+                PNPP_TRY(launch_scatter_rows_bwd(sc.dy[cur ^ 1], sv.idx, d->B, d->N, d->D, d->S * d->K, a->dpoints, st));
+            }
+        }
+    }
+    return PNPP_OK;
+}
+
+}  // namespace pnpp
+
+using namespace pnpp;
+
+extern "C" const char *pnpp_last_error(void) { return g_err; }
+extern "C" int pnpp_abi_version(void) { return 1; }
+
+extern "C" size_t pnpp_sa_saved_bytes(const pnpp_sa_desc *d) {
+    SaGeom g;
+    if (sa_geom(d, &g) != PNPP_OK) return 0;
+    return sa_saved_layout(d, g, nullptr).bytes;
+}
+extern "C" size_t pnpp_sa_scratch_bytes(const pnpp_sa_desc *d) {
+    SaGeom g;
+    if (sa_geom(d, &g) != PNPP_OK) return 0;
+    return sa_scratch_layout(d, g, nullptr).bytes;
+}
+extern "C" const int32_t *pnpp_sa_saved_neighbours(const pnpp_sa_desc *d, const void *saved) {
+    SaGeom g;
+    if (sa_geom(d, &g) != PNPP_OK || d->group_all) return nullptr;
+    return sa_saved_layout(d, g, const_cast<void *>(saved)).idx;
+}
+extern "C" int pnpp_sa_forward(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, void *stream) {
+    return sa_forward_impl(d, a, as_stream(stream));
+}
+extern "C" int pnpp_sa_backward(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, void *stream) {
+    return sa_backward_impl(d, a, as_stream(stream));
+}

@@ -1,0 +1,113 @@
+"""models/pointnet_pp_8dir.py -- drop-in for the reference file of the same name:
+PointNetSetAbstraction (the backbone block of every pointnet_pp_* model), DIRS_8, PointNetPP8Dir.
+
+Parameter containers are the same nn.Conv2d / nn.BatchNorm2d / nn.Linear modules in the same
+construction order, so state_dict keys, shapes and seeded default initialisation are identical to
+the reference (models/pointnet_pp_8dir.py:6-19,58-74).  forward() runs on the HIP kernels.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from pnpp_hip import ops, sampling
+
+
+class PointNetSetAbstraction(nn.Module):
+    """Sample centres, group the nsample nearest points, 1x1 conv + BatchNorm + ReLU x len(mlp), max.
+
+    Reference: models/pointnet_pp_8dir.py:6-43.  Two knobs the reference does not have:
+      sampler  'randperm' (default) -- per cloud torch.randperm(N)[:npoint] on the CPU default
+                                       generator, exactly the reference's draw (line 28);
+               'device'             -- the same distribution drawn on the GPU (no host work);
+               'fps'                -- true farthest point sampling (PointNet++Demo.py:8-29).
+      grouper  'knn' (default, what the reference calls query_ball_point) or ('ball', radius)
+               for the radius query of PointNet++Demo.py:49-70.
+    Both can also be set process-wide with PNPP_SAMPLER / PNPP_GROUPER.
+    """
+
+    sampler = os.environ.get("PNPP_SAMPLER", "randperm")
+    grouper = os.environ.get("PNPP_GROUPER", "knn")
+
+    def __init__(self, npoint, nsample, in_channel, mlp_channels, group_all=False):
+        super().__init__()
+        self.npoint = npoint
+        self.nsample = nsample
+        self.group_all = group_all
+
+        last_ch = in_channel + 3
+        self.convs = nn.ModuleList()
+        self.bns = nn.ModuleList()
+        for out_ch in mlp_channels:
+            self.convs.append(nn.Conv2d(last_ch, out_ch, 1))
+            self.bns.append(nn.BatchNorm2d(out_ch))
+            last_ch = out_ch
+
+    def _centres(self, xyz):
+        B, N, _ = xyz.shape
+        if self.sampler == "randperm":
+            idx = torch.stack([torch.randperm(N)[:self.npoint] for _ in range(B)])
+            return idx.to(xyz.device, non_blocking=True)
+        if self.sampler == "device":
+            return sampling.device_random_centres(B, N, self.npoint, xyz.device)
+        if self.sampler == "fps":
+            return ops.farthest_point_sample(xyz, self.npoint)
+        raise ValueError(f"unknown sampler '{self.sampler}'")
+
+    def forward(self, xyz, points, centre_idx=None):
+        """xyz (B,N,3), points (B,N,D) or None -> new_xyz (B,S,3), new_points (B,S,C_out).
+        centre_idx (B,S) optionally injects the centres (tests, parity runs)."""
+        if self.group_all:
+            return ops.set_abstraction(xyz, points, None, None, True, self.training, self.convs, self.bns)
+        if centre_idx is None:
+            centre_idx = self._centres(xyz)
+        nbr = None
+        if self.grouper != "knn":
+            kind, radius = self.grouper if isinstance(self.grouper, tuple) else tuple(self.grouper.split(":"))
+            if kind != "ball":
+                raise ValueError(f"unknown grouper '{self.grouper}'")
+            new_xyz = ops.index_points(xyz, centre_idx)
+            nbr = ops.ball_query(float(radius), self.nsample, xyz, new_xyz)
+        return ops.set_abstraction(xyz, points, centre_idx, self.nsample, False, self.training, self.convs, self.bns,
+                                   neighbour_idx=nbr)
+
+
+# the 8 horizontal directions (0, 45, ... 315 degrees), clockwise from the canonical forward axis [0,0,-1]
+DIRS_8 = torch.tensor([
+    [0.0000, 0.0, -1.0000],
+    [0.7071, 0.0, -0.7071],
+    [1.0000, 0.0, 0.0000],
+    [0.7071, 0.0, 0.7071],
+    [0.0000, 0.0, 1.0000],
+    [-0.7071, 0.0, 0.7071],
+    [-1.0000, 0.0, 0.0000],
+    [-0.7071, 0.0, -0.7071],
+])
+
+
+class PointNetPP8Dir(nn.Module):
+    """PointNet++ backbone + 8-way direction head, raw logits out (models/pointnet_pp_8dir.py:58-85)."""
+
+    def __init__(self):
+        super().__init__()
+        self.sa1 = PointNetSetAbstraction(128, 32, 0, [64, 64, 128])
+        self.sa2 = PointNetSetAbstraction(32, 32, 128, [128, 128, 256])
+        self.sa3 = PointNetSetAbstraction(None, None, 256, [256, 512, 1024], group_all=True)
+
+        self.fc1 = nn.Linear(1024, 512)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.fc2 = nn.Linear(512, 256)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.drop = nn.Dropout(0.5)
+        self.fc3 = nn.Linear(256, 8)
+
+    def forward(self, xyz, centres=None, drop_mask=None):
+        B = xyz.size(0)
+        c1, c2 = centres if centres is not None else (None, None)
+        l1_xyz, l1_pts = self.sa1(xyz, None, c1)
+        l2_xyz, l2_pts = self.sa2(l1_xyz, l1_pts, c2)
+        _, l3_pts = self.sa3(l2_xyz, l2_pts)
+        x = l3_pts.view(B, -1)
+        x = ops.fc_block(x, self.fc1, self.bn1, relu=True, training=self.training)
+        x = ops.fc_block(x, self.fc2, self.bn2, relu=True, dropout=self.drop, training=self.training, mask=drop_mask)
+        return ops.fc_block(x, self.fc3, training=self.training)

@@ -1,0 +1,499 @@
+"""Host side of the HIP operators: argument checking, workspace allocation (torch caching
+allocator), stream plumbing and torch.autograd glue around the C ABI of libpnpp_hip.so.
+
+Every function here requires float32 tensors on an AMD GPU; there is no CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+# ------------------------------------------------------------------------------------------------
+# plumbing
+# ------------------------------------------------------------------------------------------------
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(t: torch.Tensor, name: str) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on '{t.device}': the pnpp HIP operators run on an AMD GPU only "
+                           "(no CPU fallback exists in this package)")
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    _need_gpu(t, name)
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _i32(t: torch.Tensor, name: str) -> torch.Tensor:
+    _need_gpu(t, name)
+    if t.dtype not in (torch.int32, torch.int64):
+        raise TypeError(f"{name} must be an integer tensor, got {t.dtype}")
+    return t.to(torch.int32).contiguous()
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+_scratch_cache = {}
+
+
+def _scratch(nbytes: int, device: torch.device) -> torch.Tensor:
+    """Transient workspace, reused per (device, stream): all consumers are ordered on that stream."""
+    key = (device.index, _stream())
+    buf = _scratch_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _scratch_cache[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------------
+# index primitives
+# ------------------------------------------------------------------------------------------------
+def square_distance(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    src, dst = _f32(src, "src"), _f32(dst, "dst")
+    B, S, _ = src.shape
+    N = dst.shape[1]
+    out = torch.empty(B, S, N, device=src.device, dtype=torch.float32)
+    L.check(L.lib().pnpp_square_distance(src.data_ptr(), dst.data_ptr(), B, S, N, out.data_ptr(), _stream()))
+    return out
+
+
+def knn(new_xyz: torch.Tensor, xyz: torch.Tensor, k: int) -> torch.Tensor:
+    """(B,S,k) int32 neighbour indices, ascending (distance, index)."""
+    new_xyz, xyz = _f32(new_xyz, "new_xyz"), _f32(xyz, "xyz")
+    B, S, _ = new_xyz.shape
+    N = xyz.shape[1]
+    idx = torch.empty(B, S, k, device=xyz.device, dtype=torch.int32)
+    L.check(L.lib().pnpp_knn(new_xyz.data_ptr(), xyz.data_ptr(), B, S, N, int(k), idx.data_ptr(), _stream()))
+    return idx
+
+
+def farthest_point_sample(xyz: torch.Tensor, npoint: int, start: Optional[torch.Tensor] = None) -> torch.Tensor:
+    xyz = _f32(xyz, "xyz")
+    B, N, _ = xyz.shape
+    if start is None:  # PointNet++Demo.py:20 draws the first index with torch.randint
+        start = torch.randint(0, N, (B,), dtype=torch.long)
+    start = start.to(device=xyz.device, dtype=torch.int32).contiguous()
+    out = torch.empty(B, npoint, device=xyz.device, dtype=torch.int32)
+    L.check(L.lib().pnpp_fps(xyz.data_ptr(), B, N, int(npoint), start.data_ptr(), out.data_ptr(), _stream()))
+    return out
+
+
+def ball_query(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+    xyz, new_xyz = _f32(xyz, "xyz"), _f32(new_xyz, "new_xyz")
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    idx = torch.empty(B, S, nsample, device=xyz.device, dtype=torch.int32)
+    L.check(L.lib().pnpp_ball_query(new_xyz.data_ptr(), xyz.data_ptr(), B, S, N, float(radius), int(nsample),
+                                    idx.data_ptr(), _stream()))
+    return idx
+
+
+def sample_random(seed: int, stream_id: int, B: int, N: int, npoint: int, device) -> torch.Tensor:
+    out = torch.empty(B, npoint, device=device, dtype=torch.int32)
+    L.check(L.lib().pnpp_sample_random(int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1), B, N, int(npoint),
+                                       out.data_ptr(), _stream()))
+    return out
+
+
+class _IndexPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx):
+        points = _f32(points, "points")
+        idx32 = _i32(idx, "idx")
+        B, N, Cc = points.shape
+        M = idx32[0].numel()
+        out = torch.empty(*idx32.shape, Cc, device=points.device, dtype=torch.float32)
+        L.check(L.lib().pnpp_index_points(points.data_ptr(), idx32.data_ptr(), B, N, Cc, M, out.data_ptr(), _stream()))
+        ctx.save_for_backward(idx32)
+        ctx.shape = (B, N, Cc, M)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx32,) = ctx.saved_tensors
+        B, N, Cc, M = ctx.shape
+        dout = _f32(dout, "dout")
+        dpoints = torch.zeros(B, N, Cc, device=dout.device, dtype=torch.float32)
+        L.check(L.lib().pnpp_index_points_bwd(dout.data_ptr(), idx32.data_ptr(), B, N, Cc, M, dpoints.data_ptr(), _stream()))
+        return dpoints, None
+
+
+def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    return _IndexPoints.apply(points, idx)
+
+
+# ------------------------------------------------------------------------------------------------
+# set abstraction
+# ------------------------------------------------------------------------------------------------
+def _sa_desc(B, N, S, K, D, channels: Sequence[int], group_all: bool, training: bool, eps: float, momentum: float):
+    d = L.SaDesc()
+    d.B, d.N, d.S, d.K, d.D, d.L = B, N, S, K, D, len(channels)
+    for i, c in enumerate(channels):
+        d.C[i] = int(c)
+    d.group_all, d.training = int(group_all), int(training)
+    d.eps, d.momentum = float(eps), float(momentum)
+    return d
+
+
+def _ptr_array(tensors: Sequence[Optional[torch.Tensor]]):
+    arr = (C.c_void_p * L.PNPP_MAX_LAYERS)()
+    for i, t in enumerate(tensors):
+        arr[i] = _p(t)
+    return arr
+
+
+class _SetAbstraction(torch.autograd.Function):
+    """PointNetSetAbstraction.forward / backward as two C calls (models/pointnet_pp_8dir.py:21-43)."""
+
+    @staticmethod
+    def forward(ctx, xyz, points, centre_idx, neighbour_idx, cfg, running, *params):
+        # params: L x (conv_w, conv_b, bn_w, bn_b); running: L x (running_mean, running_var)
+        K, group_all, training, eps, momentum = cfg
+        Lh = len(params) // 4
+        xyz = _f32(xyz, "xyz")
+        B, N, _ = xyz.shape
+        D = 0
+        if points is not None:
+            points = _f32(points, "points")
+            D = points.shape[2]
+        conv_w = [_f32(params[4 * l], "conv weight") for l in range(Lh)]
+        conv_b = [_f32(params[4 * l + 1], "conv bias") for l in range(Lh)]
+        bn_w = [_f32(params[4 * l + 2], "bn weight") for l in range(Lh)]
+        bn_b = [_f32(params[4 * l + 3], "bn bias") for l in range(Lh)]
+        channels = [w.shape[0] for w in conv_w]
+        if group_all:
+            S, Kk = 1, N
+        else:
+            centre_idx = _i32(centre_idx, "centre_idx")
+            S, Kk = centre_idx.shape[1], int(K)
+            if neighbour_idx is not None:
+                neighbour_idx = _i32(neighbour_idx, "neighbour_idx")
+        desc = _sa_desc(B, N, S, Kk, D, channels, group_all, training, eps, momentum)
+        lib = L.lib()
+        sb = lib.pnpp_sa_saved_bytes(C.byref(desc))
+        if sb == 0:
+            L.check(L.PNPP_ERR_ARG if L.last_error() else L.PNPP_ERR_ARG)
+        saved = torch.empty(sb, dtype=torch.uint8, device=xyz.device)
+        scratch = _scratch(lib.pnpp_sa_scratch_bytes(C.byref(desc)), xyz.device)
+        new_xyz = torch.empty(B, S, 3, device=xyz.device, dtype=torch.float32)
+        out = torch.empty(B, S, channels[-1], device=xyz.device, dtype=torch.float32)
+        a = L.SaFwdArgs()
+        a.xyz, a.points = xyz.data_ptr(), _p(points)
+        a.centre_idx = None if group_all else centre_idx.data_ptr()
+        a.neighbour_idx = _p(neighbour_idx)
+        a.conv_w, a.conv_b, a.bn_w, a.bn_b = _ptr_array(conv_w), _ptr_array(conv_b), _ptr_array(bn_w), _ptr_array(bn_b)
+        a.bn_rm = _ptr_array([running[2 * l] for l in range(Lh)])
+        a.bn_rv = _ptr_array([running[2 * l + 1] for l in range(Lh)])
+        a.new_xyz, a.out, a.saved, a.scratch = new_xyz.data_ptr(), out.data_ptr(), saved.data_ptr(), scratch.data_ptr()
+        L.check(lib.pnpp_sa_forward(C.byref(desc), C.byref(a), _stream()))
+        ctx.desc = desc
+        ctx.has_points = points is not None
+        ctx.save_for_backward(xyz, points if points is not None else xyz.new_empty(0), saved, *conv_w, *bn_w, *bn_b)
+        if group_all:
+            nbr = torch.empty(0, dtype=torch.int32, device=xyz.device)
+        else:  # view of the neighbour indices kept in the saved workspace
+            off = lib.pnpp_sa_saved_neighbours(C.byref(desc), saved.data_ptr()) - saved.data_ptr()
+            nbr = saved[off:off + 4 * B * S * Kk].view(torch.int32).view(B, S, Kk)
+        ctx.mark_non_differentiable(new_xyz, nbr)
+        return new_xyz, out, nbr
+
+    @staticmethod
+    def backward(ctx, _dnew_xyz, dout, _dnbr):
+        desc = ctx.desc
+        Lh = desc.L
+        t = ctx.saved_tensors
+        xyz, points, saved = t[0], (t[1] if ctx.has_points else None), t[2]
+        conv_w, bn_w, bn_b = t[3:3 + Lh], t[3 + Lh:3 + 2 * Lh], t[3 + 2 * Lh:3 + 3 * Lh]
+        dout = _f32(dout, "dout")
+        lib = L.lib()
+        scratch = _scratch(lib.pnpp_sa_scratch_bytes(C.byref(desc)), xyz.device)
+        d_conv_w = [torch.empty_like(w) for w in conv_w]
+        d_conv_b = [torch.empty(w.shape[0], device=w.device, dtype=torch.float32) for w in conv_w]
+        d_bn_w = [torch.empty_like(w) for w in bn_w]
+        d_bn_b = [torch.empty_like(w) for w in bn_b]
+        dpoints = torch.empty_like(points) if (points is not None and ctx.needs_input_grad[1]) else None
+        a = L.SaBwdArgs()
+        a.xyz, a.points = xyz.data_ptr(), _p(points)
+        a.conv_w, a.bn_w, a.bn_b = _ptr_array(conv_w), _ptr_array(bn_w), _ptr_array(bn_b)
+        a.dout, a.saved, a.scratch = dout.data_ptr(), saved.data_ptr(), scratch.data_ptr()
+        a.d_conv_w, a.d_conv_b = _ptr_array(d_conv_w), _ptr_array(d_conv_b)
+        a.d_bn_w, a.d_bn_b = _ptr_array(d_bn_w), _ptr_array(d_bn_b)
+        a.dpoints = _p(dpoints)
+        L.check(lib.pnpp_sa_backward(C.byref(desc), C.byref(a), _stream()))
+        grads: List[Optional[torch.Tensor]] = []
+        for l in range(Lh):
+            grads += [d_conv_w[l], d_conv_b[l], d_bn_w[l], d_bn_b[l]]
+        return (None, dpoints, None, None, None, None, *grads)
+
+
+def set_abstraction(xyz, points, centre_idx, nsample, group_all, training, convs, bns, neighbour_idx=None,
+                    return_neighbours=False):
+    """Functional form used by models.pointnet_pp_8dir.PointNetSetAbstraction.
+
+    convs / bns are the nn.Conv2d / nn.BatchNorm2d containers (their tensors are used in place:
+    weights are read, running statistics are updated by the kernels when training).
+    Returns (new_xyz, new_points) exactly like the reference module.
+    """
+    params, running = [], []
+    for conv, bn in zip(convs, bns):
+        params += [conv.weight, conv.bias, bn.weight, bn.bias]
+        running += [bn.running_mean, bn.running_var]
+    eps = bns[0].eps
+    momentum = bns[0].momentum if bns[0].momentum is not None else 0.1
+    cfg = (nsample, bool(group_all), bool(training), eps, momentum)
+    new_xyz, out, nbr = _SetAbstraction.apply(xyz, points, centre_idx, neighbour_idx, cfg, running, *params)
+    if training:
+        for bn in bns:
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+    if return_neighbours:
+        return new_xyz, out, (None if group_all else nbr)
+    return new_xyz, out
+
+
+# ------------------------------------------------------------------------------------------------
+# fully connected block
+# ------------------------------------------------------------------------------------------------
+class _FcBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, nw, nb, rm, rv, mask, cfg):
+        norm, relu, training, eps, momentum, drop_scale = cfg
+        x, w, b = _f32(x, "x"), _f32(w, "weight"), _f32(b, "bias")
+        M, K = x.shape
+        N = w.shape[0]
+        d = L.FcDesc()
+        d.M, d.K, d.N, d.norm, d.relu, d.training = M, K, N, norm, int(relu), int(training)
+        d.eps, d.momentum, d.drop_scale = float(eps), float(momentum), float(drop_scale)
+        lib = L.lib()
+        sb = lib.pnpp_fc_saved_bytes(C.byref(d))
+        if sb == 0:
+            L.check(L.PNPP_ERR_ARG)
+        saved = torch.empty(sb, dtype=torch.uint8, device=x.device)
+        scratch = _scratch(lib.pnpp_fc_scratch_bytes(C.byref(d)), x.device)
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        if nw is not None:
+            nw, nb = _f32(nw, "norm weight"), _f32(nb, "norm bias")
+        if mask is not None:
+            mask = mask.contiguous()
+        a = L.FcFwdArgs()
+        a.x, a.w, a.b, a.nw, a.nb = x.data_ptr(), w.data_ptr(), b.data_ptr(), _p(nw), _p(nb)
+        a.rm, a.rv, a.mask = _p(rm), _p(rv), _p(mask)
+        a.y, a.saved, a.scratch = y.data_ptr(), saved.data_ptr(), scratch.data_ptr()
+        L.check(lib.pnpp_fc_forward(C.byref(d), C.byref(a), _stream()))
+        ctx.desc = d
+        ctx.has_norm, ctx.has_mask = nw is not None, mask is not None
+        e = x.new_empty(0)
+        ctx.save_for_backward(x, w, b, nw if nw is not None else e, nb if nb is not None else e,
+                              mask if mask is not None else e, saved)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        d = ctx.desc
+        x, w, b, nw, nb, mask, saved = ctx.saved_tensors
+        nw, nb = (nw, nb) if ctx.has_norm else (None, None)
+        mask = mask if ctx.has_mask else None
+        dy = _f32(dy, "dy")
+        lib = L.lib()
+        scratch = _scratch(lib.pnpp_fc_scratch_bytes(C.byref(d)), x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw, db = torch.empty_like(w), torch.empty_like(b)
+        dnw = torch.empty_like(nw) if nw is not None else None
+        dnb = torch.empty_like(nb) if nb is not None else None
+        a = L.FcBwdArgs()
+        a.x, a.w, a.b, a.nw, a.nb, a.mask = x.data_ptr(), w.data_ptr(), b.data_ptr(), _p(nw), _p(nb), _p(mask)
+        a.dy, a.saved, a.scratch = dy.data_ptr(), saved.data_ptr(), scratch.data_ptr()
+        a.dx, a.dw, a.db, a.dnw, a.dnb = _p(dx), dw.data_ptr(), db.data_ptr(), _p(dnw), _p(dnb)
+        L.check(lib.pnpp_fc_backward(C.byref(d), C.byref(a), _stream()))
+        return dx, dw, db, dnw, dnb, None, None, None, None
+
+
+def fc_block(x, linear, norm=None, relu=False, dropout=None, training=True, mask=None):
+    """Linear -> optional BatchNorm1d/LayerNorm -> optional ReLU -> optional dropout.
+
+    `dropout` is an nn.Dropout (its p is used, a fresh keep-mask is drawn on the device in training) or
+    None; `mask` injects an explicit (M,N) keep-mask instead (tests / parity runs).
+    """
+    import torch.nn as nn
+    nw = nb = rm = rv = None
+    kind, eps, momentum = L.NORM_NONE, 1e-5, 0.1
+    if isinstance(norm, nn.BatchNorm1d):
+        kind, eps = L.NORM_BATCH, norm.eps
+        momentum = norm.momentum if norm.momentum is not None else 0.1
+        nw, nb, rm, rv = norm.weight, norm.bias, norm.running_mean, norm.running_var
+    elif isinstance(norm, nn.LayerNorm):
+        kind, eps = L.NORM_LAYER, norm.eps
+        nw, nb = norm.weight, norm.bias
+    elif norm is not None:
+        raise TypeError(f"unsupported norm module {type(norm).__name__}")
+    drop_scale = 1.0
+    if training and mask is None and dropout is not None and dropout.p > 0:
+        mask = (torch.rand(x.shape[0], linear.weight.shape[0], device=x.device) >= dropout.p).to(torch.uint8)
+    if mask is not None:
+        if not training:
+            mask = None
+        else:
+            p = dropout.p if dropout is not None else 0.5
+            drop_scale = 1.0 / (1.0 - p)
+            mask = mask.to(device=x.device, dtype=torch.uint8)
+    cfg = (kind, relu, training, eps, momentum, drop_scale)
+    y = _FcBlock.apply(x, linear.weight, linear.bias, nw, nb, rm, rv, mask, cfg)
+    if training and kind == L.NORM_BATCH and norm.num_batches_tracked is not None:
+        norm.num_batches_tracked += 1
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# heads and losses
+# ------------------------------------------------------------------------------------------------
+class _VmHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, o):
+        o = _f32(o, "o")
+        B = o.shape[0]
+        mu = torch.empty(B, device=o.device, dtype=torch.float32)
+        kappa = torch.empty_like(mu)
+        L.check(L.lib().pnpp_vm_head_kl(o.data_ptr(), None, None, B, mu.data_ptr(), kappa.data_ptr(), None, None, _stream()))
+        ctx.save_for_backward(o)
+        return mu, kappa
+
+    @staticmethod
+    def backward(ctx, dmu, dkappa):
+        (o,) = ctx.saved_tensors
+        B = o.shape[0]
+        dmu = _f32(dmu, "dmu") if dmu is not None else torch.zeros(B, device=o.device)
+        dkappa = _f32(dkappa, "dkappa") if dkappa is not None else torch.zeros(B, device=o.device)
+        d_o = torch.empty_like(o)
+        L.check(L.lib().pnpp_vm_head_bwd(o.data_ptr(), dmu.data_ptr(), dkappa.data_ptr(), B, d_o.data_ptr(), _stream()))
+        return d_o
+
+
+def vm_head(o: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """mu = tanh(o[:,0])*pi, kappa = softplus(o[:,1])  (pointnet_pp_vonMises.py:36-37)."""
+    return _VmHead.apply(o)
+
+
+class _KlSingle(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu_p, kappa_p, mu_q, kappa_q):
+        mu_p, kappa_p = _f32(mu_p, "mu_p"), _f32(kappa_p, "kappa_p")
+        mu_q, kappa_q = _f32(mu_q, "mu_q"), _f32(kappa_q, "kappa_q")
+        n = mu_p.numel()
+        kl, dmu, dk = torch.empty_like(mu_p), torch.empty_like(mu_p), torch.empty_like(mu_p)
+        L.check(L.lib().pnpp_vm_kl_single(mu_p.data_ptr(), kappa_p.data_ptr(), mu_q.data_ptr(), kappa_q.data_ptr(), n,
+                                          kl.data_ptr(), dmu.data_ptr(), dk.data_ptr(), _stream()))
+        ctx.save_for_backward(dmu, dk)
+        return kl
+
+    @staticmethod
+    def backward(ctx, g):
+        dmu, dk = ctx.saved_tensors
+        return g * dmu, g * dk, None, None
+
+
+def kl_von_mises_single(mu_p, kappa_p, mu_q, kappa_q):
+    """train_single_peak_vonMises_KL.py:23-28 (value and analytic gradient from one launch)."""
+    return _KlSingle.apply(mu_p, kappa_p, mu_q, kappa_q)
+
+
+def vm_head_kl_fused(o, mu_gt, kappa_gt):
+    """fc3 output -> (mu, kappa, loss_vec, d loss_vec/d o) in ONE launch (no autograd graph)."""
+    o, mu_gt, kappa_gt = _f32(o, "o"), _f32(mu_gt, "mu_gt"), _f32(kappa_gt, "kappa_gt")
+    B = o.shape[0]
+    mu = torch.empty(B, device=o.device, dtype=torch.float32)
+    kappa, lv, d_o = torch.empty_like(mu), torch.empty_like(mu), torch.empty_like(o)
+    L.check(L.lib().pnpp_vm_head_kl(o.data_ptr(), mu_gt.data_ptr(), kappa_gt.data_ptr(), B, mu.data_ptr(), kappa.data_ptr(),
+                                    lv.data_ptr(), d_o.data_ptr(), _stream()))
+    return mu, kappa, lv, d_o
+
+
+class _MatchLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, kappa, w, vm_gt, K_gt):
+        mu, kappa, w, vm_gt = _f32(mu, "mu"), _f32(kappa, "kappa"), _f32(w, "w"), _f32(vm_gt, "vm_gt")
+        K32 = _i32(K_gt, "K_gt")
+        B, maxK = mu.shape
+        lv = torch.empty(B, device=mu.device, dtype=torch.float32)
+        dmu, dk, dw = torch.empty_like(mu), torch.empty_like(mu), torch.empty_like(mu)
+        assign = torch.empty(B, maxK, device=mu.device, dtype=torch.int32)
+        L.check(L.lib().pnpp_vm_match_loss(mu.data_ptr(), kappa.data_ptr(), w.data_ptr(), vm_gt.data_ptr(), K32.data_ptr(), B,
+                                           maxK, lv.data_ptr(), dmu.data_ptr(), dk.data_ptr(), dw.data_ptr(),
+                                           assign.data_ptr(), _stream()))
+        ctx.save_for_backward(dmu, dk, dw)
+        ctx.assign = assign
+        return lv
+
+    @staticmethod
+    def backward(ctx, g):
+        dmu, dk, dw = ctx.saved_tensors
+        g = g[:, None]
+        return g * dmu, g * dk, g * dw, None, None
+
+
+def match_loss(mu, kappa, w, vm_gt, K_gt):
+    """train_multi_peaks_vonMises_KL.py:54-81, whole batch in one launch, no host round trip."""
+    return _MatchLoss.apply(mu, kappa, w, vm_gt, K_gt)
+
+
+class _MvmHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pi_raw, mu_raw, kappa_raw, temp, kappa_max):
+        pi_raw, mu_raw, kappa_raw = _f32(pi_raw, "pi_raw"), _f32(mu_raw, "mu_raw"), _f32(kappa_raw, "kappa_raw")
+        B, K = pi_raw.shape
+        mu, kappa, weight = torch.empty_like(pi_raw), torch.empty_like(pi_raw), torch.empty_like(pi_raw)
+        L.check(L.lib().pnpp_mvm_head(pi_raw.data_ptr(), mu_raw.data_ptr(), kappa_raw.data_ptr(), B, K, float(temp),
+                                      float(kappa_max), mu.data_ptr(), kappa.data_ptr(), weight.data_ptr(), _stream()))
+        ctx.save_for_backward(pi_raw, mu_raw, kappa_raw, weight)
+        ctx.cfg = (float(temp), float(kappa_max))
+        return mu, kappa, weight
+
+    @staticmethod
+    def backward(ctx, dmu, dkappa, dweight):
+        pi_raw, mu_raw, kappa_raw, weight = ctx.saved_tensors
+        B, K = pi_raw.shape
+        z = lambda t: _f32(t, "grad") if t is not None else torch.zeros_like(pi_raw)
+        dmu, dkappa, dweight = z(dmu), z(dkappa), z(dweight)
+        dpi, dmr, dkr = torch.empty_like(pi_raw), torch.empty_like(mu_raw), torch.empty_like(kappa_raw)
+        L.check(L.lib().pnpp_mvm_head_bwd(pi_raw.data_ptr(), mu_raw.data_ptr(), kappa_raw.data_ptr(), weight.data_ptr(),
+                                          dmu.data_ptr(), dkappa.data_ptr(), dweight.data_ptr(), B, K, ctx.cfg[0], ctx.cfg[1],
+                                          dpi.data_ptr(), dmr.data_ptr(), dkr.data_ptr(), _stream()))
+        return dpi, dmr, dkr, None, None
+
+
+def mvm_head(pi_raw, mu_raw, kappa_raw, temp: float, kappa_max: Optional[float]):
+    return _MvmHead.apply(pi_raw, mu_raw, kappa_raw, temp, float("inf") if kappa_max is None else kappa_max)
+
+
+class _SoftCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, p):
+        logits, p = _f32(logits, "logits"), _f32(p, "p_target")
+        B, Cc = logits.shape
+        lv, dl = torch.empty(B, device=logits.device, dtype=torch.float32), torch.empty_like(logits)
+        L.check(L.lib().pnpp_soft_ce(logits.data_ptr(), p.data_ptr(), B, Cc, lv.data_ptr(), dl.data_ptr(), _stream()))
+        ctx.save_for_backward(dl)
+        return lv
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return g[:, None] * dl, None
+
+
+def soft_ce(logits, p_target):
+    """train_8dir_KL.py:60-68."""
+    return _SoftCE.apply(logits, p_target)

@@ -1,0 +1,231 @@
+/*
+ * pnpp_hip.h -- C ABI of libpnpp_hip.so: the MI355X (gfx950) implementation of the
+ * PointNet++ set-abstraction + von-Mises-KL training path of
+ * 0xPabloxx/3d-pointcloud-orientation-estimation.
+ *
+ * The reference has no FFI of its own: its boundary is the Python surface listed in
+ * SURVEY.md 8(b).  Each entry point below names the reference interface (file:line under
+ * /root/reference) whose work it performs; the Python host in
+ * 3d-pointcloud-orientation-estimation_amd/ keeps the reference's names on top of these.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - Every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - Tensors are dense row-major float32; indices are int32 on the device
+ *     (the Python host converts to the reference's int64 at its own boundary).
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *     synchronises, allocates or frees.  Outputs and workspaces are caller-owned.
+ *   - Return value: PNPP_OK or a negative pnpp_status; pnpp_last_error() gives the text.
+ *     No exception crosses the ABI.  Functions are re-entrant; the only global state is
+ *     the thread-local last-error string and an immutable device-property cache.
+ */
+#ifndef PNPP_HIP_H
+#define PNPP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PNPP_OK = 0,
+    PNPP_ERR_ARG = -1,      /* bad shape / null pointer / unsupported size: Python raises ValueError   */
+    PNPP_ERR_RANGE = -2,    /* k > N and similar: Python raises RuntimeError like torch.topk           */
+    PNPP_ERR_LAUNCH = -3,   /* hipLaunch / hipGetLastError failure: Python raises RuntimeError         */
+    PNPP_ERR_WORKSPACE = -4 /* workspace too small                                                       */
+} pnpp_status;
+
+const char *pnpp_last_error(void);
+int pnpp_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Index primitives
+ * ---------------------------------------------------------------------------------------- */
+
+/* models/base.py:20-27  square_distance(src (B,S,3), dst (B,N,3)) -> out (B,S,N).
+ * Bit-equal to the ATen CPU evaluation order (fmaf-chained dot, unfused norms). */
+int pnpp_square_distance(const float *src, const float *dst, int B, int S, int N, float *out, void *stream);
+
+/* models/base.py:29-35  query_ball_point(new_xyz, xyz, nsample) == kNN.
+ * new_xyz (B,S,3), xyz (B,N,3) -> idx (B,S,k) int32, ascending (distance, index).
+ * The k smallest by the bit-exact float32 recipe; lowest index wins ties. */
+int pnpp_knn(const float *new_xyz, const float *xyz, int B, int S, int N, int k, int32_t *idx, void *stream);
+
+/* PointNet++Demo.py:8-29  farthest_point_sample with the start indices injected.
+ * xyz (B,N,3), start (B) -> out (B,npoint) int32. */
+int pnpp_fps(const float *xyz, int B, int N, int npoint, const int32_t *start, int32_t *out, void *stream);
+
+/* PointNet++Demo.py:49-70  query_ball_point(radius, nsample, xyz, new_xyz) -> idx (B,S,nsample) int32. */
+int pnpp_ball_query(const float *new_xyz, const float *xyz, int B, int S, int N, float radius, int nsample,
+                    int32_t *idx, void *stream);
+
+/* models/pointnet_pp_8dir.py:28  per-cloud uniform random subset of size npoint out of N, without
+ * replacement, in random order -- the device-side replacement of B host `torch.randperm(N)[:npoint]`
+ * calls (throughput mode; parity mode replays the CPU generator on the host and passes the indices in).
+ * Counter-based: the result is a pure function of (seed, stream_id, b).  out (B,npoint) int32. */
+int pnpp_sample_random(uint64_t seed, uint64_t stream_id, int B, int N, int npoint, int32_t *out, void *stream);
+
+/* models/base.py:4-18  index_points(points (B,N,C), idx (B,M)) -> out (B,M,C); idx is int32, flattened
+ * over its trailing dims.  _bwd accumulates dpoints (B,N,C) += scatter(dout) deterministically
+ * (dpoints must be zero-initialised by the caller when it wants a pure gradient). */
+int pnpp_index_points(const float *points, const int32_t *idx, int B, int N, int C, int M, float *out, void *stream);
+int pnpp_index_points_bwd(const float *dout, const int32_t *idx, int B, int N, int C, int M, float *dpoints,
+                          void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Set abstraction: grouping + 3 x (1x1 conv -> train/eval BatchNorm2d -> ReLU) + max over nsample
+ * models/pointnet_pp_8dir.py:21-43 (PointNetSetAbstraction.forward) and its autograd backward.
+ * ---------------------------------------------------------------------------------------- */
+#define PNPP_MAX_LAYERS 4
+
+typedef struct {
+    int B;             /* clouds                                                                  */
+    int N;             /* points per cloud going in                                               */
+    int S;             /* centres per cloud (npoint); 1 when group_all                            */
+    int K;             /* neighbours per centre (nsample); N when group_all                       */
+    int D;             /* feature channels of `points` (0 when points is None)                    */
+    int L;             /* number of conv/bn layers (3 in every reference model)                   */
+    int C[PNPP_MAX_LAYERS]; /* mlp_channels, each a multiple of 32                                */
+    int group_all;     /* pointnet_pp_8dir.py:23-26                                               */
+    int training;      /* 1: batch statistics + running-stat update; 0: running statistics        */
+    float eps;         /* 1e-5                                                                    */
+    float momentum;    /* 0.1                                                                     */
+} pnpp_sa_desc;
+
+typedef struct {
+    const float *xyz;          /* (B,N,3)                                                          */
+    const float *points;       /* (B,N,D) or NULL                                                  */
+    const int32_t *centre_idx; /* (B,S) centre indices (unused when group_all)                     */
+    const int32_t *neighbour_idx; /* optional (B,S,K): use these neighbours instead of running the kNN
+                                  (radius grouping of PointNet++Demo.py:49-70, or injection in tests)  */
+    const float *conv_w[PNPP_MAX_LAYERS];   /* (C[l], Cin[l]) = state_dict convs.l.weight, xyz columns first */
+    const float *conv_b[PNPP_MAX_LAYERS];   /* (C[l])                                               */
+    const float *bn_w[PNPP_MAX_LAYERS];     /* gamma                                                */
+    const float *bn_b[PNPP_MAX_LAYERS];     /* beta                                                 */
+    float *bn_rm[PNPP_MAX_LAYERS];          /* running_mean (updated in training)                   */
+    float *bn_rv[PNPP_MAX_LAYERS];          /* running_var  (updated in training)                   */
+    float *new_xyz;            /* out (B,S,3)                                                      */
+    float *out;                /* out (B,S,C[L-1])                                                 */
+    void *saved;               /* activations kept for backward, pnpp_sa_saved_bytes()             */
+    void *scratch;             /* transient, pnpp_sa_scratch_bytes()                               */
+} pnpp_sa_fwd_args;
+
+typedef struct {
+    const float *xyz, *points;
+    const float *conv_w[PNPP_MAX_LAYERS];
+    const float *bn_w[PNPP_MAX_LAYERS];
+    const float *bn_b[PNPP_MAX_LAYERS];
+    const float *dout;         /* (B,S,C[L-1]) upstream gradient                                   */
+    const void *saved;         /* as written by pnpp_sa_forward                                    */
+    void *scratch;             /* pnpp_sa_scratch_bytes()                                          */
+    float *d_conv_w[PNPP_MAX_LAYERS];       /* out, same shapes as conv_w                           */
+    float *d_conv_b[PNPP_MAX_LAYERS];       /* out (written as exact zeros in training: a bias in front
+                                               of a train-mode BatchNorm has zero gradient)         */
+    float *d_bn_w[PNPP_MAX_LAYERS], *d_bn_b[PNPP_MAX_LAYERS];
+    float *dpoints;            /* out (B,N,D) or NULL                                              */
+} pnpp_sa_bwd_args;
+
+size_t pnpp_sa_saved_bytes(const pnpp_sa_desc *d);
+size_t pnpp_sa_scratch_bytes(const pnpp_sa_desc *d);
+int pnpp_sa_forward(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, void *stream);
+int pnpp_sa_backward(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, void *stream);
+/* read-only view of the neighbour indices kept in `saved` ((B,S,K) int32; NULL when group_all) */
+const int32_t *pnpp_sa_saved_neighbours(const pnpp_sa_desc *d, const void *saved);
+
+/* ------------------------------------------------------------------------------------------
+ * Fully connected block: y = act(norm(x W^T + b)) with norm in {BatchNorm1d, LayerNorm, none},
+ * optional ReLU and inverted dropout by an explicit {0,1} mask.
+ * models/pointnet_pp_vonMises.py:32-35, pointnet_pp_8dir.py:81-85, pointnet_pp_mvM.py:82-83.
+ * ---------------------------------------------------------------------------------------- */
+typedef enum { PNPP_NORM_NONE = 0, PNPP_NORM_BATCH = 1, PNPP_NORM_LAYER = 2 } pnpp_norm;
+
+typedef struct {
+    int M, K, N;        /* rows (batch), in features, out features                               */
+    int norm;           /* pnpp_norm                                                              */
+    int relu;           /* apply ReLU after norm                                                  */
+    int training;
+    float eps, momentum;
+    float drop_scale;   /* 1/(1-p) applied with `mask`; ignored when mask == NULL                 */
+} pnpp_fc_desc;
+
+typedef struct {
+    const float *x;      /* (M,K)                                                                  */
+    const float *w;      /* (N,K)                                                                  */
+    const float *b;      /* (N)                                                                    */
+    const float *nw, *nb;/* norm affine (N) or NULL                                                */
+    float *rm, *rv;      /* BatchNorm running stats or NULL                                        */
+    const uint8_t *mask; /* (M,N) dropout keep-mask or NULL                                        */
+    float *y;            /* out (M,N)                                                              */
+    void *saved;         /* pnpp_fc_saved_bytes()                                                  */
+    void *scratch;       /* pnpp_fc_scratch_bytes()                                                */
+} pnpp_fc_fwd_args;
+
+typedef struct {
+    const float *x, *w, *b, *nw, *nb;
+    const uint8_t *mask;
+    const float *dy;     /* (M,N)                                                                  */
+    const void *saved;
+    void *scratch;
+    float *dx;           /* (M,K) or NULL                                                          */
+    float *dw, *db;      /* (N,K), (N)                                                             */
+    float *dnw, *dnb;    /* (N) or NULL                                                            */
+} pnpp_fc_bwd_args;
+
+size_t pnpp_fc_saved_bytes(const pnpp_fc_desc *d);
+size_t pnpp_fc_scratch_bytes(const pnpp_fc_desc *d);
+int pnpp_fc_forward(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, void *stream);
+int pnpp_fc_backward(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Output heads and losses (forward value and analytic gradient in one launch)
+ * ---------------------------------------------------------------------------------------- */
+
+/* pointnet_pp_vonMises.py:36-37 + train_single_peak_vonMises_KL.py:23-28,83:
+ * o (B,2) raw fc3 output -> mu = tanh(o0)*pi, kappa = softplus(o1);
+ * loss_vec[b] = KL(vM(mu,kappa) || vM(mu_gt,kappa_gt)) by the reference formula (kappa_p <= 1e-6 branch
+ * included, log I0 evaluated as kappa + log(i0e) so kappa >= 89 stays finite where the reference is NaN).
+ * d_o (B,2) = d loss_vec[b] / d o[b,:]  (the host scales by the upstream gradient, 1/B for .mean()). */
+int pnpp_vm_head_kl(const float *o, const float *mu_gt, const float *kappa_gt, int B, float *mu, float *kappa,
+                    float *loss_vec, float *d_o, void *stream);
+/* backward of the activation alone: d_o[b] = (dmu[b]*pi*(1-tanh^2 o0), dkappa[b]*sigmoid(o1)). */
+int pnpp_vm_head_bwd(const float *o, const float *dmu, const float *dkappa, int B, float *d_o, void *stream);
+
+/* train_single_peak_vonMises_KL.py:23-28 on its own: values and d/dmu_p, d/dkappa_p. */
+int pnpp_vm_kl_single(const float *mu_p, const float *kappa_p, const float *mu_q, const float *kappa_q, int n,
+                      float *kl, float *dmu, float *dkappa, void *stream);
+
+/* train_multi_peaks_vonMises_KL.py:38-81 match_loss: per sample K x K cost of the clamped / wrapped KL,
+ * nan_to_num(1e6), optimal assignment (exhaustive over <= 8! permutations, first optimum in lexicographic
+ * order), loss_b = sum w_i c_i / (sum w_i + 1e-8).  mu, kappa, w (B,maxK); vm_gt (B,maxK,3); K_gt (B) int32.
+ * Outputs loss_vec (B), gradients (B,maxK) each, assignment (B,maxK) int32 (-1 beyond K). */
+int pnpp_vm_match_loss(const float *mu, const float *kappa, const float *w, const float *vm_gt, const int32_t *K_gt,
+                       int B, int maxK, float *loss_vec, float *dmu, float *dkappa, float *dw, int32_t *assign,
+                       void *stream);
+
+/* pointnet_pp_mvM.py:91-125: raw head outputs -> (mu, kappa, weight) and the backward of that map.
+ * pi_raw (B,K), mu_raw (B,2K), kappa_raw (B,K). */
+int pnpp_mvm_head(const float *pi_raw, const float *mu_raw, const float *kappa_raw, int B, int K, float temp,
+                  float kappa_max, float *mu, float *kappa, float *weight, void *stream);
+int pnpp_mvm_head_bwd(const float *pi_raw, const float *mu_raw, const float *kappa_raw, const float *weight,
+                      const float *dmu, const float *dkappa, const float *dweight, int B, int K, float temp,
+                      float kappa_max, float *dpi_raw, float *dmu_raw, float *dkappa_raw, void *stream);
+
+/* train_8dir_KL.py:60-68: loss_vec[b] = -sum p * log_softmax(logits); dlogits = softmax*sum(p) - p. */
+int pnpp_soft_ce(const float *logits, const float *p, int B, int C, float *loss_vec, float *dlogits, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Step glue on one flat parameter / gradient buffer
+ * (train_single_peak_vonMises_KL.py:80,85; train_multi_peaks_vonMises_KL.py:221,235-236)
+ * ---------------------------------------------------------------------------------------- */
+/* torch.optim.Adam(lr, betas, eps, weight_decay=0) single fused update; step is 1-based. */
+int pnpp_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, int step, float lr,
+                   float beta1, float beta2, float eps, float grad_scale, void *stream);
+/* sum of squares of a flat buffer into out[0] (double), deterministic two-level reduction. */
+int pnpp_sumsq(const float *x, size_t n, double *out, void *scratch, size_t scratch_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNPP_HIP_H */
