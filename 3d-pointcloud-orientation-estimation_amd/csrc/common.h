@@ -48,6 +48,22 @@ struct Carver {
     size_t bytes() const { return align_up(off, 256); }
 };
 
+// ---- opt-in per-launch HIP-event timing (pnpp_profile_enable / pnpp_profile_report) ----
+bool prof_on();
+void prof_begin(hipStream_t st, const char *fmt, ...);
+void prof_end(hipStream_t st);
+struct ProfScope {
+    hipStream_t st;
+    bool on;
+    template <typename... Args>
+    ProfScope(hipStream_t s, const char *fmt, Args... args) : st(s), on(prof_on()) {
+        if (on) prof_begin(st, fmt, args...);
+    }
+    ~ProfScope() {
+        if (on) prof_end(st);
+    }
+};
+
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kMaxStatBlocks = 512;  // upper bound on partial-statistic slabs per GEMM
 

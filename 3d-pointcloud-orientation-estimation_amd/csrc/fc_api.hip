@@ -180,6 +180,78 @@ fc_bwd_ln_cols_kernel(const float *__restrict__ gbuf, const float *__restrict__ 
     }
 }
 
+// ---- narrow output layers (N <= 16, no norm): fc3 / head_pi / head_mu / head_kappa ------------------
+// Too narrow for a 32-wide MFMA tile; these are K-long dot products, one wavefront per output element.
+constexpr int FC_SMALL_N = 16;
+
+__global__ void __launch_bounds__(256) fc_small_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                           const float *__restrict__ b, const uint8_t *__restrict__ mask,
+                                                           float drop_scale, int relu, int K, int N, float *__restrict__ z,
+                                                           float *__restrict__ y) {
+    const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float *xr = x + (size_t)m * K;
+    for (int n = wave; n < N; n += 4) {
+        const float *wr = w + (size_t)n * K;
+        double acc = 0.0;
+        for (int k = lane; k < K; k += 64) acc += (double)xr[k] * (double)wr[k];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) acc += shfl_xor_f64(acc, s);
+        if (lane == 0) {
+            const float zz = (float)acc;  // bias-free pre-activation, like the MFMA path keeps it
+            z[(size_t)m * N + n] = zz;
+            float v = zz + b[n];
+            if (relu) v = fmaxf(v, 0.f);
+            if (mask) v = mask[(size_t)m * N + n] ? v * drop_scale : 0.f;
+            y[(size_t)m * N + n] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ float fc_small_dz(const float *dy, const float *z, const float *b, const uint8_t *mask,
+                                             float drop_scale, int relu, size_t i, int n) {
+    float g = dy[i];
+    if (mask) g = mask[i] ? g * drop_scale : 0.f;
+    if (relu && !(z[i] + b[n] > 0.f)) g = 0.f;
+    return g;
+}
+
+// dW[n][k] = sum_m dz[m][n] x[m][k];  db[n] = sum_m dz[m][n]      grid (N), threads over k
+__global__ void __launch_bounds__(256) fc_small_dw_kernel(const float *__restrict__ dy, const float *__restrict__ z,
+                                                          const float *__restrict__ b, const uint8_t *__restrict__ mask,
+                                                          float drop_scale, int relu, const float *__restrict__ x, int M,
+                                                          int K, int N, float *__restrict__ dw, float *__restrict__ db) {
+    const int n = blockIdx.x;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        double acc = 0.0;
+        for (int m = 0; m < M; ++m)
+            acc += (double)fc_small_dz(dy, z, b, mask, drop_scale, relu, (size_t)m * N + n, n) * (double)x[(size_t)m * K + k];
+        dw[(size_t)n * K + k] = (float)acc;
+    }
+    if (threadIdx.x == 0) {
+        double acc = 0.0;
+        for (int m = 0; m < M; ++m) acc += (double)fc_small_dz(dy, z, b, mask, drop_scale, relu, (size_t)m * N + n, n);
+        db[n] = (float)acc;
+    }
+}
+
+// dx[m][k] = sum_n dz[m][n] w[n][k]      grid (M), threads over k
+__global__ void __launch_bounds__(256) fc_small_dx_kernel(const float *__restrict__ dy, const float *__restrict__ z,
+                                                          const float *__restrict__ b, const uint8_t *__restrict__ mask,
+                                                          float drop_scale, int relu, const float *__restrict__ w, int K, int N,
+                                                          float *__restrict__ dx) {
+    const int m = blockIdx.x;
+    float g[FC_SMALL_N];
+#pragma unroll
+    for (int n = 0; n < FC_SMALL_N; ++n) g[n] = n < N ? fc_small_dz(dy, z, b, mask, drop_scale, relu, (size_t)m * N + n, n) : 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int n = 0; n < FC_SMALL_N; ++n)
+            if (n < N) acc = fmaf(g[n], w[(size_t)n * K + k], acc);
+        dx[(size_t)m * K + k] = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 struct FcSaved {
     float *z, *mean, *istd, *scale, *shift;
@@ -216,10 +288,13 @@ static FcScratch fc_scratch_layout(const pnpp_fc_desc *d, void *base) {
     return s;
 }
 
+static bool fc_is_small(const pnpp_fc_desc *d) { return d->norm == PNPP_NORM_NONE && d->N <= FC_SMALL_N; }
+
 static int fc_check(const pnpp_fc_desc *d) {
     PNPP_REQUIRE(d, PNPP_ERR_ARG, "fc: null descriptor");
     PNPP_REQUIRE(d->M > 0 && d->K > 0 && d->N > 0, PNPP_ERR_ARG, "fc: non-positive size M=%d K=%d N=%d", d->M, d->K, d->N);
-    PNPP_REQUIRE(d->K % 4 == 0 && d->N % 4 == 0, PNPP_ERR_ARG, "fc: K=%d and N=%d must be multiples of 4", d->K, d->N);
+    if (!fc_is_small(d))
+        PNPP_REQUIRE(d->K % 4 == 0 && d->N % 4 == 0, PNPP_ERR_ARG, "fc: K=%d and N=%d must be multiples of 4", d->K, d->N);
     PNPP_REQUIRE(d->norm >= PNPP_NORM_NONE && d->norm <= PNPP_NORM_LAYER, PNPP_ERR_ARG, "fc: bad norm kind %d", d->norm);
     return PNPP_OK;
 }
@@ -231,6 +306,14 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
     if (d->norm == PNPP_NORM_BATCH) PNPP_REQUIRE(a->rm && a->rv, PNPP_ERR_ARG, "fc_forward: running statistics are null");
     const FcSaved sv = fc_saved_layout(d, a->saved);
     const FcScratch sc = fc_scratch_layout(d, a->scratch);
+
+    if (fc_is_small(d)) {
+        ProfScope ps(st, "fc_small_fwd_kernel M=%d N=%d K=%d", d->M, d->N, d->K);
+        hipLaunchKernelGGL(fc_small_fwd_kernel, dim3(d->M), dim3(256), 0, st, a->x, a->w, a->b, a->mask, d->drop_scale, d->relu,
+                           d->K, d->N, sv.z, a->y);
+        PNPP_CHECK_LAUNCH("fc_forward(small)");
+        return PNPP_OK;
+    }
 
     PrepItem it{a->w, sc.wt, nullptr, d->N, d->K, d->K, -1};
     PNPP_TRY(launch_prep_weights(&it, 1, st));
@@ -280,6 +363,17 @@ static int fc_backward_impl(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, hi
     if (d->norm != PNPP_NORM_NONE) PNPP_REQUIRE(a->nw && a->nb, PNPP_ERR_ARG, "fc_backward: norm affine parameters are null");
     const FcSaved sv = fc_saved_layout(d, const_cast<void *>(a->saved));
     const FcScratch sc = fc_scratch_layout(d, a->scratch);
+
+    if (fc_is_small(d)) {
+        ProfScope ps(st, "fc_small_bwd M=%d N=%d K=%d", d->M, d->N, d->K);
+        hipLaunchKernelGGL(fc_small_dw_kernel, dim3(d->N), dim3(256), 0, st, a->dy, sv.z, a->b, a->mask, d->drop_scale, d->relu,
+                           a->x, d->M, d->K, d->N, a->dw, a->db);
+        if (a->dx)
+            hipLaunchKernelGGL(fc_small_dx_kernel, dim3(d->M), dim3(256), 0, st, a->dy, sv.z, a->b, a->mask, d->drop_scale,
+                               d->relu, a->w, d->K, d->N, a->dx);
+        PNPP_CHECK_LAUNCH("fc_backward(small)");
+        return PNPP_OK;
+    }
 
     // 1. dz = d loss / d (x W^T)  (M x N) and the parameter gradients of the normalisation
     if (d->norm == PNPP_NORM_LAYER) {

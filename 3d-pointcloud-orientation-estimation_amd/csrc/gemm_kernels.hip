@@ -264,6 +264,7 @@ static int launch_gemm_cfg(const AOperand &A, const float *Bm, int ldb, int M, i
     const int gx = tiles < kMaxStatBlocks ? tiles : kMaxStatBlocks;
     const dim3 grid(gx, cdiv(Nout, BN)), block(256);
     if (nslab) *nslab = gx;
+    ProfScope ps(st, "gemm_kernel<%d,%d,%d,%d,A%d,E%d> M=%d N=%d K=%d", BM, BN, WM, WN, A.mode, E.mode, M, Nout, Kd);
 #define PNPP_LAUNCH(AM, EM)                                                                                         \
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AM, EM>), grid, block, 0, st, A, Bm, ldb, M, Nout, Kd, E); \
     break;
@@ -386,6 +387,7 @@ int launch_dw(const AOperand &dz, int Nc, const AOperand &a2, int Kp, int M, flo
     rps = (rps + 1) & ~1;  // even: a row pair never straddles two splits
     const int waves = tilesC * tilesK * nsplit;
     const dim3 grid(cdiv(waves, 4)), block(256);
+    ProfScope ps(st, "dw_kernel<A%d,A%d> M=%d N=%d K=%d split=%d", dz.mode, a2.mode, M, Nc, Kp, nsplit);
 #define PNPP_DW(DM, AM)                                                                                              \
     hipLaunchKernelGGL((dw_kernel<DM, AM, 2, 2>), grid, block, 0, st, dz, a2, M, Nc, Kp, tilesC, tilesK, rps, kp_pad, slab); \
     break;
@@ -436,6 +438,7 @@ int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kv
                        hipStream_t st) {
     const int total = Nc * Kvalid;
     const int grid = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;
+    ProfScope ps(st, "slab_reduce_kernel N=%d K=%d split=%d", Nc, Kvalid, nsplit);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, st, slab, nsplit, Nc, kp_pad, Kvalid, perm_D, out, ldo);
     PNPP_CHECK_LAUNCH("slab_reduce");
     return PNPP_OK;
@@ -472,6 +475,7 @@ int launch_prep_weights(const PrepItem *items, int n, hipStream_t st) {
         maxtot = items[i].Kd * items[i].Cout > maxtot ? items[i].Kd * items[i].Cout : maxtot;
     }
     const int gx = cdiv(maxtot, 256) < 256 ? cdiv(maxtot, 256) : 256;
+    ProfScope ps(st, "prep_weights_kernel n=%d", n);
     hipLaunchKernelGGL(prep_weights_kernel, dim3(gx, n), dim3(256), 0, st, P);
     PNPP_CHECK_LAUNCH("prep_weights");
     return PNPP_OK;
@@ -559,6 +563,7 @@ bn_finalize_bwd_kernel(const double *__restrict__ slab, int nslab, int C, double
 int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, const float *bias, const float *gamma,
                            const float *beta, float *rm, float *rv, float momentum, float eps, int training, float *mean,
                            float *istd, float *scale, float *shift, hipStream_t st) {
+    ProfScope ps(st, "bn_finalize_fwd_kernel C=%d", C);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, slab, nslab, C, count, bias, gamma, beta,
                        rm, rv, momentum, eps, training, mean, istd, scale, shift);
     PNPP_CHECK_LAUNCH("bn_finalize_fwd");
@@ -568,6 +573,7 @@ int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, c
 int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, int training, const float *gamma,
                            const float *mean, const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias,
                            hipStream_t st) {
+    ProfScope ps(st, "bn_finalize_bwd_kernel C=%d", C);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, slab, nslab, C, count, training, gamma,
                        mean, istd, cst, dgamma, dbeta, dbias);
     PNPP_CHECK_LAUNCH("bn_finalize_bwd");
@@ -602,6 +608,7 @@ int launch_pool_fwd(const float *z, const float *scale, const float *shift, int 
                     hipStream_t st) {
     const size_t total = (size_t)G * C;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    ProfScope ps(st, "pool_fwd_kernel G=%d K=%d C=%d", G, K, C);
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid), dim3(256), 0, st, z, scale, shift, G, K, C, out, arg);
     PNPP_CHECK_LAUNCH("pool_fwd");
     return PNPP_OK;
@@ -648,6 +655,7 @@ int launch_pool_bwd(const float *dout, const int32_t *arg, const float *z, const
     int gy = cdiv(G, 4);
     if (gy > kMaxStatBlocks) gy = kMaxStatBlocks;
     *nslab = gy;
+    ProfScope ps(st, "pool_bwd_kernel G=%d K=%d C=%d", G, K, C);
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(cdiv(C, 64), gy), dim3(256), 0, st, dout, arg, z, scale, shift, mean, istd, G, K, C,
                        dy, slab);
     PNPP_CHECK_LAUNCH("pool_bwd");

@@ -364,6 +364,7 @@ int launch_knn(const float *new_xyz, const float *xyz, int B, int S, int N, int 
     PNPP_REQUIRE(k <= N, PNPP_ERR_RANGE, "selected index k out of range (k=%d > N=%d)", k, N);
     PNPP_REQUIRE(k <= KNN_KMAX, PNPP_ERR_ARG, "knn: nsample=%d exceeds the supported maximum %d", k, KNN_KMAX);
     PNPP_REQUIRE(B <= 65535, PNPP_ERR_ARG, "knn: batch %d exceeds grid limit", B);
+    ProfScope ps(st, "knn_kernel B=%d S=%d N=%d k=%d", B, S, N, k);
     hipLaunchKernelGGL(knn_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, st, new_xyz, xyz, S, N, k, idx);
     PNPP_CHECK_LAUNCH("knn");
     return PNPP_OK;
@@ -378,6 +379,7 @@ int launch_gather_centres(const float *xyz, const int32_t *centre, int B, int N,
 
 int launch_scatter_rows_bwd(const float *dout, const int32_t *idx, int B, int N, int C, int M, float *dpoints, hipStream_t st) {
     PNPP_REQUIRE(B <= 65535, PNPP_ERR_ARG, "index_points_bwd: batch %d exceeds grid limit", B);
+    ProfScope ps(st, "scatter_rows_bwd_kernel B=%d N=%d C=%d M=%d", B, N, C, M);
     hipLaunchKernelGGL(scatter_rows_bwd_kernel, dim3(N, B), dim3(64), 0, st, dout, idx, N, C, M, dpoints);
     PNPP_CHECK_LAUNCH("index_points_bwd");
     return PNPP_OK;

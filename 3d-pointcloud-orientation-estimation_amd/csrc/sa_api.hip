@@ -8,6 +8,10 @@
 // free, copy to the host or synchronise (they can be captured into a hipGraph).
 #include <stdarg.h>
 
+#include <map>
+#include <string>
+#include <vector>
+
 #include "kernels.h"
 
 namespace pnpp {
@@ -19,6 +23,31 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- opt-in launch timing ----------------------------------------------------------------------
+struct ProfRec {
+    std::string tag;
+    hipEvent_t a, b;
+};
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+
+bool prof_on() { return g_prof; }
+void prof_begin(hipStream_t st, const char *fmt, ...) {
+    char buf[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    ProfRec r;
+    r.tag = buf;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, st);
+    g_recs.push_back(r);
+}
+void prof_end(hipStream_t st) {
+    if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().b, st);
 }
 
 #define PNPP_TRY(expr)                 \
@@ -289,6 +318,43 @@ using namespace pnpp;
 
 extern "C" const char *pnpp_last_error(void) { return g_err; }
 extern "C" int pnpp_abi_version(void) { return 1; }
+
+extern "C" int pnpp_profile_enable(int on) {
+    for (auto &r : g_recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_recs.clear();
+    g_prof = on != 0;
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_profile_report(char *buf, size_t buflen) {
+    PNPP_REQUIRE(buf && buflen > 0, PNPP_ERR_ARG, "profile_report: null buffer");
+    std::map<std::string, std::pair<long, double>> agg;
+    std::vector<std::string> order;
+    for (auto &r : g_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) {
+            set_error("profile_report: event query failed");
+            return PNPP_ERR_LAUNCH;
+        }
+        if (!agg.count(r.tag)) order.push_back(r.tag);
+        agg[r.tag].first += 1;
+        agg[r.tag].second += (double)ms;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_recs.clear();
+    size_t off = 0;
+    buf[0] = 0;
+    for (auto &t : order) {
+        int n = snprintf(buf + off, buflen - off, "%s\t%ld\t%.6f\n", t.c_str(), agg[t].first, agg[t].second);
+        if (n < 0 || (size_t)n >= buflen - off) break;
+        off += (size_t)n;
+    }
+    return (int)order.size();
+}
 
 extern "C" size_t pnpp_sa_saved_bytes(const pnpp_sa_desc *d) {
     SaGeom g;

@@ -59,6 +59,8 @@ _i, _f, _u64, _sz = C.c_int, C.c_float, C.c_uint64, C.c_size_t
 SIGNATURES = {
     "pnpp_last_error": (C.c_char_p, []),
     "pnpp_abi_version": (_i, []),
+    "pnpp_profile_enable": (_i, [_i]),
+    "pnpp_profile_report": (_i, [C.c_char_p, _sz]),
     "pnpp_square_distance": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp]),
     "pnpp_knn": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp]),
     "pnpp_fps": (_i, [_fp, _i, _i, _i, _fp, _fp, _fp]),

@@ -1,0 +1,61 @@
+"""One process per GPU, batch (cloud) sharding, ONE gradient exchange per step.
+
+The reference is single-process; this is the MI355X-native scale-out: every rank holds a
+replica, takes a contiguous shard of the global batch, and after backward the ranks sum one flat float32
+gradient buffer (~5.9 MB) with a single all-reduce -- RCCL over xGMI on GPUs (`backend="nccl"` is RCCL on
+ROCm), gloo in the CPU tests.  The 1/world factor is folded into the optimiser's grad_scale, BatchNorm
+statistics stay per rank (what DDP does to the reference's modules), and centre sampling is decorrelated
+across ranks through pnpp_hip.sampling.set_rank.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialises torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1."""
+    rank, local_rank, world = env_world()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    try:
+        from . import sampling
+        sampling.set_rank(rank)
+    except Exception:  # pragma: no cover
+        pass
+    return rank, local_rank, world
+
+
+def shard_bounds(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of the global batch for `rank` (first `global_batch % world` ranks get one more)."""
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_flat(flat: torch.Tensor, src: int = 0) -> None:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat, src)
+
+
+def all_reduce_flat_grad(flat_g: torch.Tensor, async_op: bool = False):
+    """Sum the flat gradient buffer over ranks (the caller folds 1/world into the optimiser step)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.all_reduce(flat_g, op=dist.ReduceOp.SUM, async_op=async_op)
+    return None
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1

@@ -1,0 +1,78 @@
+"""Step glue on ONE flat parameter / gradient buffer.
+
+The reference's loops call opt.zero_grad(), loss.backward(), [clip_grad_norm_], opt.step() over ~60 small
+tensors (train_single_peak_vonMises_KL.py:80-85, train_multi_peaks_vonMises_KL.py:221-236).  Here every
+parameter is a view into one contiguous buffer and every .grad a view into another, so zero_grad is one
+memset, the optimiser one kernel launch, and data parallelism one all-reduce.
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable, Optional
+
+import torch
+
+from . import _lib as L
+from .ops import _stream
+
+
+class FlatAdam:
+    """torch.optim.Adam(params, lr, betas, eps) semantics (no amsgrad / weight decay), one fused launch."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdam runs on the GPU only (no CPU fallback exists in this package)")
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        total = sum(p.numel() for p in self.params)
+        self.flat_p = torch.empty(total, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self._views = []
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + n].view(p.shape)
+            g = self.flat_g[off:off + n].view(p.shape)
+            p.grad = g
+            self._views.append(g)
+            off += n
+        self.step_count = 0
+        self._scratch = torch.empty(1024 * 8 + 8, device=dev, dtype=torch.uint8)
+
+    @property
+    def numel(self) -> int:
+        return self.flat_p.numel()
+
+    def zero_grad(self) -> None:
+        """One memset; autograd then accumulates in place into the flat buffer."""
+        self.flat_g.zero_()
+        for p, g in zip(self.params, self._views):
+            if p.grad is not g:
+                p.grad = g
+
+    def grad_norm(self) -> torch.Tensor:
+        """L2 norm of the whole gradient as a 0-dim float64 tensor on the device (no host sync)."""
+        out = torch.empty(1, device=self.flat_g.device, dtype=torch.float64)
+        L.check(L.lib().pnpp_sumsq(self.flat_g.data_ptr(), self.flat_g.numel(), out.data_ptr(), self._scratch.data_ptr(),
+                                   self._scratch.numel(), _stream()))
+        return out.sqrt_()[0]
+
+    def clip_grad_norm_(self, max_norm: float) -> float:
+        """torch.nn.utils.clip_grad_norm_ semantics; the scale is folded into the next step()."""
+        norm = float(self.grad_norm())
+        self._pending_scale = min(1.0, max_norm / (norm + 1e-6))
+        return norm
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        self.step_count += 1
+        scale = grad_scale * getattr(self, "_pending_scale", 1.0)
+        self._pending_scale = 1.0
+        L.check(L.lib().pnpp_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                                       self.exp_avg_sq.data_ptr(), self.flat_p.numel(), self.step_count, self.lr,
+                                       self.betas[0], self.betas[1], self.eps, float(scale), _stream()))

@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- clouds/sec, fwd+bwd, pointnet_pp_vonMises, N=1024 (BASELINE.json metric) on N GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One step = zero_grad + forward (device-side centre sampling, kNN grouping, fused MLP, head) + single-peak
+von-Mises KL + backward + [one flat-gradient all-reduce when N > 1] + fused Adam, on a batch of B=32 synthetic
+clouds per GPU that is already resident in HBM.  float32 end to end (exact-f32 MFMA), weak scaling.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      -- the kernel that took the most time: achieved rate from HIP events recorded by the library
+                   around every launch in a SEPARATE instrumented pass (never while throughput is timed)
+  cpu_baseline  -- the CPU oracle (float32 restatement of the reference step) timed on the host cores on a
+                   bounded sample of the same workload (rank 0, N=1 only); baseline only, not a target.
+"""
+import argparse
+import json
+import os
+import re
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "3d-pointcloud-orientation-estimation_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+N_POINTS = 1024
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32x32x2_f32)
+
+
+def build_step(model, opt, xyz, mu_gt, kappa_gt, world):
+    from pnpp_hip import ops, dist as pdist
+
+    def step():
+        opt.zero_grad()
+        mu, kappa = model(xyz)
+        loss = ops.kl_von_mises_single(mu, kappa, mu_gt, kappa_gt).mean()
+        loss.backward()
+        pdist.all_reduce_flat_grad(opt.flat_g)
+        opt.step(grad_scale=1.0 / world)
+        return loss
+
+    return step
+
+
+def kernel_cost(tag: str):
+    """Algorithmic FLOPs and HBM bytes of one launch from its tag ('Kernels')."""
+    m = re.search(r"M=(\d+) N=(\d+) K=(\d+)", tag)
+    if not m:
+        return None
+    M, N, K = (int(x) for x in m.groups())
+    flops = 2.0 * M * N * K
+    if tag.startswith("gemm_kernel"):
+        e = int(re.search(r",E(\d)>", tag).group(1))
+        a = int(re.search(r",A(\d),", tag).group(1))
+        byts = 4.0 * (M * N + K * N)                      # write C, read weights
+        byts += 4.0 * M * K * (2 if a == 4 else 1)        # read A (dy and z for the BatchNorm-backward operand)
+        if a == 2:                                         # gathered operand: indices, not rows, are the compulsory part
+            byts = 4.0 * (M * N + K * N) + 4.0 * M
+        if e == 2:
+            byts += 4.0 * M * N                            # read the previous layer's z for the ReLU mask
+        return flops, byts
+    if tag.startswith("dw_kernel"):
+        a2 = int(re.search(r",A(\d)>", tag).group(1))
+        dzm = int(re.search(r"<A(\d),", tag).group(1))
+        split = int(re.search(r"split=(\d+)", tag).group(1))
+        byts = 4.0 * M * N * (2 if dzm == 4 else 1) + 4.0 * M * K * (0 if a2 == 2 else 1) + 4.0 * split * N * K
+        return flops, byts
+    return None
+
+
+def roofline_leg(step, nsteps=5):
+    """Instrumented pass: HIP events around every launch, aggregated per (kernel, shape) tag."""
+    from pnpp_hip import _lib
+    import ctypes
+    lib = _lib.lib()
+    torch.cuda.synchronize()
+    lib.pnpp_profile_enable(1)
+    for _ in range(nsteps):
+        step()
+    torch.cuda.synchronize()
+    buf = ctypes.create_string_buffer(1 << 16)
+    ntag = lib.pnpp_profile_report(buf, len(buf))
+    lib.pnpp_profile_enable(0)
+    rows = []
+    for line in buf.value.decode().splitlines():
+        tag, cnt, ms = line.split("\t")
+        rows.append((tag, int(cnt), float(ms)))
+    if ntag <= 0 or not rows:
+        return None, []
+    rows.sort(key=lambda r: -r[2])
+    total = sum(r[2] for r in rows)
+    table = [{"kernel": t, "launches": c, "avg_us": 1e3 * ms / c, "share": ms / total} for t, c, ms in rows[:12]]
+    for tag, cnt, ms in rows:                              # dominant kernel that has a cost model
+        cost = kernel_cost(tag)
+        if cost is None:
+            continue
+        flops, byts = cost
+        sec = ms * 1e-3 / cnt
+        t_mfma, t_hbm = flops / (MFMA_F32_PEAK_TFLOPS * 1e12), byts / (HBM_PEAK_GBS * 1e9)
+        if t_mfma >= t_hbm:
+            ach = flops / sec / 1e12
+            roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / MFMA_F32_PEAK_TFLOPS}
+        else:
+            ach = byts / sec / 1e9
+            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+        roof.update(kernel=tag, avg_us=sec * 1e6, launches_per_step=cnt / nsteps, share_of_kernel_time=ms / total,
+                    alg_flops=flops, alg_bytes=byts, traffic=None)
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from a separate --pmc pass
+        if os.path.exists(pmc):
+            try:
+                roof["traffic"] = json.load(open(pmc)).get(tag)
+            except Exception:
+                pass
+        return roof, table
+    return None, table
+
+
+def cpu_baseline(B, budget_s=20.0):
+    """The CPU oracle's float32 step (restatement of the reference's CPU path) on the host cores."""
+    from oracle import restatement as R
+    from models.pointnet_pp_vonMises import PointNetPPVonMises
+    torch.manual_seed(42)
+    state = PointNetPPVonMises().state_dict()
+    P = R.cast_params(state, torch.float32)
+    params = [v for v in P.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    xyz, mu_gt, kappa_gt, _ = R.synthetic_clouds(B, N_POINTS, seed=1234)
+    mask_gen = torch.Generator().manual_seed(1)
+
+    def step():
+        opt.zero_grad()
+        centres = R.replay_centres(B)
+        mask = (torch.rand(B, 256, generator=mask_gen) < 0.5).float()
+        mu, kappa = R.vonmises_forward(xyz, P, centres, mask, True, None)
+        loss = R.kl_single(mu, kappa, mu_gt, kappa_gt).mean()
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    step()
+    t0 = time.perf_counter()
+    times = []
+    while time.perf_counter() - t0 < budget_s and len(times) < 40:
+        t = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "clouds/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} steps of batch {B} x {N_POINTS} points, median step {med * 1e3:.1f} ms, "
+                      f"fwd+loss+bwd+Adam, oracle/restatement.py float32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU (config 2: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from pnpp_hip import _lib, dist as pdist, optim
+    from models.pointnet_pp_8dir import PointNetSetAbstraction
+    from models.pointnet_pp_vonMises import PointNetPPVonMises
+    import synthetic
+    import torch.distributed as tdist
+
+    _lib.lib()                                             # fail loudly if the HIP extension is missing
+    rank, local_rank, world = pdist.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    torch.manual_seed(42)                                  # train_single_peak_vonMises_KL.py:19-20
+    PointNetSetAbstraction.sampler = "device"              # centre sampling on the GPU (same distribution as randperm)
+    model = PointNetPPVonMises().to(dev).train()
+    opt = optim.FlatAdam(model.parameters(), lr=1e-3)
+    pdist.broadcast_flat(opt.flat_p)
+    B = args.batch
+    xyz, mu_gt, kappa_gt, _ = synthetic.rotated_clouds(B, N_POINTS, seed=1234 + rank)
+    xyz, mu_gt, kappa_gt = xyz.to(dev), mu_gt.to(dev), kappa_gt.to(dev)
+    step = build_step(model, opt, xyz, mu_gt, kappa_gt, world)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            tdist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        tdist.all_reduce(elapsed, op=tdist.ReduceOp.MAX)
+    elapsed = float(elapsed)
+    final_loss = float(loss)
+
+    roof, table = (None, [])
+    if not args.no_roofline and rank == 0:
+        roof, table = roofline_leg(step)
+    cpu = None
+    if world > 1:
+        tdist.barrier()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(B)
+        ms = 1e3 * elapsed / args.steps
+        out = {
+            "metric": "clouds/sec fwd+bwd, pointnet_pp_vonMises N=1024", "value": world * B * args.steps / elapsed,
+            "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: models/pointnet_pp_vonMises.py single-peak KL, N=1024, batch=32 per GPU, "
+                                   "fwd+loss+bwd+allreduce+Adam, random-init weights (seed 42), device-side centre sampling",
+                       "per_gpu_batch": B, "global_batch": B * world, "points": N_POINTS,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "final_loss": final_loss, "roofline": roof, "cpu_baseline": cpu, "top_kernels": table,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

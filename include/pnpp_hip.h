@@ -40,6 +40,15 @@ typedef enum {
 const char *pnpp_last_error(void);
 int pnpp_abi_version(void);
 
+/* Opt-in per-launch timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+ * pnpp_profile_enable(1) starts recording one event pair around every kernel the library launches (not
+ * thread-safe, adds ~2 us per launch: never on while throughput is being timed); pnpp_profile_report
+ * synchronises the recorded events and writes one line per distinct launch tag,
+ * "<kernel and shape tag>\t<launches>\t<total ms>\n", into buf (truncated to buflen), then clears.
+ * Returns the number of distinct tags, or a negative pnpp_status. */
+int pnpp_profile_enable(int on);
+int pnpp_profile_report(char *buf_host, size_t buflen);
+
 /* ------------------------------------------------------------------------------------------
  * Index primitives
  * ---------------------------------------------------------------------------------------- */

@@ -1,0 +1,166 @@
+"""GPU parity, index kernels: HIP (through the C ABI) vs the CPU oracle and the reference-captured
+golden vectors.  Bar: bit-exact (distance matrix bit-equal, index arrays equal)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from pnpp_hip import ops
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return ops
+
+
+def test_square_distance_bit_exact(ops, oracle, golden):
+    g = golden("index.npz")
+    for i in range(3):
+        got = ops.square_distance(_t(g[f"sq{i}_src"]).cuda(), _t(g[f"sq{i}_dst"]).cuda()).cpu().numpy()
+        assert got.tobytes() == g[f"sq{i}_out"].tobytes()
+    # a larger random case against the oracle (self-distances included: slightly negative values)
+    x = torch.rand(3, 700, 3) * 4 - 2
+    got = ops.square_distance(x[:, :50].cuda(), x.cuda()).cpu()
+    assert got.numpy().tobytes() == oracle.square_distance(x[:, :50], x).numpy().tobytes()
+
+
+def test_knn_matches_reference_sets_and_oracle_order(ops, oracle, golden):
+    g = golden("index.npz")
+    xyz = _t(g["knn_xyz"])
+    c1, c2 = _t(g["knn_c1"].astype(np.int64)), _t(g["knn_c2"].astype(np.int64))
+    new1 = oracle.index_points(xyz, c1)
+    idx1 = ops.knn(new1.cuda(), xyz.cuda(), 32).cpu().numpy()
+    assert np.array_equal(np.sort(idx1, -1), g["knn_idx1_sorted"])            # reference's sets
+    assert np.array_equal(idx1, oracle.knn_indices(new1, xyz, 32).numpy())    # oracle's order too
+    new2 = oracle.index_points(new1, c2)
+    idx2 = ops.knn(new2.cuda(), new1.cuda(), 32).cpu().numpy()
+    assert np.array_equal(np.sort(idx2, -1), g["knn_idx2_sorted"])
+    xr, cr = _t(g["knnr_xyz"]), _t(g["knnr_c"].astype(np.int64))
+    idxr = ops.knn(oracle.index_points(xr, cr).cuda(), xr.cuda(), 7).cpu().numpy()
+    assert np.array_equal(np.sort(idxr, -1), g["knnr_idx_sorted"])
+
+
+@pytest.mark.parametrize("B,N,S,k", [(1, 1, 1, 1), (2, 33, 5, 33), (3, 1500, 9, 64), (2, 2500, 7, 128), (1, 10000, 16, 32)])
+def test_knn_ragged_and_multi_tile(ops, oracle, B, N, S, k):
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    xyz = torch.rand(B, N, 3, generator=g) * 2 - 1
+    new = xyz[:, torch.randperm(N, generator=g)[:S]] if N >= S else xyz[:, :S]
+    got = ops.knn(new.contiguous().cuda(), xyz.cuda(), k).cpu().numpy()
+    assert np.array_equal(got, oracle.knn_indices(new, xyz, k).numpy())
+
+
+def test_knn_duplicates_lowest_index_wins(ops, oracle):
+    """Real clouds smaller than num_points are sampled with replacement (dataloader_*.py:12-14): exact ties."""
+    base = torch.rand(1, 40, 3)
+    xyz = base[:, torch.randint(0, 40, (200,))]
+    got = ops.knn(xyz[:, :10].contiguous().cuda(), xyz.cuda(), 16).cpu().numpy()
+    assert np.array_equal(got, oracle.knn_indices(xyz[:, :10], xyz, 16).numpy())
+
+
+def test_knn_errors(ops):
+    x = torch.rand(1, 5, 3).cuda()
+    with pytest.raises(RuntimeError, match="out of range"):
+        ops.knn(x[:, :2].contiguous(), x, 6)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.knn(x[:, :2].cpu(), x.cpu(), 2)
+    with pytest.raises(TypeError):
+        ops.knn(x[:, :2].double(), x.double(), 2)
+
+
+def test_fps_matches_demo(ops, oracle, golden):
+    g = golden("index.npz")
+    got = ops.farthest_point_sample(_t(g["knn_xyz"]).cuda(), 128, _t(g["fps_start"])).cpu().numpy()
+    assert np.array_equal(got, g["fps_idx"])
+    got = ops.farthest_point_sample(_t(g["knnr_xyz"]).cuda(), 17, _t(g["fpsr_start"])).cpu().numpy()
+    assert np.array_equal(got, g["fpsr_idx"])
+
+
+@pytest.mark.parametrize("B,N,npoint", [(1, 1, 1), (2, 100, 100), (3, 4097, 40), (1, 10000, 64)])
+def test_fps_sizes(ops, oracle, B, N, npoint):
+    g = torch.Generator().manual_seed(N)
+    xyz = torch.rand(B, N, 3, generator=g)
+    start = torch.randint(0, N, (B,), generator=g)
+    got = ops.farthest_point_sample(xyz.cuda(), npoint, start).cpu().numpy()
+    assert np.array_equal(got, oracle.farthest_point_sample(xyz, npoint, start.numpy()).numpy())
+
+
+def test_ball_query_matches_demo(ops, oracle, golden):
+    g = golden("index.npz")
+    xyz = _t(g["knn_xyz"])
+    new = oracle.index_points(xyz, _t(g["fps_idx"].astype(np.int64)))
+    for r in (0.2, 0.4):
+        got = ops.ball_query(r, 32, xyz.cuda(), new.cuda()).cpu().numpy()
+        assert np.array_equal(got, g[f"ball_{r}"])
+    xr = _t(g["knnr_xyz"])
+    newr = oracle.index_points(xr, _t(g["fpsr_idx"].astype(np.int64)))
+    assert np.array_equal(ops.ball_query(0.3, 5, xr.cuda(), newr.cuda()).cpu().numpy(), g["ballr_0.3"])
+
+
+def test_ball_query_empty_and_multi_tile(ops, oracle):
+    xyz = torch.rand(2, 3000, 3)
+    far = torch.full((2, 3, 3), 50.0)                      # nothing inside the radius -> index N everywhere
+    new = torch.cat([xyz[:, 2000:2004], far], 1)
+    for r, ns in ((0.05, 8), (0.3, 64)):
+        got = ops.ball_query(r, ns, xyz.cuda(), new.cuda()).cpu().numpy()
+        assert np.array_equal(got, oracle.ball_query(r, ns, xyz, new).numpy())
+    assert (got[:, 4:] == 3000).all()
+
+
+def test_sample_random_is_a_uniform_ordered_subset(ops):
+    B, N, S = 64, 1024, 128
+    a = ops.sample_random(42, 1, B, N, S, "cuda").cpu().numpy()
+    assert a.shape == (B, S) and a.min() >= 0 and a.max() < N
+    assert all(len(set(r)) == S for r in a)                            # without replacement
+    assert np.array_equal(a, ops.sample_random(42, 1, B, N, S, "cuda").cpu().numpy())   # pure function of (seed, id)
+    b = ops.sample_random(42, 2, B, N, S, "cuda").cpu().numpy()
+    assert not np.array_equal(a, b)
+    assert len({tuple(r) for r in a}) == B                             # clouds draw independently
+    # marginal uniformity: each index is picked with probability S/N; chi-square over many draws
+    cnt = np.zeros(N)
+    for s in range(40):
+        cnt += np.bincount(ops.sample_random(7, s, B, N, S, "cuda").cpu().numpy().ravel(), minlength=N)
+    exp = 40 * B * S / N
+    chi2 = ((cnt - exp) ** 2 / exp).sum()
+    assert 800 < chi2 < 1250, chi2                                      # ~N(1023, 45); (1 - S/N) shrinks it a little
+    # first position is uniform too (ordered subset, not sorted)
+    first = np.concatenate([ops.sample_random(9, s, B, N, S, "cuda").cpu().numpy()[:, 0] for s in range(40)])
+    assert abs(first.mean() - (N - 1) / 2) < 4 * N / np.sqrt(12 * first.size)
+    # full permutation when npoint == N
+    p = ops.sample_random(1, 1, 2, 200, 200, "cuda").cpu().numpy()
+    assert all(sorted(r) == list(range(200)) for r in p)
+
+
+def test_index_points_forward_backward(ops, oracle):
+    g = torch.Generator().manual_seed(3)
+    for C in (3, 64, 130):
+        pts = torch.randn(3, 50, C, generator=g)
+        idx = torch.randint(0, 50, (3, 7, 9), generator=g)
+        a = pts.clone().cuda().requires_grad_(True)
+        out = ops.index_points(a, idx.cuda())
+        ref_in = pts.clone().double().requires_grad_(True)
+        ref = oracle.index_points(ref_in, idx)
+        assert torch.equal(out.cpu(), ref.float())
+        gy = torch.randn(out.shape, generator=g)
+        out.backward(gy.cuda())
+        ref.backward(gy.double())
+        assert torch.allclose(a.grad.cpu().double(), ref_in.grad, rtol=0, atol=1e-5)
+    # 2-D index form (B,S)
+    out = ops.index_points(pts.cuda(), idx[:, :, 0].cuda())
+    assert torch.equal(out.cpu(), oracle.index_points(pts, idx[:, :, 0]))
+
+
+def test_models_base_surface(oracle, golden):
+    from models import base
+    g = golden("index.npz")
+    xyz = _t(g["knn_xyz"]).cuda()
+    new = base.index_points(xyz, _t(g["knn_c1"].astype(np.int64)).cuda())
+    idx = base.query_ball_point(new, xyz, 32)
+    assert idx.dtype == torch.int64 and idx.shape == (2, 128, 32)
+    assert np.array_equal(np.sort(idx.cpu().numpy(), -1), g["knn_idx1_sorted"])
+    d = base.square_distance(new, xyz)
+    assert d.shape == (2, 128, 1024)
