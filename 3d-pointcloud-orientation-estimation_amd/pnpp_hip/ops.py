@@ -162,7 +162,7 @@ class _SetAbstraction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, points, centre_idx, neighbour_idx, cfg, running, *params):
         # params: L x (conv_w, conv_b, bn_w, bn_b); running: L x (running_mean, running_var)
-        K, group_all, training, eps, momentum = cfg
+        K, group_all, training, eps, momentum, sinks = cfg
         Lh = len(params) // 4
         xyz = _f32(xyz, "xyz")
         B, N, _ = xyz.shape
@@ -201,6 +201,7 @@ class _SetAbstraction(torch.autograd.Function):
         a.new_xyz, a.out, a.saved, a.scratch = new_xyz.data_ptr(), out.data_ptr(), saved.data_ptr(), scratch.data_ptr()
         L.check(lib.pnpp_sa_forward(C.byref(desc), C.byref(a), _stream()))
         ctx.desc = desc
+        ctx.sinks = sinks
         ctx.has_points = points is not None
         ctx.save_for_backward(xyz, points if points is not None else xyz.new_empty(0), saved, *conv_w, *bn_w, *bn_b)
         if group_all:
@@ -221,10 +222,14 @@ class _SetAbstraction(torch.autograd.Function):
         dout = _f32(dout, "dout")
         lib = L.lib()
         scratch = _scratch(lib.pnpp_sa_scratch_bytes(C.byref(desc)), xyz.device)
-        d_conv_w = [torch.empty_like(w) for w in conv_w]
-        d_conv_b = [torch.empty(w.shape[0], device=w.device, dtype=torch.float32) for w in conv_w]
-        d_bn_w = [torch.empty_like(w) for w in bn_w]
-        d_bn_b = [torch.empty_like(w) for w in bn_b]
+        # gradient destinations: a parameter's flat-buffer sink when an optimiser registered one (the kernels then
+        # write straight into the flat gradient buffer and autograd has nothing to accumulate), else fresh tensors
+        sinks = ctx.sinks or [None] * (4 * Lh)
+        d_conv_w = [sinks[4 * l] if sinks[4 * l] is not None else torch.empty_like(conv_w[l]) for l in range(Lh)]
+        d_conv_b = [sinks[4 * l + 1] if sinks[4 * l + 1] is not None else
+                    torch.empty(conv_w[l].shape[0], device=xyz.device, dtype=torch.float32) for l in range(Lh)]
+        d_bn_w = [sinks[4 * l + 2] if sinks[4 * l + 2] is not None else torch.empty_like(bn_w[l]) for l in range(Lh)]
+        d_bn_b = [sinks[4 * l + 3] if sinks[4 * l + 3] is not None else torch.empty_like(bn_b[l]) for l in range(Lh)]
         dpoints = torch.empty_like(points) if (points is not None and ctx.needs_input_grad[1]) else None
         a = L.SaBwdArgs()
         a.xyz, a.points = xyz.data_ptr(), _p(points)
@@ -236,7 +241,8 @@ class _SetAbstraction(torch.autograd.Function):
         L.check(lib.pnpp_sa_backward(C.byref(desc), C.byref(a), _stream()))
         grads: List[Optional[torch.Tensor]] = []
         for l in range(Lh):
-            grads += [d_conv_w[l], d_conv_b[l], d_bn_w[l], d_bn_b[l]]
+            for j, t in enumerate((d_conv_w[l], d_conv_b[l], d_bn_w[l], d_bn_b[l])):
+                grads.append(None if sinks[4 * l + j] is not None else t)
         return (None, dpoints, None, None, None, None, *grads)
 
 
@@ -254,12 +260,13 @@ def set_abstraction(xyz, points, centre_idx, nsample, group_all, training, convs
         running += [bn.running_mean, bn.running_var]
     eps = bns[0].eps
     momentum = bns[0].momentum if bns[0].momentum is not None else 0.1
-    cfg = (nsample, bool(group_all), bool(training), eps, momentum)
+    sinks = [getattr(p, "_pnpp_grad_sink", None) for p in params]
+    cfg = (nsample, bool(group_all), bool(training), eps, momentum, sinks if any(s is not None for s in sinks) else None)
     new_xyz, out, nbr = _SetAbstraction.apply(xyz, points, centre_idx, neighbour_idx, cfg, running, *params)
     if training:
-        for bn in bns:
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+        nbt = [bn.num_batches_tracked for bn in bns if bn.num_batches_tracked is not None]
+        if nbt:
+            torch._foreach_add_(nbt, 1)
     if return_neighbours:
         return new_xyz, out, (None if group_all else nbr)
     return new_xyz, out
@@ -271,7 +278,7 @@ def set_abstraction(xyz, points, centre_idx, nsample, group_all, training, convs
 class _FcBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, nw, nb, rm, rv, mask, cfg):
-        norm, relu, training, eps, momentum, drop_scale = cfg
+        norm, relu, training, eps, momentum, drop_scale, sinks = cfg
         x, w, b = _f32(x, "x"), _f32(w, "weight"), _f32(b, "bias")
         M, K = x.shape
         N = w.shape[0]
@@ -295,6 +302,7 @@ class _FcBlock(torch.autograd.Function):
         a.y, a.saved, a.scratch = y.data_ptr(), saved.data_ptr(), scratch.data_ptr()
         L.check(lib.pnpp_fc_forward(C.byref(d), C.byref(a), _stream()))
         ctx.desc = d
+        ctx.sinks = sinks
         ctx.has_norm, ctx.has_mask = nw is not None, mask is not None
         e = x.new_empty(0)
         ctx.save_for_backward(x, w, b, nw if nw is not None else e, nb if nb is not None else e,
@@ -311,15 +319,18 @@ class _FcBlock(torch.autograd.Function):
         lib = L.lib()
         scratch = _scratch(lib.pnpp_fc_scratch_bytes(C.byref(d)), x.device)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw, db = torch.empty_like(w), torch.empty_like(b)
-        dnw = torch.empty_like(nw) if nw is not None else None
-        dnb = torch.empty_like(nb) if nb is not None else None
+        sk = ctx.sinks or (None, None, None, None)
+        dw = sk[0] if sk[0] is not None else torch.empty_like(w)
+        db = sk[1] if sk[1] is not None else torch.empty_like(b)
+        dnw = (sk[2] if sk[2] is not None else torch.empty_like(nw)) if nw is not None else None
+        dnb = (sk[3] if sk[3] is not None else torch.empty_like(nb)) if nb is not None else None
         a = L.FcBwdArgs()
         a.x, a.w, a.b, a.nw, a.nb, a.mask = x.data_ptr(), w.data_ptr(), b.data_ptr(), _p(nw), _p(nb), _p(mask)
         a.dy, a.saved, a.scratch = dy.data_ptr(), saved.data_ptr(), scratch.data_ptr()
         a.dx, a.dw, a.db, a.dnw, a.dnb = _p(dx), dw.data_ptr(), db.data_ptr(), _p(dnw), _p(dnb)
         L.check(lib.pnpp_fc_backward(C.byref(d), C.byref(a), _stream()))
-        return dx, dw, db, dnw, dnb, None, None, None, None
+        keep = lambda t, i: None if sk[i] is not None else t
+        return dx, keep(dw, 0), keep(db, 1), keep(dnw, 2), keep(dnb, 3), None, None, None, None
 
 
 def fc_block(x, linear, norm=None, relu=False, dropout=None, training=True, mask=None):
@@ -350,7 +361,8 @@ def fc_block(x, linear, norm=None, relu=False, dropout=None, training=True, mask
             p = dropout.p if dropout is not None else 0.5
             drop_scale = 1.0 / (1.0 - p)
             mask = mask.to(device=x.device, dtype=torch.uint8)
-    cfg = (kind, relu, training, eps, momentum, drop_scale)
+    sinks = tuple(getattr(p, "_pnpp_grad_sink", None) if p is not None else None for p in (linear.weight, linear.bias, nw, nb))
+    cfg = (kind, relu, training, eps, momentum, drop_scale, sinks if any(s is not None for s in sinks) else None)
     y = _FcBlock.apply(x, linear.weight, linear.bias, nw, nb, rm, rv, mask, cfg)
     if training and kind == L.NORM_BATCH and norm.num_batches_tracked is not None:
         norm.num_batches_tracked += 1

@@ -19,7 +19,10 @@ from .ops import _stream
 class FlatAdam:
     """torch.optim.Adam(params, lr, betas, eps) semantics (no amsgrad / weight decay), one fused launch."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fused_grads=True):
+        """fused_grads: register every parameter's slice of the flat gradient buffer as the destination the
+        backward kernels write to directly (valid when each parameter is used once per step, as in every
+        reference model); autograd then has no per-parameter accumulation kernels to launch."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("optimizer got an empty parameter list")
@@ -40,6 +43,8 @@ class FlatAdam:
             p.data = self.flat_p[off:off + n].view(p.shape)
             g = self.flat_g[off:off + n].view(p.shape)
             p.grad = g
+            if fused_grads:
+                p._pnpp_grad_sink = g
             self._views.append(g)
             off += n
         self.step_count = 0

@@ -98,6 +98,12 @@ def roofline_leg(step, nsteps=5):
     rows.sort(key=lambda r: -r[2])
     total = sum(r[2] for r in rows)
     table = [{"kernel": t, "launches": c, "avg_us": 1e3 * ms / c, "share": ms / total} for t, c, ms in rows[:12]]
+    dump = os.environ.get("PNPP_BENCH_DUMP")
+    if dump:                                               # full per-kernel table for offline analysis
+        with open(dump, "w") as f:
+            f.write(f"# total kernel ms per step {total / nsteps:.4f}\n")
+            for t, c, ms in rows:
+                f.write(f"{1e3 * ms / nsteps:9.1f} us/step  {c / nsteps:4.1f} x {1e3 * ms / c:8.1f} us  {t}\n")
     for tag, cnt, ms in rows:                              # dominant kernel that has a cost model
         cost = kernel_cost(tag)
         if cost is None:
@@ -210,7 +216,7 @@ def main():
     if world > 1:
         tdist.all_reduce(elapsed, op=tdist.ReduceOp.MAX)
     elapsed = float(elapsed)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     roof, table = (None, [])
     if not args.no_roofline and rank == 0:

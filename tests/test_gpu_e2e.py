@@ -186,3 +186,48 @@ def test_samplers_and_eval(oracle):
     with torch.no_grad():
         mu_e, kap_e = model(xyz.cuda(), centres=[c.cuda() for c in centres])
     assert torch.isfinite(mu_e).all() and (kap_e >= 0).all()
+
+
+def test_flat_adam_matches_torch_adam(oracle):
+    """FlatAdam (one fused launch, gradients written straight into the flat buffer) vs torch.optim.Adam
+    (train_single_peak_vonMises_KL.py:70,80-85) with identical centres and masks.
+
+    Two steps only: Adam's update m/(sqrt(v)+eps) is +-lr for ANY gradient well above eps=1e-8, including the
+    structurally-zero ones (sa*.bns.2.bias, conv biases' neighbours) that are pure fp32 noise, so last-bit
+    differences between two correct Adam implementations are amplified to O(lr) from the third step on."""
+    import copy
+    from models.pointnet_pp_vonMises import PointNetPPVonMises
+    from pnpp_hip import ops, optim
+    torch.manual_seed(42)
+    m1 = PointNetPPVonMises().cuda().train()
+    m2 = copy.deepcopy(m1)
+    m3 = copy.deepcopy(m1)
+    o1 = optim.FlatAdam(m1.parameters(), lr=1e-3)
+    o2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    o3 = optim.FlatAdam(m3.parameters(), lr=1e-3, fused_grads=False)
+    xyz, mu_gt, kappa_gt, _ = oracle.synthetic_clouds(8, 1024, seed=3)
+    xyz, mu_gt, kappa_gt = xyz.cuda(), mu_gt.cuda(), kappa_gt.cuda()
+    for it in range(2):
+        torch.manual_seed(100 + it)
+        centres = [c.cuda() for c in oracle.replay_centres(8)]
+        mask = (torch.rand(8, 256) < 0.5).to(torch.uint8).cuda()
+        losses = []
+        for m, o in ((m1, o1), (m2, o2), (m3, o3)):
+            o.zero_grad()
+            mu, kappa = m(xyz, centres=centres, drop_mask=mask)
+            loss = ops.kl_von_mises_single(mu, kappa, mu_gt, kappa_gt).mean()
+            loss.backward()
+            losses.append(loss.item())
+        assert abs(losses[0] - losses[1]) < 1e-6 and losses[0] == losses[2], (it, losses)
+        for (n, a), b, c in zip(m1.named_parameters(), m2.parameters(), m3.parameters()):
+            assert torch.equal(a.grad, c.grad), n                 # fused gradient sinks change nothing
+            assert torch.allclose(a.grad, b.grad, rtol=0, atol=1e-6 * max(1.0, float(b.grad.abs().max()))), n
+        if it == 1:   # gradient norm helper (train_multi_peaks_vonMises_KL.py:235)
+            ref = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m2.parameters()))
+            assert abs(float(o1.grad_norm()) - float(ref)) < 1e-5 * float(ref)
+        o1.step(), o2.step(), o3.step()
+        for (n, a), b, c in zip(m1.named_parameters(), m2.parameters(), m3.parameters()):
+            assert torch.equal(a, c), n
+            assert torch.allclose(a, b, rtol=0, atol=2e-6), (it, n)
+    for a, b in zip(m1.buffers(), m2.buffers()):
+        assert torch.allclose(a.double(), b.double(), rtol=1e-5, atol=1e-6)
