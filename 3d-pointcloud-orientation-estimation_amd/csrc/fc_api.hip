@@ -270,14 +270,13 @@ static FcSaved fc_saved_layout(const pnpp_fc_desc *d, void *base) {
     return s;
 }
 struct FcScratch {
-    float *wt, *dz, *gbuf, *dwslab;
+    float *dz, *gbuf, *dwslab;
     double *slab;
     size_t bytes;
 };
 static FcScratch fc_scratch_layout(const pnpp_fc_desc *d, void *base) {
     Carver cv(base);
     FcScratch s;
-    s.wt = cv.take<float>((size_t)d->K * d->N);
     s.slab = cv.take<double>((size_t)kMaxStatBlocks * 2 * d->N);
     s.dz = cv.take<float>((size_t)d->M * d->N);
     s.gbuf = cv.take<float>((size_t)d->M * d->N);
@@ -315,8 +314,11 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
         return PNPP_OK;
     }
 
-    PrepItem it{a->w, sc.wt, nullptr, d->N, d->K, d->K, -1};
-    PNPP_TRY(launch_prep_weights(&it, 1, st));
+    BOperand W;  // the linear weight (N x K) is read in place
+    W.b = a->w;
+    W.ldb = d->K;
+    W.trans = 1;
+    W.rows = d->K;
     AOperand A;
     A.mode = A_PLAIN;
     A.a = a->x;
@@ -332,10 +334,10 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
             PNPP_REQUIRE(d->M > 1, PNPP_ERR_ARG, "Expected more than 1 value per channel when training");  // torch's message
             E.mode = E_STORE_STATS;
             E.slab = sc.slab;
-            PNPP_TRY(launch_gemm(A, sc.wt, d->N, d->M, d->N, d->K, E, &nslab, st));
+            PNPP_TRY(launch_gemm(A, W, d->M, d->N, d->K, E, &nslab, st));
         } else {
             E.mode = E_STORE;
-            PNPP_TRY(launch_gemm(A, sc.wt, d->N, d->M, d->N, d->K, E, nullptr, st));
+            PNPP_TRY(launch_gemm(A, W, d->M, d->N, d->K, E, nullptr, st));
         }
         PNPP_TRY(launch_bn_finalize_fwd(sc.slab, nslab, d->N, (double)d->M, a->b, a->nw, a->nb, a->rm, a->rv, d->momentum, d->eps,
                                         d->training, sv.mean, sv.istd, sv.scale, sv.shift, st));
@@ -343,7 +345,7 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
                            d->relu, d->M, d->N, a->y);
     } else {
         E.mode = E_STORE;
-        PNPP_TRY(launch_gemm(A, sc.wt, d->N, d->M, d->N, d->K, E, nullptr, st));
+        PNPP_TRY(launch_gemm(A, W, d->M, d->N, d->K, E, nullptr, st));
         if (d->norm == PNPP_NORM_LAYER) {
             hipLaunchKernelGGL(fc_apply_ln_kernel, dim3(d->M), dim3(256), 0, st, sv.z, a->b, a->nw, a->nb, a->mask, d->drop_scale,
                                d->relu, d->N, d->eps, a->y, sv.mean, sv.istd);
@@ -409,7 +411,11 @@ static int fc_backward_impl(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, hi
         E.mode = E_STORE;
         E.c = a->dx;
         E.ldc = d->K;
-        PNPP_TRY(launch_gemm(dz, a->w, d->K, d->M, d->K, d->N, E, nullptr, st));
+        BOperand W;
+        W.b = a->w;
+        W.ldb = d->K;
+        W.rows = d->N;
+        PNPP_TRY(launch_gemm(dz, W, d->M, d->K, d->N, E, nullptr, st));
     }
     return PNPP_OK;
 }

@@ -26,43 +26,70 @@ constexpr int APITCH = KC + 1;  // odd pitch: the 32 rows a half-wave reads land
 // transform applied when the chunk is written to LDS.
 // ---------------------------------------------------------------------------------------------
 struct RawA {
-    float4 p, q;  // p: primary values; q: z (A_DZ) or the centre coordinates to subtract (A_GATHER xyz part)
+    float4 p, q;  // p: primary values; q: z (A_DZ*) or the centre coordinates to subtract (A_GATHER xyz part)
+    int4 ia;      // A_DZ_POOL: arg-max neighbour of the row's group, per channel
 };
 
+// Loads are UNCONDITIONAL on clamped (always valid) addresses and masked afterwards: a load inside a
+// per-lane branch makes hipcc branch around it and drain vmcnt(0) per element, which serialises the
+// whole prefetch (cdna_hip_programming.md, "three .s-level traps", item c).
 template <int MODE>
 __device__ __forceinline__ RawA fetch_a4(const AOperand &A, int row, int k, int M, int Kd) {
     RawA r;
     r.p = make_float4(0.f, 0.f, 0.f, 0.f);
     r.q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row >= M || k >= Kd) return r;
+    r.ia = make_int4(0, 0, 0, 0);
+    const int rc = min(row, M - 1);
     if constexpr (MODE == A_PLAIN || MODE == A_BNRELU) {
-        r.p = *reinterpret_cast<const float4 *>(A.a + (size_t)row * A.lda + k);
+        const int kc = min(k, Kd - 4);
+        r.p = *reinterpret_cast<const float4 *>(A.a + (size_t)rc * A.lda + kc);
     } else if constexpr (MODE == A_DZ) {
-        r.p = *reinterpret_cast<const float4 *>(A.a + (size_t)row * A.lda + k);
-        r.q = *reinterpret_cast<const float4 *>(A.z + (size_t)row * A.lda + k);
+        const int kc = min(k, Kd - 4);
+        r.p = *reinterpret_cast<const float4 *>(A.a + (size_t)rc * A.lda + kc);
+        r.q = *reinterpret_cast<const float4 *>(A.z + (size_t)rc * A.lda + kc);
+    } else if constexpr (MODE == A_DZ_POOL) {
+        const int kc = min(k, Kd - 4);
+        const size_t g = (size_t)(rc / A.K);
+        r.p = *reinterpret_cast<const float4 *>(A.a + g * A.lda + kc);
+        r.ia = *reinterpret_cast<const int4 *>(A.arg + g * A.lda + kc);
+        r.q = *reinterpret_cast<const float4 *>(A.z + (size_t)rc * A.lda + kc);
     } else {  // A_GATHER / A_CONCAT: features first, then xyz (relative to the centre when gathering)
-        size_t prow = (size_t)row, grp = 0;
+        size_t prow = (size_t)rc, grp = 0;
         if constexpr (MODE == A_GATHER) {
-            grp = (size_t)(row / A.K);  // centre row (b*S + s)
-            prow = (size_t)(grp / A.S) * A.N + A.idx[row];
+            grp = (size_t)(rc / A.K);  // centre row (b*S + s)
+            prow = (size_t)(grp / A.S) * A.N + A.idx[rc];
         }
-        if ((A.D & 3) == 0 && k + 3 < A.D) {
-            r.p = *reinterpret_cast<const float4 *>(A.a + prow * A.D + k);
-            return r;
-        }
-        float pv[4] = {0.f, 0.f, 0.f, 0.f}, qv[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kk = k + i;
-            if (kk < A.D) {
-                pv[i] = A.a[prow * A.D + kk];
-            } else if (kk < A.D + 3) {
-                pv[i] = A.xyz[prow * 3 + (kk - A.D)];
-                if constexpr (MODE == A_GATHER) qv[i] = A.new_xyz[grp * 3 + (kk - A.D)];
+        if ((A.D & 3) == 0 && A.D >= 4) {
+            // whole float4 groups are either features (k < D) or the [x y z 0] tail (k == D)
+            const float4 f = *reinterpret_cast<const float4 *>(A.a + prow * A.D + min(k, A.D - 4));
+            const float *xp = A.xyz + prow * 3;
+            const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+            if constexpr (MODE == A_GATHER) {
+                const float *cp = A.new_xyz + grp * 3;
+                c0 = cp[0], c1 = cp[1], c2 = cp[2];
             }
+            const bool feat = k < A.D;
+            r.p = feat ? f : make_float4(x0, x1, x2, 0.f);
+            r.q = feat ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(c0, c1, c2, 0.f);
+        } else {
+            float pv[4], qv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kk = k + i;
+                const bool feat = kk < A.D;
+                const int xc = min(max(kk - A.D, 0), 2);
+                const float *src = feat ? A.a + prow * A.D + kk : A.xyz + prow * 3 + xc;
+                const float v = *src;
+                float cv = 0.f;
+                if constexpr (MODE == A_GATHER) cv = A.new_xyz[grp * 3 + xc];
+                const bool valid = kk < A.D + 3;
+                pv[i] = valid ? v : 0.f;
+                qv[i] = (valid && !feat) ? cv : 0.f;
+            }
+            r.p = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            r.q = make_float4(qv[0], qv[1], qv[2], qv[3]);
         }
-        r.p = make_float4(pv[0], pv[1], pv[2], pv[3]);
-        r.q = make_float4(qv[0], qv[1], qv[2], qv[3]);
     }
     return r;
 }
@@ -84,17 +111,23 @@ __device__ __forceinline__ void xform_a4(const AOperand &A, const RawA &r, int r
         // float32 subtraction of the centre, pointnet_pp_8dir.py:32 (q = 0 for features and for group_all)
         v[0] = __fsub_rn(r.p.x, r.q.x), v[1] = __fsub_rn(r.p.y, r.q.y);
         v[2] = __fsub_rn(r.p.z, r.q.z), v[3] = __fsub_rn(r.p.w, r.q.w);
-    } else {  // A_DZ
+    } else {  // A_DZ / A_DZ_POOL
+        float4 dy = r.p;
+        if constexpr (MODE == A_DZ_POOL) {
+            const int kk = row % A.K;  // neighbour slot of this row inside its group
+            dy.x = kk == r.ia.x ? dy.x : 0.f, dy.y = kk == r.ia.y ? dy.y : 0.f;
+            dy.z = kk == r.ia.z ? dy.z : 0.f, dy.w = kk == r.ia.w ? dy.w : 0.f;
+        }
         const float *c = A.cst + k;
         const float4 g = *reinterpret_cast<const float4 *>(c);
         const float4 mu = *reinterpret_cast<const float4 *>(c + A.C);
         const float4 is = *reinterpret_cast<const float4 *>(c + 2 * A.C);
         const float4 c1 = *reinterpret_cast<const float4 *>(c + 3 * A.C);
         const float4 c2 = *reinterpret_cast<const float4 *>(c + 4 * A.C);
-        v[0] = g.x * (r.p.x - c1.x - (r.q.x - mu.x) * is.x * c2.x);
-        v[1] = g.y * (r.p.y - c1.y - (r.q.y - mu.y) * is.y * c2.y);
-        v[2] = g.z * (r.p.z - c1.z - (r.q.z - mu.z) * is.z * c2.z);
-        v[3] = g.w * (r.p.w - c1.w - (r.q.w - mu.w) * is.w * c2.w);
+        v[0] = g.x * (dy.x - c1.x - (r.q.x - mu.x) * is.x * c2.x);
+        v[1] = g.y * (dy.y - c1.y - (r.q.y - mu.y) * is.y * c2.y);
+        v[2] = g.z * (dy.z - c1.z - (r.q.z - mu.z) * is.z * c2.z);
+        v[3] = g.w * (dy.w - c1.w - (r.q.w - mu.w) * is.w * c2.w);
     }
 }
 
@@ -109,7 +142,7 @@ template <int MODE>
 __device__ __forceinline__ ChanConst load_chan_const(const AOperand &A, int k, int Kvalid) {
     ChanConst c{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (k >= Kvalid) return c;
-    if constexpr (MODE == A_DZ) {
+    if constexpr (MODE == A_DZ || MODE == A_DZ_POOL) {
         const float *p = A.cst + k;
         c.g = p[0], c.mu = p[A.C], c.is = p[2 * A.C], c.c1 = p[3 * A.C], c.c2 = p[4 * A.C];
     } else if constexpr (MODE == A_BNRELU) {
@@ -118,27 +151,37 @@ __device__ __forceinline__ ChanConst load_chan_const(const AOperand &A, int k, i
     return c;
 }
 
-// raw loads of element (row, k): up to two values (second one: z for A_DZ, centre coordinate for A_GATHER)
+// raw loads of element (row, k): up to two values (second one: z for A_DZ*, centre coordinate for A_GATHER).
+// Unconditional loads on clamped indices; xform_a1 masks what was out of range.
 template <int MODE>
-__device__ __forceinline__ float2 fetch_a1(const AOperand &A, int row, int k, int Kvalid, bool ok) {
+__device__ __forceinline__ float2 fetch_a1(const AOperand &A, int row, int k, int Kvalid, int M) {
     float2 r = make_float2(0.f, 0.f);
-    if (!ok || k >= Kvalid) return r;
+    const int rc = min(row, M - 1), kc = min(k, Kvalid - 1);
     if constexpr (MODE == A_PLAIN || MODE == A_BNRELU) {
-        r.x = A.a[(size_t)row * A.lda + k];
+        r.x = A.a[(size_t)rc * A.lda + kc];
     } else if constexpr (MODE == A_DZ) {
-        r.x = A.a[(size_t)row * A.lda + k];
-        r.y = A.z[(size_t)row * A.lda + k];
+        r.x = A.a[(size_t)rc * A.lda + kc];
+        r.y = A.z[(size_t)rc * A.lda + kc];
+    } else if constexpr (MODE == A_DZ_POOL) {
+        const int g = rc / A.K;
+        const size_t gi = (size_t)g * A.lda + kc;
+        const float d = A.a[gi];
+        r.x = (rc - g * A.K == A.arg[gi]) ? d : 0.f;
+        r.y = A.z[(size_t)rc * A.lda + kc];
     } else if constexpr (MODE == A_GATHER) {
-        const int grp = row / A.K;
-        const size_t prow = (size_t)(grp / A.S) * A.N + A.idx[row];
-        if (k < A.D) {
-            r.x = A.a[prow * A.D + k];
-        } else {
-            r.x = A.xyz[prow * 3 + (k - A.D)];
-            r.y = A.new_xyz[(size_t)grp * 3 + (k - A.D)];
-        }
+        const int grp = rc / A.K;
+        const size_t prow = (size_t)(grp / A.S) * A.N + A.idx[rc];
+        const bool feat = kc < A.D;
+        const int xc = min(max(kc - A.D, 0), 2);
+        const float *src = feat ? A.a + prow * A.D + kc : A.xyz + prow * 3 + xc;
+        r.x = *src;
+        const float cv = A.new_xyz[(size_t)grp * 3 + xc];
+        r.y = feat ? 0.f : cv;
     } else {  // A_CONCAT
-        r.x = k < A.D ? A.a[(size_t)row * A.D + k] : A.xyz[(size_t)row * 3 + (k - A.D)];
+        const bool feat = kc < A.D;
+        const int xc = min(max(kc - A.D, 0), 2);
+        const float *src = feat ? A.a + (size_t)rc * A.D + kc : A.xyz + (size_t)rc * 3 + xc;
+        r.x = *src;
     }
     return r;
 }
@@ -150,7 +193,7 @@ __device__ __forceinline__ float xform_a1(const float2 r, const ChanConst &c, in
         return r.x;
     } else if constexpr (MODE == A_BNRELU) {
         return fmaxf(fmaf(r.x, c.sc, c.sh), 0.f);
-    } else if constexpr (MODE == A_DZ) {
+    } else if constexpr (MODE == A_DZ || MODE == A_DZ_POOL) {
         return c.g * (r.x - c.c1 - (r.y - c.mu) * c.is * c.c2);
     } else {
         return __fsub_rn(r.x, r.y);
@@ -162,12 +205,16 @@ __device__ __forceinline__ float xform_a1(const float2 r, const ChanConst &c, in
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int AMODE, int EMODE>
 __global__ void __launch_bounds__(WM * WN * 64, 2)
-gemm_kernel(const AOperand A, const float *__restrict__ Bm, int ldb, int M, int Nout, int Kd, const Epilogue E) {
+gemm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, const Epilogue E) {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
     constexpr int NTHR = WM * WN * 64;
     static_assert(TM % 32 == 0 && TN % 32 == 0 && (BM * (KC / 4)) % NTHR == 0 && (KC * (BN / 4)) % NTHR == 0, "tile configuration");
-    __shared__ __attribute__((aligned(16))) float lds[BM * APITCH + KC * BN];
+    constexpr int BP = BN;
+    __shared__ __attribute__((aligned(16))) float lds[BM * APITCH + KC * BP];
     float *As = lds, *Bs = lds + BM * APITCH;
+    const float *__restrict__ Bm = B.b;
+    const int ldb = B.ldb;
+    const bool bvec = (ldb & 3) == 0 && ((uintptr_t)Bm & 15) == 0 && B.perm_D < 0;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -202,10 +249,41 @@ gemm_kernel(const AOperand A, const float *__restrict__ Bm, int ldb, int M, int 
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int f = tid + i * NTHR;
-                const int kk = f / (BN / 4), jq = f % (BN / 4);
-                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k0 + kk < Kd && n0 + 4 * jq < Nout)
-                    rb[i] = *reinterpret_cast<const float4 *>(Bm + (size_t)(k0 + kk) * ldb + n0 + 4 * jq);
+                float t[4];
+                if (!B.trans) {  // [k][n]: four consecutive n of one reduction row
+                    const int kk = k0 + f / (BN / 4), n = n0 + 4 * (f % (BN / 4));
+                    const float *src = Bm + (size_t)min(kk, B.rows - 1) * ldb;
+                    if (bvec) {
+                        const float4 v = *reinterpret_cast<const float4 *>(src + min(n, Nout - 4));
+                        t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = src[min(n + e, Nout - 1)];
+                    }
+                    const bool okk = kk < B.rows;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = (okk && n + e < Nout) ? t[e] : 0.f;
+                } else {  // [n][k]: four consecutive reduction indices of one output column; n runs fastest over the
+                          // lanes so that the transposing LDS stores below are conflict-free
+                    const int n = n0 + f % BN, kq = k0 + 4 * (f / BN);
+                    const float *src = Bm + (size_t)min(n, Nout - 1) * ldb;
+                    if (bvec) {
+                        const float4 v = *reinterpret_cast<const float4 *>(src + min(kq, B.rows - 4));
+                        t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int kp = min(kq + e, B.rows - 1);
+                            int col = kp;
+                            if (B.perm_D >= 0) col = kp < B.perm_D ? kp + 3 : kp - B.perm_D;
+                            t[e] = src[col];
+                        }
+                    }
+                    const bool okn = n < Nout;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = (okn && kq + e < B.rows) ? t[e] : 0.f;
+                }
+                rb[i] = make_float4(t[0], t[1], t[2], t[3]);
             }
         };
         fetch(0);
@@ -223,13 +301,18 @@ gemm_kernel(const AOperand A, const float *__restrict__ Bm, int ldb, int M, int 
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int f = tid + i * NTHR;
-                *reinterpret_cast<float4 *>(Bs + (f / (BN / 4)) * BN + 4 * (f % (BN / 4))) = rb[i];
+                if (!B.trans) {
+                    *reinterpret_cast<float4 *>(Bs + (f / (BN / 4)) * BP + 4 * (f % (BN / 4))) = rb[i];
+                } else {
+                    float *d = Bs + 4 * (f / BN) * BP + f % BN;
+                    d[0] = rb[i].x, d[BP] = rb[i].y, d[2 * BP] = rb[i].z, d[3 * BP] = rb[i].w;
+                }
             }
             __syncthreads();
             if (k0 + KC < Kd) fetch(k0 + KC);
             const int ksteps = min(KC, Kd - k0) >> 1;
             const float *ap = As + (wm * TM + l31) * APITCH + lh;
-            const float *bp = Bs + lh * BN + wn * TN + l31;
+            const float *bp = Bs + lh * BP + wn * TN + l31;
             if (ksteps == KC / 2) {
 #pragma unroll 4
                 for (int s = 0; s < KC / 2; ++s) {
@@ -237,7 +320,7 @@ gemm_kernel(const AOperand A, const float *__restrict__ Bm, int ldb, int M, int 
 #pragma unroll
                     for (int i = 0; i < MT; ++i) a[i] = ap[i * 32 * APITCH + 2 * s];
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) b[j] = bp[2 * s * BN + j * 32];
+                    for (int j = 0; j < NT; ++j) b[j] = bp[2 * s * BP + j * 32];
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -250,7 +333,7 @@ gemm_kernel(const AOperand A, const float *__restrict__ Bm, int ldb, int M, int 
 #pragma unroll
                     for (int i = 0; i < MT; ++i) a[i] = ap[i * 32 * APITCH + 2 * s];
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) b[j] = bp[2 * s * BN + j * 32];
+                    for (int j = 0; j < NT; ++j) b[j] = bp[2 * s * BP + j * 32];
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -273,19 +356,18 @@ gemm_kernel(const AOperand A, const float *__restrict__ Bm, int ldb, int M, int 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < M && col < Nout) {
-                        float v = acc[i][j][r];
-                        if constexpr (EMODE == E_STORE_STATS) {
-                            s1[j] += (double)v;
-                            s2[j] += (double)v * (double)v;
-                        } else if constexpr (EMODE == E_MASK_STATS) {
-                            const float zp = E.zp[(size_t)row * E.ldc + col];
-                            v = (fmaf(zp, sc, sh) > 0.f) ? v : 0.f;
-                            s1[j] += (double)v;
-                            s2[j] += (double)v * (double)((zp - mu) * is);
-                        }
-                        E.c[(size_t)row * E.ldc + col] = v;
+                    const bool ok = row < M && col < Nout;
+                    float v = ok ? acc[i][j][r] : 0.f;  // padding rows are exact zeros: they add nothing to the sums
+                    if constexpr (EMODE == E_STORE_STATS) {
+                        s1[j] += (double)v;
+                        s2[j] += (double)v * (double)v;
+                    } else if constexpr (EMODE == E_MASK_STATS) {
+                        const float zp = E.zp[(size_t)min(row, M - 1) * E.ldc + min(col, Nout - 1)];
+                        v = (fmaf(zp, sc, sh) > 0.f) ? v : 0.f;
+                        s1[j] += (double)v;
+                        s2[j] += (double)v * (double)((zp - mu) * is);
                     }
+                    if (ok) E.c[(size_t)row * E.ldc + col] = v;
                 }
             }
     }
@@ -322,14 +404,17 @@ gemm_kernel(const AOperand A, const float *__restrict__ Bm, int ldb, int M, int 
 // operand), B (weights, [k][n] row-major) is read straight into the MFMA operand layout (the lane
 // index is n: one 128-byte segment per half-wave).  Next chunk's loads fly during the MFMA loop.
 // ---------------------------------------------------------------------------------------------
-template <int EMODE>
+template <int EMODE, bool BT>
 __global__ void __launch_bounds__(256)
-gemm_smallm_kernel(const float *__restrict__ Am, int lda, const float *__restrict__ Bm, int ldb, int M, int Nout, int Kd,
-                   int Kb, const Epilogue E) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * APITCH + 4 * 32 * 32];
+gemm_smallm_kernel(const float *__restrict__ Am, int lda, const BOperand B, int M, int Nout, int Kd, const Epilogue E) {
+    // per wave: A chunk [32][33], (BT only) weight chunk [32 n][33]; then the K-split partials [4][32][32]
+    __shared__ __attribute__((aligned(16))) float lds[8 * 32 * APITCH + 4 * 32 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     float *As = lds + wave * 32 * APITCH;
-    float *part = lds + 4 * 32 * APITCH;  // [4][32][32]
+    float *Ws = lds + (4 + wave) * 32 * APITCH;
+    float *part = lds + 8 * 32 * APITCH;  // [4][32][32]
+    const float *__restrict__ Bm = B.b;
+    const int ldb = B.ldb;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
     const int nchunks = (Kd + KC - 1) / KC;
 
@@ -338,19 +423,25 @@ gemm_smallm_kernel(const float *__restrict__ Am, int lda, const float *__restric
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     float4 na[4];
-    float nb[KC / 2];
+    float4 nw[4];        // BT: weight rows, same (row, 4k) mapping as the A chunk
+    float nb[KC / 2];    // !BT: weights already in operand layout
     auto fetch = [&](int c) {
         const int k0 = c * KC;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = m0 + (lane >> 3) + 8 * i, k = k0 + 4 * (lane & 7);
-            na[i] = (row < M && k < Kd) ? *reinterpret_cast<const float4 *>(Am + (size_t)row * lda + k)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int r = (lane >> 3) + 8 * i, k = k0 + 4 * (lane & 7);
+            na[i] = (m0 + r < M && k < Kd) ? *reinterpret_cast<const float4 *>(Am + (size_t)(m0 + r) * lda + k)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (BT)
+                nw[i] = (n0 + r < Nout && k < B.rows) ? *reinterpret_cast<const float4 *>(Bm + (size_t)(n0 + r) * ldb + k)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if constexpr (!BT) {
 #pragma unroll
-        for (int s2 = 0; s2 < KC / 2; ++s2) {
-            const int k = k0 + 2 * s2 + lh;
-            nb[s2] = (k < Kb && n0 + l31 < Nout) ? Bm[(size_t)k * ldb + n0 + l31] : 0.f;
+            for (int s2 = 0; s2 < KC / 2; ++s2) {
+                const int k = k0 + 2 * s2 + lh;
+                nb[s2] = (k < B.rows && n0 + l31 < Nout) ? Bm[(size_t)k * ldb + n0 + l31] : 0.f;
+            }
         }
     };
     if (wave < nchunks) fetch(wave);
@@ -358,15 +449,20 @@ gemm_smallm_kernel(const float *__restrict__ Am, int lda, const float *__restric
         float cb[KC / 2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float *d = As + ((lane >> 3) + 8 * i) * APITCH + 4 * (lane & 7);
-            d[0] = na[i].x, d[1] = na[i].y, d[2] = na[i].z, d[3] = na[i].w;
+            const int o = ((lane >> 3) + 8 * i) * APITCH + 4 * (lane & 7);
+            As[o] = na[i].x, As[o + 1] = na[i].y, As[o + 2] = na[i].z, As[o + 3] = na[i].w;
+            if constexpr (BT) Ws[o] = nw[i].x, Ws[o + 1] = nw[i].y, Ws[o + 2] = nw[i].z, Ws[o + 3] = nw[i].w;
         }
+        if constexpr (!BT) {
 #pragma unroll
-        for (int s2 = 0; s2 < KC / 2; ++s2) cb[s2] = nb[s2];
+            for (int s2 = 0; s2 < KC / 2; ++s2) cb[s2] = nb[s2];
+        }
         if (c + 4 < nchunks) fetch(c + 4);
 #pragma unroll
-        for (int s2 = 0; s2 < KC / 2; ++s2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[l31 * APITCH + 2 * s2 + lh], cb[s2], acc, 0, 0, 0);
+        for (int s2 = 0; s2 < KC / 2; ++s2) {
+            const float bv = BT ? Ws[l31 * APITCH + 2 * s2 + lh] : cb[s2];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[l31 * APITCH + 2 * s2 + lh], bv, acc, 0, 0, 0);
+        }
     }
     // K-split reduction in fixed wave order, then the epilogue on the summed tile
 #pragma unroll
@@ -401,15 +497,15 @@ gemm_smallm_kernel(const float *__restrict__ Am, int lda, const float *__restric
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_gemm_cfg(const AOperand &A, const float *Bm, int ldb, int M, int Nout, int Kd, const Epilogue &E,
-                           int *nslab, hipStream_t st) {
+static int launch_gemm_cfg(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab,
+                           hipStream_t st) {
     const int tiles = cdiv(M, BM);
     const int gx = tiles < kMaxStatBlocks ? tiles : kMaxStatBlocks;
     const dim3 grid(gx, cdiv(Nout, BN)), block(WM * WN * 64);
     if (nslab) *nslab = gx;
     ProfScope ps(st, "gemm_kernel<%d,%d,%d,%d,A%d,E%d> M=%d N=%d K=%d", BM, BN, WM, WN, A.mode, E.mode, M, Nout, Kd);
-#define PNPP_LAUNCH(AM, EM)                                                                                         \
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AM, EM>), grid, block, 0, st, A, Bm, ldb, M, Nout, Kd, E); \
+#define PNPP_LAUNCH(AM, EM)                                                                                   \
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AM, EM>), grid, block, 0, st, A, B, M, Nout, Kd, E); \
     break;
 #define PNPP_BY_E(AM)                                                          \
     switch (E.mode) {                                                          \
@@ -425,6 +521,7 @@ static int launch_gemm_cfg(const AOperand &A, const float *Bm, int ldb, int M, i
         case A_GATHER: PNPP_BY_E(A_GATHER)
         case A_CONCAT: PNPP_BY_E(A_CONCAT)
         case A_DZ: PNPP_BY_E(A_DZ)
+        case A_DZ_POOL: PNPP_BY_E(A_DZ_POOL)
         default: set_error("gemm: bad A mode %d", A.mode); return PNPP_ERR_ARG;
     }
 #undef PNPP_BY_E
@@ -433,38 +530,43 @@ static int launch_gemm_cfg(const AOperand &A, const float *Bm, int ldb, int M, i
     return PNPP_OK;
 }
 
-int launch_gemm(const AOperand &A, const float *Bm, int ldb, int M, int Nout, int Kd, const Epilogue &E, int *nslab,
+int launch_gemm(const AOperand &A, const BOperand &Bin, int M, int Nout, int Kd, const Epilogue &E, int *nslab,
                 hipStream_t st) {
     PNPP_REQUIRE(M > 0 && Nout > 0 && Kd > 0, PNPP_ERR_ARG, "gemm: non-positive size M=%d N=%d K=%d", M, Nout, Kd);
-    if (A.mode == A_PLAIN && E.mode != E_MASK_STATS && M <= 512 && cdiv(M, 32) <= kMaxStatBlocks) {
-        PNPP_REQUIRE(Kd % 4 == 0 && A.lda % 4 == 0 && ((uintptr_t)A.a & 15) == 0, PNPP_ERR_ARG, "gemm(small M): A pitch/alignment");
+    PNPP_REQUIRE(Bin.b && Bin.ldb > 0, PNPP_ERR_ARG, "gemm: null B operand");
+    PNPP_REQUIRE(Kd % 4 == 0, PNPP_ERR_ARG, "gemm: K=%d must be a multiple of 4", Kd);
+    BOperand B = Bin;
+    if (B.rows <= 0 || B.rows > Kd) B.rows = Kd;
+    const bool b_aligned = (B.ldb % 4 == 0) && (((uintptr_t)B.b & 15) == 0) && B.perm_D < 0;
+    if (A.mode == A_PLAIN && E.mode != E_MASK_STATS && M <= 512 && cdiv(M, 32) <= kMaxStatBlocks && b_aligned) {
+        PNPP_REQUIRE(A.lda % 4 == 0 && ((uintptr_t)A.a & 15) == 0, PNPP_ERR_ARG, "gemm(small M): A pitch/alignment");
         const dim3 grid(cdiv(Nout, 32), cdiv(M, 32));
         if (nslab) *nslab = grid.y;
-        ProfScope ps(st, "gemm_smallm_kernel<E%d> M=%d N=%d K=%d", E.mode, M, Nout, Kd);
-        if (E.mode == E_STORE_STATS)
-            hipLaunchKernelGGL((gemm_smallm_kernel<E_STORE_STATS>), grid, dim3(256), 0, st, A.a, A.lda, Bm, ldb, M, Nout, Kd, Kd, E);
-        else
-            hipLaunchKernelGGL((gemm_smallm_kernel<E_STORE>), grid, dim3(256), 0, st, A.a, A.lda, Bm, ldb, M, Nout, Kd, Kd, E);
+        ProfScope ps(st, "gemm_smallm_kernel<E%d,T%d> M=%d N=%d K=%d", E.mode, B.trans, M, Nout, Kd);
+        if (E.mode == E_STORE_STATS) {
+            if (B.trans) hipLaunchKernelGGL((gemm_smallm_kernel<E_STORE_STATS, true>), grid, dim3(256), 0, st, A.a, A.lda, B, M, Nout, Kd, E);
+            else hipLaunchKernelGGL((gemm_smallm_kernel<E_STORE_STATS, false>), grid, dim3(256), 0, st, A.a, A.lda, B, M, Nout, Kd, E);
+        } else {
+            if (B.trans) hipLaunchKernelGGL((gemm_smallm_kernel<E_STORE, true>), grid, dim3(256), 0, st, A.a, A.lda, B, M, Nout, Kd, E);
+            else hipLaunchKernelGGL((gemm_smallm_kernel<E_STORE, false>), grid, dim3(256), 0, st, A.a, A.lda, B, M, Nout, Kd, E);
+        }
         PNPP_CHECK_LAUNCH("gemm(small M)");
         return PNPP_OK;
     }
-    PNPP_REQUIRE(Kd % 4 == 0 && ldb % 4 == 0 && Nout % 4 == 0, PNPP_ERR_ARG,
-                 "gemm: K=%d, N=%d and ldb=%d must be multiples of 4", Kd, Nout, ldb);
-    PNPP_REQUIRE(((uintptr_t)Bm & 15) == 0, PNPP_ERR_ARG, "gemm: B operand must be 16-byte aligned");
-    if (A.mode == A_PLAIN || A.mode == A_BNRELU || A.mode == A_DZ)
+    if (A.mode == A_PLAIN || A.mode == A_BNRELU || A.mode == A_DZ || A.mode == A_DZ_POOL)
         PNPP_REQUIRE(A.lda % 4 == 0 && ((uintptr_t)A.a & 15) == 0, PNPP_ERR_ARG, "gemm: A operand pitch/alignment");
     // tile shape: tall tiles for the grouped layers (M = B*npoint*nsample), square-ish for small M
     if (M >= 128 * 128) {
-        if (Nout % 128 == 0) return launch_gemm_cfg<128, 128, 4, 2>(A, Bm, ldb, M, Nout, Kd, E, nslab, st);
-        if (Nout % 64 == 0) return launch_gemm_cfg<128, 64, 4, 1>(A, Bm, ldb, M, Nout, Kd, E, nslab, st);
-        return launch_gemm_cfg<128, 32, 4, 1>(A, Bm, ldb, M, Nout, Kd, E, nslab, st);
+        if (Nout % 128 == 0) return launch_gemm_cfg<128, 128, 4, 2>(A, B, M, Nout, Kd, E, nslab, st);
+        if (Nout % 64 == 0) return launch_gemm_cfg<128, 64, 4, 2>(A, B, M, Nout, Kd, E, nslab, st);
+        return launch_gemm_cfg<128, 32, 4, 1>(A, B, M, Nout, Kd, E, nslab, st);
     }
     if (M > 32) {
-        if (Nout % 64 == 0) return launch_gemm_cfg<64, 64, 2, 2>(A, Bm, ldb, M, Nout, Kd, E, nslab, st);
-        return launch_gemm_cfg<128, 32, 4, 1>(A, Bm, ldb, M, Nout, Kd, E, nslab, st);
+        if (Nout % 64 == 0) return launch_gemm_cfg<64, 64, 2, 2>(A, B, M, Nout, Kd, E, nslab, st);
+        return launch_gemm_cfg<128, 32, 4, 1>(A, B, M, Nout, Kd, E, nslab, st);
     }
-    if (Nout % 128 == 0) return launch_gemm_cfg<32, 128, 1, 4>(A, Bm, ldb, M, Nout, Kd, E, nslab, st);
-    return launch_gemm_cfg<128, 32, 4, 1>(A, Bm, ldb, M, Nout, Kd, E, nslab, st);
+    if (Nout % 128 == 0) return launch_gemm_cfg<32, 128, 1, 4>(A, B, M, Nout, Kd, E, nslab, st);
+    return launch_gemm_cfg<128, 32, 4, 1>(A, B, M, Nout, Kd, E, nslab, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -500,16 +602,38 @@ dw_kernel(const AOperand dz, const AOperand a2, int M, int Nc, int Kp, int tiles
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // A_DZ_POOL: a batch of 2U rows lies inside one group when K % 2U == 0 (row ranges start on multiples of 2U),
+    // so the pooled gradient / arg-max of the group are fetched once per batch instead of once per row
+    const bool grp_batch = (DZMODE == A_DZ_POOL) && (dz.K % (2 * U) == 0) && (r0 % (2 * U) == 0);
     for (int row = r0; row < r1; row += 2 * U) {
         float2 fa[U][CT], fb[U][KT];
+        float gdm[CT];
+        int garg[CT], gk0 = 0;
+        if (DZMODE == A_DZ_POOL && grp_batch) {
+            const int g = row / dz.K;
+            gk0 = row - g * dz.K;
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                const int c = min(c0 + i * 32 + l31, Nc - 1);
+                gdm[i] = dz.a[(size_t)g * dz.lda + c];
+                garg[i] = dz.arg[(size_t)g * dz.lda + c];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int m = row + 2 * u + lh;
-            const bool ok = m < r1;
 #pragma unroll
-            for (int i = 0; i < CT; ++i) fa[u][i] = fetch_a1<DZMODE>(dz, m, c0 + i * 32 + l31, Nc, ok);
+            for (int i = 0; i < CT; ++i) {
+                if (DZMODE == A_DZ_POOL && grp_batch) {
+                    const int c = min(c0 + i * 32 + l31, Nc - 1);
+                    fa[u][i].x = (gk0 + 2 * u + lh == garg[i]) ? gdm[i] : 0.f;
+                    fa[u][i].y = dz.z[(size_t)min(m, M - 1) * dz.lda + c];
+                } else {
+                    fa[u][i] = fetch_a1<DZMODE>(dz, m, c0 + i * 32 + l31, Nc, M);
+                }
+            }
 #pragma unroll
-            for (int j = 0; j < KT; ++j) fb[u][j] = fetch_a1<A2MODE>(a2, m, k0 + j * 32 + l31, Kp, ok);
+            for (int j = 0; j < KT; ++j) fb[u][j] = fetch_a1<A2MODE>(a2, m, k0 + j * 32 + l31, Kp, M);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -558,7 +682,7 @@ int launch_dw(const AOperand &dz, int Nc, const AOperand &a2, int Kp, int M, flo
     const int tilesC = cdiv(Nc, 64), tilesK = cdiv(Kp, 64);
     PNPP_REQUIRE(kp_pad == tilesK * 64, PNPP_ERR_ARG, "dw: kp_pad mismatch");
     int rps = cdiv(M, nsplit);
-    rps = (rps + 1) & ~1;  // even: a row pair never straddles two splits
+    rps = (rps + 7) & ~7;  // multiple of 8: a fetch batch (4 row pairs) never straddles two splits or two groups
     const int waves = tilesC * tilesK * nsplit;
     const dim3 grid(cdiv(waves, 4)), block(256);
     ProfScope ps(st, "dw_kernel<A%d,A%d> M=%d N=%d K=%d split=%d", dz.mode, a2.mode, M, Nc, Kp, nsplit);
@@ -577,6 +701,7 @@ int launch_dw(const AOperand &dz, int Nc, const AOperand &a2, int Kp, int M, flo
     switch (dz.mode) {
         case A_PLAIN: PNPP_DW_BY_A(A_PLAIN)
         case A_DZ: PNPP_DW_BY_A(A_DZ)
+        case A_DZ_POOL: PNPP_DW_BY_A(A_DZ_POOL)
         default: set_error("dw: bad dZ mode %d", dz.mode); return PNPP_ERR_ARG;
     }
 #undef PNPP_DW_BY_A
@@ -807,12 +932,13 @@ int launch_pool_fwd(const float *z, const float *scale, const float *shift, int 
     return PNPP_OK;
 }
 
-// backward of max + ReLU: dense dy (zero except at the arg-max row when the pooled value is > 0)
-// plus the two BatchNorm-backward column sums.  block = 64 channels x 4 group lanes.
+// backward of max + ReLU: the dense gradient (zero except at the arg-max row when the pooled value is > 0)
+// is NOT written; this kernel emits the masked pooled gradient dm (G x C) and the two BatchNorm-backward
+// column sums, and the consumers rebuild dy from (dm, arg) on the fly.  block = 64 channels x 4 group lanes.
 __global__ void __launch_bounds__(256)
 pool_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ arg, const float *__restrict__ z,
                 const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
-                const float *__restrict__ istd, int G, int K, int C, float *__restrict__ dy, double *__restrict__ slab) {
+                const float *__restrict__ istd, int G, int K, int C, float *__restrict__ dm, double *__restrict__ slab) {
     __shared__ double red[4][2][64];
     const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -821,11 +947,9 @@ pool_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ arg,
         const float mu = mean[c], is = istd[c], sc = scale[c], sh = shift[c];
         for (int g = blockIdx.y * 4 + gl; g < G; g += gridDim.y * 4) {
             const size_t gi = (size_t)g * C + c;
-            const int a = arg[gi];
-            const float za = z[((size_t)g * K + a) * C + c];
+            const float za = z[((size_t)g * K + arg[gi]) * C + c];
             const float d = fmaf(za, sc, sh) > 0.f ? dout[gi] : 0.f;  // ReLU'(pooled value), same expression as forward
-            float *p = dy + (size_t)g * K * C + c;
-            for (int k = 0; k < K; ++k) p[(size_t)k * C] = (k == a) ? d : 0.f;
+            dm[gi] = d;
             s1 += (double)d;
             s2 += (double)d * (double)((za - mu) * is);
         }
@@ -843,14 +967,15 @@ pool_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ arg,
 }
 
 int launch_pool_bwd(const float *dout, const int32_t *arg, const float *z, const float *scale, const float *shift,
-                    const float *mean, const float *istd, int G, int K, int C, float *dy, double *slab, int *nslab,
+                    const float *mean, const float *istd, int G, int K, int C, float *dm, double *slab, int *nslab,
                     hipStream_t st) {
-    int gy = cdiv(G, 4);
+    int gy = cdiv(G, 16);  // four groups per lane-row and pass
     if (gy > kMaxStatBlocks) gy = kMaxStatBlocks;
+    if (gy < 1) gy = 1;
     *nslab = gy;
     ProfScope ps(st, "pool_bwd_kernel G=%d K=%d C=%d", G, K, C);
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(cdiv(C, 64), gy), dim3(256), 0, st, dout, arg, z, scale, shift, mean, istd, G, K, C,
-                       dy, slab);
+                       dm, slab);
     PNPP_CHECK_LAUNCH("pool_bwd");
     return PNPP_OK;
 }

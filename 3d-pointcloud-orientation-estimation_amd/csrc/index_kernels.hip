@@ -61,18 +61,35 @@ __global__ void __launch_bounds__(256) square_distance_kernel(const float *__res
 // kNN grouping (models/base.py:29-35): one wavefront per query centre.
 //   * the cloud is staged tile by tile (TILE points) into LDS as x[],y[],z[],|p|^2[] (SoA);
 //   * every lane forms 64-bit keys (sortable(d) << 32 | n) for TILE/64 candidates in registers;
-//   * the current best-k list rides along as up to two extra candidates per lane;
-//   * k rounds of "wave-min, owner retires its key" emit the neighbours in ascending (d, n).
+//   * prune: the k-th smallest of the 64 lane minima bounds the k-th smallest key of the tile from
+//     above (k <= 64), and so does the previous best list's last entry; only keys <= that bound are
+//     compacted (ballot + prefix popcount) into a small LDS pool -- typically 40-70 of 1024;
+//   * select: every pooled key counts the pooled keys below it (broadcast LDS reads); rank < k
+//     writes straight to its sorted slot.  Keys are unique (index in the low word), so ranks are too.
+//   * pathological inputs (pool overflow: massive ties, or k > 64) fall back to k rounds of
+//     "wave-min, owner retires its key".
+// Output: neighbours in ascending (distance, index).
 // ---------------------------------------------------------------------------------------------
 constexpr int KNN_TILE = 1024;
 constexpr int KNN_CPL = KNN_TILE / 64;  // candidates per lane per tile
 constexpr int KNN_KMAX = 128;
+constexpr int KNN_POOL = 256;
 constexpr unsigned long long KEY_MAX = ~0ull;
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        unsigned o = (unsigned)__shfl_xor((int)v, m, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
 
 __global__ void __launch_bounds__(256) knn_kernel(const float *__restrict__ new_xyz, const float *__restrict__ xyz, int S,
                                                   int N, int k, int32_t *__restrict__ idx) {
     __shared__ float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE], sn[KNN_TILE];
-    __shared__ unsigned long long best[4][KNN_KMAX];
+    __shared__ unsigned long long best[4][2][KNN_KMAX];
+    __shared__ unsigned long long pool[4][KNN_POOL];
 
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -84,12 +101,13 @@ __global__ void __launch_bounds__(256) knn_kernel(const float *__restrict__ new_
         ax = a[0], ay = a[1], az = a[2];
         sa = sq3_exact(ax, ay, az);
     }
-    best[wave][lane] = KEY_MAX;
-    best[wave][lane + 64] = KEY_MAX;
+    int cur = 0;         // which half of best[] holds the current list
+    bool have = false;   // best[cur][0..k) is valid (wave-uniform)
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     const float *cloud = xyz + (size_t)b * N * 3;
     for (int t0 = 0; t0 < N; t0 += KNN_TILE) {
-        __syncthreads();  // previous tile fully consumed (also orders the best[] initialisation)
+        __syncthreads();  // previous tile fully consumed
         const int cnt = min(KNN_TILE, N - t0);
         // coalesced stage: 3*cnt consecutive floats, de-interleaved into SoA
         for (int i = threadIdx.x; i < cnt * 3; i += 256) {
@@ -103,43 +121,79 @@ __global__ void __launch_bounds__(256) knn_kernel(const float *__restrict__ new_
         if (!active) continue;
 
         unsigned long long key[KNN_CPL + 2];
+        unsigned long long lmin = KEY_MAX;
 #pragma unroll
         for (int j = 0; j < KNN_CPL; ++j) {
             const int p = j * 64 + lane;
+            key[j] = KEY_MAX;
             if (p < cnt) {
                 float d = pair_dist_exact(ax, ay, az, sx[p], sy[p], sz[p], sa, sn[p]);
                 key[j] = ((unsigned long long)f32_sortable(d) << 32) | (unsigned)(t0 + p);
-            } else {
-                key[j] = KEY_MAX;
             }
+            lmin = key[j] < lmin ? key[j] : lmin;
         }
-        key[KNN_CPL] = best[wave][lane];
-        key[KNN_CPL + 1] = best[wave][lane + 64];
+        // previous best list rides along as up to two more candidates per lane
+        key[KNN_CPL] = (have && lane < k) ? best[wave][cur][lane] : KEY_MAX;
+        key[KNN_CPL + 1] = (have && lane + 64 < k) ? best[wave][cur][lane + 64] : KEY_MAX;
 
-        unsigned long long lmin = KEY_MAX;
+        // ---- pruning bound on the distance word ----
+        unsigned long long T = KEY_MAX;
+        if (k <= 64) {
+            const unsigned hi = (unsigned)(lmin >> 32);
+            int cnt_le = 0;
 #pragma unroll
-        for (int j = 0; j < KNN_CPL + 2; ++j) lmin = key[j] < lmin ? key[j] : lmin;
-
-        for (int it = 0; it < k; ++it) {
-            const unsigned long long w = wave_min_u64(lmin);
-            if (lane == 0) best[wave][it] = w;  // safe: old best[] already copied into registers
-            if (lmin == w && w != KEY_MAX) {    // keys are unique (index in the low word): one owner
-                unsigned long long m2 = KEY_MAX;
+            for (int i = 0; i < 64; ++i) cnt_le += ((unsigned)__builtin_amdgcn_readlane((int)hi, i) <= hi) ? 1 : 0;
+            const unsigned thi = wave_min_u32(cnt_le >= k ? hi : 0xffffffffu);
+            T = ((unsigned long long)thi << 32) | 0xffffffffull;
+        }
+        if (have) {
+            const unsigned long long last = best[wave][cur][k - 1];
+            T = last < T ? last : T;
+        }
+        // ---- compaction of the survivors into the LDS pool ----
+        int P = 0;  // wave-uniform
 #pragma unroll
-                for (int j = 0; j < KNN_CPL + 2; ++j) {
-                    if (key[j] == w) key[j] = KEY_MAX;
-                    m2 = key[j] < m2 ? key[j] : m2;
+        for (int j = 0; j < KNN_CPL + 2; ++j) {
+            const bool in = key[j] <= T && key[j] != KEY_MAX;
+            const unsigned long long m = __ballot(in);
+            const int pos = P + __popcll(m & lt_mask);
+            if (in && pos < KNN_POOL) pool[wave][pos] = key[j];
+            P += __popcll(m);
+        }
+        if (P <= KNN_POOL) {
+            // ---- rank selection inside the pool ----
+            for (int e0 = 0; e0 < P; e0 += 64) {
+                const int e = e0 + lane;
+                const unsigned long long mine = e < P ? pool[wave][e] : KEY_MAX;
+                int r = 0;
+                for (int j = 0; j < P; ++j) r += pool[wave][j] < mine ? 1 : 0;
+                if (e < P && r < k) best[wave][cur ^ 1][r] = mine;
+            }
+        } else {
+            // ---- fallback: k rounds of wave-min extraction over everything this lane holds ----
+            unsigned long long fmin = KEY_MAX;
+#pragma unroll
+            for (int j = 0; j < KNN_CPL + 2; ++j) fmin = key[j] < fmin ? key[j] : fmin;
+            for (int it = 0; it < k; ++it) {
+                const unsigned long long w = wave_min_u64(fmin);
+                if (lane == 0) best[wave][cur ^ 1][it] = w;
+                if (fmin == w && w != KEY_MAX) {  // keys are unique: exactly one owner
+                    unsigned long long m2 = KEY_MAX;
+#pragma unroll
+                    for (int j = 0; j < KNN_CPL + 2; ++j) {
+                        if (key[j] == w) key[j] = KEY_MAX;
+                        m2 = key[j] < m2 ? key[j] : m2;
+                    }
+                    fmin = m2;
                 }
-                lmin = m2;
             }
         }
-        // lanes re-read best[] at the top of the next tile; make lane 0's writes visible to the wave
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        cur ^= 1;
+        have = true;
     }
     if (active) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int32_t *o = idx + ((size_t)b * S + q) * k;
-        for (int j = lane; j < k; j += 64) o[j] = (int32_t)(unsigned)(best[wave][j] & 0xffffffffu);
+        for (int j = lane; j < k; j += 64) o[j] = (int32_t)(unsigned)(best[wave][cur][j] & 0xffffffffu);
     }
 }
 

@@ -16,7 +16,9 @@ enum AMode {
     A_BNRELU = 1,  // relu(A[row][k] * scale[k] + shift[k])           (BatchNorm apply + ReLU of the previous layer)
     A_GATHER = 2,  // [points[b, idx[row], :D] | xyz[b, idx[row]] - new_xyz[row / K] | 0]   (grouping, features first)
     A_CONCAT = 3,  // [points[row, :D] | xyz[row] | 0]                                     (group_all)
-    A_DZ = 4       // g[c] * (dy[row][c] - c1[c] - (Z[row][c] - mu[c]) * istd[c] * c2[c])  (BatchNorm backward)
+    A_DZ = 4,      // g[c] * (dy[row][c] - c1[c] - (Z[row][c] - mu[c]) * istd[c] * c2[c])  (BatchNorm backward)
+    A_DZ_POOL = 5  // same, with dy never materialised: dy[row][c] = (row % K == arg[row/K][c]) ? dm[row/K][c] : 0
+                   // (backward of max-over-nsample + ReLU; a = dm (G x C), arg = arg-max rows)
 };
 
 struct AOperand {
@@ -27,6 +29,7 @@ struct AOperand {
     const float *xyz = nullptr, *new_xyz = nullptr;  // GATHER/CONCAT
     const int32_t *idx = nullptr;                    // GATHER
     int D = 0, N = 0, S = 0, K = 0;                  // GATHER/CONCAT geometry (N points, S centres per cloud, K neighbours)
+    const int32_t *arg = nullptr;                    // DZ_POOL: arg-max neighbour per (group, channel)
     const float *z = nullptr;                        // DZ: pre-BN activations of the same layer
     const float *cst = nullptr;                      // DZ: [5][C] = g, mu, istd, c1, c2
     int C = 0;                                       // DZ: channel count (row pitch of cst)
@@ -48,9 +51,19 @@ struct Epilogue {
     const float *scale = nullptr, *shift = nullptr, *mu = nullptr, *istd = nullptr;
 };
 
-// C[M x Nout] = A'[M x Kd] * Bm[Kd x Nout] (Bm row-major, pitch ldb).  Returns the number of
-// statistic slabs written (gridDim.x) through *nslab when the epilogue collects statistics.
-int launch_gemm(const AOperand &A, const float *Bm, int ldb, int M, int Nout, int Kd, const Epilogue &E, int *nslab,
+// The B operand (weights) is read in place from its state_dict layout -- no transposed copies are made.
+struct BOperand {
+    const float *b = nullptr;
+    int ldb = 0;
+    int trans = 0;     // 0: b is [Kd][Nout] (row = reduction index); 1: b is [Nout][Kd] (a conv / linear weight)
+    int perm_D = -1;   // trans only: >= 0 maps reduction index k' to weight column (k' < D ? k'+3 : k'-D) and
+                       // treats k' >= D+3 as zero (layer 0: kernels order the operand features-first, weights xyz-first)
+    int rows = 0;      // number of valid reduction rows (<= Kd; beyond it B is treated as zero)
+};
+
+// C[M x Nout] = A'[M x Kd] * B[Kd x Nout].  Returns the number of statistic slabs written (gridDim.x)
+// through *nslab when the epilogue collects statistics.
+int launch_gemm(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab,
                 hipStream_t st);
 
 // dW[Nc x Kp] = dZ^T[Nc x M] * A2[M x Kp], split over `nsplit` row ranges into slab[nsplit][Nc][kp_pad].
@@ -80,9 +93,10 @@ int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, i
 
 int launch_pool_fwd(const float *z, const float *scale, const float *shift, int G, int K, int C, float *out, int32_t *arg,
                     hipStream_t st);
-// expands the pooled gradient to dense dy (G*K x C) and collects the BatchNorm-backward column sums
+// backward of max + ReLU without materialising the dense gradient: writes the masked pooled gradient dm (G x C)
+// and collects the BatchNorm-backward column sums; consumers rebuild dy on the fly (A_DZ_POOL)
 int launch_pool_bwd(const float *dout, const int32_t *arg, const float *z, const float *scale, const float *shift,
-                    const float *mean, const float *istd, int G, int K, int C, float *dy, double *slab, int *nslab,
+                    const float *mean, const float *istd, int G, int K, int C, float *dm, double *slab, int *nslab,
                     hipStream_t st);
 
 int launch_fill_zero(void *p, size_t bytes, hipStream_t st);

@@ -114,10 +114,9 @@ static SaSaved sa_saved_layout(const pnpp_sa_desc *d, const SaGeom &g, void *bas
 }
 
 struct SaScratch {
-    float *wt[PNPP_MAX_LAYERS];
-    float *wperm0;
     double *slab;
     float *dy[2];
+    float *dm;
     float *cst;
     float *dwslab;
     size_t bytes;
@@ -126,12 +125,11 @@ struct SaScratch {
 static SaScratch sa_scratch_layout(const pnpp_sa_desc *d, const SaGeom &g, void *base) {
     Carver cv(base);
     SaScratch s;
-    for (int l = 0; l < d->L; ++l) s.wt[l] = cv.take<float>((size_t)g.Kd[l] * d->C[l]);
-    s.wperm0 = cv.take<float>((size_t)d->C[0] * g.Kd0);
     s.slab = cv.take<double>((size_t)kMaxStatBlocks * 2 * g.maxC);
     const int wide = g.maxC > d->D ? g.maxC : d->D;
     s.dy[0] = cv.take<float>((size_t)g.M * wide);
     s.dy[1] = cv.take<float>((size_t)g.M * wide);
+    s.dm = cv.take<float>((size_t)g.G * d->C[d->L - 1]);
     s.cst = cv.take<float>((size_t)5 * g.maxC);
     size_t dwmax = 0;
     for (int l = 0; l < d->L; ++l) {
@@ -187,13 +185,7 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
         }
     }
 
-    // 2. weights -> [reduction][out] layout, features-first for layer 0
-    PrepItem items[PNPP_MAX_LAYERS];
-    for (int l = 0; l < d->L; ++l)
-        items[l] = PrepItem{a->conv_w[l], sc.wt[l], nullptr, d->C[l], g.Cin[l], g.Kd[l], l == 0 ? d->D : -1};
-    PNPP_TRY(launch_prep_weights(items, d->L, st));
-
-    // 3. conv -> BN -> ReLU chain; BN apply + ReLU of layer l-1 happen inside layer l's operand loader
+    // 2. conv -> BN -> ReLU chain; BN apply + ReLU of layer l-1 happen inside layer l's operand loader
     for (int l = 0; l < d->L; ++l) {
         AOperand A;
         if (l == 0) {
@@ -208,11 +200,17 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
         Epilogue E;
         E.c = sv.z[l];
         E.ldc = d->C[l];
+        BOperand W;  // the conv weight (C_l x Cin_l) is read in place; layer 0 maps features-first k' to xyz-first columns
+        W.b = a->conv_w[l];
+        W.ldb = g.Cin[l];
+        W.trans = 1;
+        W.perm_D = l == 0 ? d->D : -1;
+        W.rows = g.Cin[l];
         int nslab = 0;
         if (d->training) {
             E.mode = E_STORE_STATS;
             E.slab = sc.slab;
-            PNPP_TRY(launch_gemm(A, sc.wt[l], d->C[l], g.M, d->C[l], g.Kd[l], E, &nslab, st));
+            PNPP_TRY(launch_gemm(A, W, g.M, d->C[l], g.Kd[l], E, &nslab, st));
             PNPP_TRY(launch_bn_finalize_fwd(sc.slab, nslab, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
                                             a->bn_rm[l], a->bn_rv[l], d->momentum, d->eps, 1, sv.mean[l], sv.istd[l],
                                             sv.scale[l], sv.shift[l], st));
@@ -221,11 +219,11 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
             PNPP_TRY(launch_bn_finalize_fwd(nullptr, 0, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
                                             a->bn_rm[l], a->bn_rv[l], d->momentum, d->eps, 0, sv.mean[l], sv.istd[l],
                                             sv.scale[l], sv.shift[l], st));
-            PNPP_TRY(launch_gemm(A, sc.wt[l], d->C[l], g.M, d->C[l], g.Kd[l], E, nullptr, st));
+            PNPP_TRY(launch_gemm(A, W, g.M, d->C[l], g.Kd[l], E, nullptr, st));
         }
     }
 
-    // 4. max over the neighbourhood (pointnet_pp_8dir.py:42-43)
+    // 3. max over the neighbourhood (pointnet_pp_8dir.py:42-43)
     const int Lm = d->L - 1;
     PNPP_TRY(launch_pool_fwd(sv.z[Lm], sv.scale[Lm], sv.shift[Lm], g.G, d->K, d->C[Lm], a->out, sv.arg, st));
     return PNPP_OK;
@@ -243,22 +241,19 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
     const SaSaved sv = sa_saved_layout(d, g, const_cast<void *>(a->saved));
     const SaScratch sc = sa_scratch_layout(d, g, a->scratch);
 
-    if (want_dpoints) {  // features-first row-major copy of W0 for the dX GEMM
-        PrepItem it{a->conv_w[0], sc.wt[0], sc.wperm0, d->C[0], g.Cin[0], g.Kd[0], d->D};
-        PNPP_TRY(launch_prep_weights(&it, 1, st));
-    }
-
     const int Lm = d->L - 1;
     int cur = 0, nslab = 0;
     PNPP_TRY(launch_pool_bwd(a->dout, sv.arg, sv.z[Lm], sv.scale[Lm], sv.shift[Lm], sv.mean[Lm], sv.istd[Lm], g.G, d->K,
-                             d->C[Lm], sc.dy[cur], sc.slab, &nslab, st));
+                             d->C[Lm], sc.dm, sc.slab, &nslab, st));
     for (int l = Lm; l >= 0; --l) {
         const int C = d->C[l];
         PNPP_TRY(launch_bn_finalize_bwd(sc.slab, nslab, C, (double)g.M, d->training, a->bn_w[l], sv.mean[l], sv.istd[l], sc.cst,
                                         a->d_bn_w[l], a->d_bn_b[l], a->d_conv_b[l], st));
-        AOperand dz;
-        dz.mode = A_DZ;
-        dz.a = sc.dy[cur];
+        AOperand dz;  // the top layer's dense gradient is never materialised (A_DZ_POOL rebuilds it from dm / arg)
+        dz.mode = l == Lm ? A_DZ_POOL : A_DZ;
+        dz.a = l == Lm ? sc.dm : sc.dy[cur];
+        dz.arg = sv.arg;
+        dz.K = d->K;
         dz.lda = C;
         dz.z = sv.z[l];
         dz.cst = sc.cst;
@@ -292,18 +287,26 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             E.shift = sv.shift[l - 1];
             E.mu = sv.mean[l - 1];
             E.istd = sv.istd[l - 1];
-            PNPP_TRY(launch_gemm(dz, a->conv_w[l], d->C[l - 1], g.M, d->C[l - 1], C, E, &nslab, st));
+            BOperand W;  // dY_{l-1} = dZ_l * W_l with W_l (C_l x C_{l-1}) row-major as stored
+            W.b = a->conv_w[l];
+            W.ldb = d->C[l - 1];
+            W.rows = C;
+            PNPP_TRY(launch_gemm(dz, W, g.M, d->C[l - 1], C, E, &nslab, st));
             cur ^= 1;
         } else if (want_dpoints) {
             Epilogue E;
             E.mode = E_STORE;
             E.ldc = d->D;
+            BOperand W;  // feature columns of W_0: (C_0 x (3+D)) row-major, skip the three xyz columns
+            W.b = a->conv_w[0] + 3;
+            W.ldb = g.Cin[0];
+            W.rows = C;
             if (d->group_all) {  // rows are the points themselves
                 E.c = a->dpoints;
-                PNPP_TRY(launch_gemm(dz, sc.wperm0, g.Kd0, g.M, d->D, C, E, nullptr, st));
+                PNPP_TRY(launch_gemm(dz, W, g.M, d->D, C, E, nullptr, st));
             } else {
                 E.c = sc.dy[cur ^ 1];
-                PNPP_TRY(launch_gemm(dz, sc.wperm0, g.Kd0, g.M, d->D, C, E, nullptr, st));
+                PNPP_TRY(launch_gemm(dz, W, g.M, d->D, C, E, nullptr, st));
                 PNPP_TRY(launch_fill_zero(a->dpoints, (size_t)d->B * d->N * d->D * sizeof(float), st));
                 PNPP_TRY(launch_scatter_rows_bwd(sc.dy[cur ^ 1], sv.idx, d->B, d->N, d->D, d->S * d->K, a->dpoints, st));
             }

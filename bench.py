@@ -61,7 +61,8 @@ def kernel_cost(tag: str):
         e = int(re.search(r",E(\d)>", tag).group(1))
         a = int(re.search(r",A(\d),", tag).group(1))
         byts = 4.0 * (M * N + K * N)                      # write C, read weights
-        byts += 4.0 * M * K * (2 if a == 4 else 1)        # read A (dy and z for the BatchNorm-backward operand)
+        byts += 4.0 * M * K * (2 if a == 4 else 1)        # read A (dy and z for the BatchNorm-backward operand; A5: z only,
+                                                           # the pooled gradient it is rebuilt from is G x C and L2-resident)
         if a == 2:                                         # gathered operand: indices, not rows, are the compulsory part
             byts = 4.0 * (M * N + K * N) + 4.0 * M
         if e == 2:
