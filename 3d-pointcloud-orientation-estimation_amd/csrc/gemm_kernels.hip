@@ -398,6 +398,464 @@ gemm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, const E
 }
 
 // ---------------------------------------------------------------------------------------------
+// weights-stationary GEMM for the grouped layers (M = B*npoint*nsample rows, K and N <= 260):
+//   * the whole weight panel W[K x BN] is staged ONCE per workgroup and stays in LDS;
+//   * a workgroup is a persistent worker over row tiles; per tile the whole A'[BM x K] panel is staged
+//     in one shot (transform applied on the way in), so there are two barriers per tile instead of
+//     two per 32-deep K chunk, and the next tile's HBM stream is already in flight (registers) while
+//     the current tile runs its K/2 MFMA steps -- a full tile of compute hides the load latency;
+//   * only the HBM streams are prefetched; L2-resident side tables (pooled gradient, arg-max,
+//     per-channel constants) are read when the tile is written to LDS.
+// Layout of the reduction dimension for grouped operands: [features (D) | x y z 0].
+// ---------------------------------------------------------------------------------------------
+struct RawS {
+    float4 p, q;  // q: z stream of A_DZ
+};
+struct RawTail {
+    float x0, x1, x2, c0, c1, c2;
+};
+
+template <int MODE>
+__device__ __forceinline__ RawS ws_fetch(const AOperand &A, int row, int k, int M, int Kmain) {
+    RawS r;
+    r.p = make_float4(0.f, 0.f, 0.f, 0.f);
+    r.q = r.p;
+    const int rc = min(row, M - 1), kc = min(k, Kmain - 4);
+    if constexpr (MODE == A_PLAIN || MODE == A_BNRELU) {
+        r.p = *reinterpret_cast<const float4 *>(A.a + (size_t)rc * A.lda + kc);
+    } else if constexpr (MODE == A_DZ) {
+        r.p = *reinterpret_cast<const float4 *>(A.a + (size_t)rc * A.lda + kc);
+        r.q = *reinterpret_cast<const float4 *>(A.z + (size_t)rc * A.lda + kc);
+    } else if constexpr (MODE == A_DZ_POOL) {
+        r.p = *reinterpret_cast<const float4 *>(A.z + (size_t)rc * A.lda + kc);  // the only HBM stream
+    } else if constexpr (MODE == A_GATHER) {
+        const size_t prow = (size_t)((rc / A.K) / A.S) * A.N + A.idx[rc];
+        r.p = *reinterpret_cast<const float4 *>(A.a + prow * A.D + kc);
+    } else {  // A_CONCAT
+        r.p = *reinterpret_cast<const float4 *>(A.a + (size_t)rc * A.D + kc);
+    }
+    return r;
+}
+
+template <int MODE>
+__device__ __forceinline__ void ws_xform(const AOperand &A, const RawS &r, int row, int k, int M, int Kmain, float (&v)[4]) {
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (row >= M || k >= Kmain) return;
+    if constexpr (MODE == A_PLAIN || MODE == A_GATHER || MODE == A_CONCAT) {
+        v[0] = r.p.x, v[1] = r.p.y, v[2] = r.p.z, v[3] = r.p.w;
+    } else if constexpr (MODE == A_BNRELU) {
+        const float4 s = *reinterpret_cast<const float4 *>(A.scale + k);
+        const float4 h = *reinterpret_cast<const float4 *>(A.shift + k);
+        v[0] = fmaxf(fmaf(r.p.x, s.x, h.x), 0.f);
+        v[1] = fmaxf(fmaf(r.p.y, s.y, h.y), 0.f);
+        v[2] = fmaxf(fmaf(r.p.z, s.z, h.z), 0.f);
+        v[3] = fmaxf(fmaf(r.p.w, s.w, h.w), 0.f);
+    } else {  // A_DZ / A_DZ_POOL
+        float4 dy, z;
+        if constexpr (MODE == A_DZ) {
+            dy = r.p, z = r.q;
+        } else {
+            z = r.p;
+            const int g = row / A.K, kk = row - g * A.K;
+            const float4 dm = *reinterpret_cast<const float4 *>(A.a + (size_t)g * A.lda + k);
+            const int4 ia = *reinterpret_cast<const int4 *>(A.arg + (size_t)g * A.lda + k);
+            dy.x = kk == ia.x ? dm.x : 0.f, dy.y = kk == ia.y ? dm.y : 0.f;
+            dy.z = kk == ia.z ? dm.z : 0.f, dy.w = kk == ia.w ? dm.w : 0.f;
+        }
+        const float *c = A.cst + k;
+        const float4 g4 = *reinterpret_cast<const float4 *>(c);
+        const float4 mu = *reinterpret_cast<const float4 *>(c + A.C);
+        const float4 is = *reinterpret_cast<const float4 *>(c + 2 * A.C);
+        const float4 c1 = *reinterpret_cast<const float4 *>(c + 3 * A.C);
+        const float4 c2 = *reinterpret_cast<const float4 *>(c + 4 * A.C);
+        v[0] = g4.x * (dy.x - c1.x - (z.x - mu.x) * is.x * c2.x);
+        v[1] = g4.y * (dy.y - c1.y - (z.y - mu.y) * is.y * c2.y);
+        v[2] = g4.z * (dy.z - c1.z - (z.z - mu.z) * is.z * c2.z);
+        v[3] = g4.w * (dy.w - c1.w - (z.w - mu.w) * is.w * c2.w);
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ RawTail ws_fetch_tail(const AOperand &A, int row, int M) {
+    RawTail t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE == A_GATHER || MODE == A_CONCAT) {
+        const int rc = min(row, M - 1);
+        size_t prow = (size_t)rc;
+        if constexpr (MODE == A_GATHER) {
+            const size_t grp = (size_t)(rc / A.K);
+            prow = (size_t)(grp / A.S) * A.N + A.idx[rc];
+            const float *cp = A.new_xyz + grp * 3;
+            t.c0 = cp[0], t.c1 = cp[1], t.c2 = cp[2];
+        }
+        const float *xp = A.xyz + prow * 3;
+        t.x0 = xp[0], t.x1 = xp[1], t.x2 = xp[2];
+    }
+    return t;
+}
+
+// KD: reduction length (compile time; for grouped operands KD = D + 4 with the [x y z 0] tail last).
+// Thread -> (column group kq = tid % G4, rows tid / G4 + i * RPP): every thread keeps ONE column group
+// for the whole kernel, so its per-channel constants live in registers, and with K_nbr == 32 the
+// pooled-gradient / arg-max entries of a tile's few neighbour groups are fetched once per tile.
+template <int KD, int BM, int BN, int WM, int WN, int AMODE, int EMODE>
+__global__ void __launch_bounds__(256, 2)
+gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, const Epilogue E) {
+    constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
+    constexpr bool HAS_TAIL = (AMODE == A_GATHER || AMODE == A_CONCAT);
+    constexpr int KMAIN = HAS_TAIL ? KD - 4 : KD;  // columns served by the float4 stream
+    constexpr int G4 = KMAIN / 4;                  // column groups per row
+    constexpr int RPP = G4 > 0 ? 256 / (G4 > 0 ? G4 : 1) : 1;  // rows staged per pass
+    constexpr int NG = G4 > 0 ? BM / RPP : 0;      // passes per tile
+    constexpr int KP = KD + 1;                     // odd A pitch: conflict-free lane-per-row operand reads
+    constexpr int GPT = (BM + 31) / 32;            // neighbour groups per tile when nsample == 32
+    static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "tile configuration");
+    static_assert(G4 == 0 || (256 % G4 == 0 && BM % RPP == 0 && (32 % RPP == 0 || RPP % 32 == 0)), "staging map");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Ws = lds;            // [KD][BN]
+    float *As = lds + KD * BN;  // [BM][KP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int col_blk = blockIdx.x % ncol, worker = blockIdx.x / ncol, nworkers = gridDim.x / ncol;
+    const int n0 = col_blk * BN;
+    const int kq = G4 > 0 ? 4 * (tid % (G4 > 0 ? G4 : 1)) : 0;  // this thread's first column
+    const int r_base = G4 > 0 ? tid / (G4 > 0 ? G4 : 1) : 0;
+
+    // ---- weights: staged once, [k][n] ----
+    {
+        const float *__restrict__ Bm = B.b;
+        const int ldb = B.ldb;
+        const bool bvec = (ldb & 3) == 0 && ((uintptr_t)Bm & 15) == 0 && B.perm_D < 0;
+        for (int f = tid; f < KD * (BN / 4); f += 256) {
+            float t[4];
+            if (!B.trans) {
+                const int kk = f / (BN / 4), n = n0 + 4 * (f % (BN / 4));
+                const float *src = Bm + (size_t)min(kk, B.rows - 1) * ldb;
+                if (bvec) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src + min(n, Nout - 4));
+                    t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = src[min(n + e, Nout - 1)];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (kk < B.rows && n + e < Nout) ? t[e] : 0.f;
+                *reinterpret_cast<float4 *>(Ws + kk * BN + 4 * (f % (BN / 4))) = make_float4(t[0], t[1], t[2], t[3]);
+            } else {
+                const int nl = f % BN, k4 = 4 * (f / BN), n = n0 + nl;
+                const float *src = Bm + (size_t)min(n, Nout - 1) * ldb;
+                if (bvec) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src + min(k4, B.rows - 4));
+                    t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kp = min(k4 + e, B.rows - 1);
+                        int col = kp;
+                        if (B.perm_D >= 0) col = kp < B.perm_D ? kp + 3 : kp - B.perm_D;
+                        t[e] = src[col];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Ws[(k4 + e) * BN + nl] = (n < Nout && k4 + e < B.rows) ? t[e] : 0.f;
+            }
+        }
+    }
+
+    // ---- per-channel constants of this thread's column group: registers for the whole kernel ----
+    float4 c_g = make_float4(0.f, 0.f, 0.f, 0.f), c_mu = c_g, c_is = c_g, c_c1 = c_g, c_c2 = c_g, c_sc = c_g, c_sh = c_g;
+    if constexpr (G4 > 0 && (AMODE == A_DZ || AMODE == A_DZ_POOL)) {
+        const float *c = A.cst + kq;
+        c_g = *reinterpret_cast<const float4 *>(c);
+        c_mu = *reinterpret_cast<const float4 *>(c + A.C);
+        c_is = *reinterpret_cast<const float4 *>(c + 2 * A.C);
+        c_c1 = *reinterpret_cast<const float4 *>(c + 3 * A.C);
+        c_c2 = *reinterpret_cast<const float4 *>(c + 4 * A.C);
+    } else if constexpr (G4 > 0 && AMODE == A_BNRELU) {
+        c_sc = *reinterpret_cast<const float4 *>(A.scale + kq);
+        c_sh = *reinterpret_cast<const float4 *>(A.shift + kq);
+    }
+
+    double s1[NT], s2[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) s1[i] = s2[i] = 0.0;
+
+    const int tiles = (M + BM - 1) / BM;
+    const bool pool_fast = (AMODE == A_DZ_POOL) && A.K == 32;  // tiles start on neighbour-group boundaries (BM % 32 == 0)
+    float4 rp[NG > 0 ? NG : 1], rq[(AMODE == A_DZ && NG > 0) ? NG : 1];
+    RawTail rt;
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int rc = min(m0 + r_base + i * RPP, M - 1);
+            if constexpr (AMODE == A_PLAIN || AMODE == A_BNRELU) {
+                rp[i] = *reinterpret_cast<const float4 *>(A.a + (size_t)rc * A.lda + kq);
+            } else if constexpr (AMODE == A_DZ) {
+                rp[i] = *reinterpret_cast<const float4 *>(A.a + (size_t)rc * A.lda + kq);
+                rq[i] = *reinterpret_cast<const float4 *>(A.z + (size_t)rc * A.lda + kq);
+            } else if constexpr (AMODE == A_DZ_POOL) {
+                rp[i] = *reinterpret_cast<const float4 *>(A.z + (size_t)rc * A.lda + kq);  // the only HBM stream
+            } else if constexpr (AMODE == A_GATHER) {
+                const size_t prow = (size_t)((rc / A.K) / A.S) * A.N + A.idx[rc];
+                rp[i] = *reinterpret_cast<const float4 *>(A.a + prow * A.D + kq);
+            } else {
+                rp[i] = *reinterpret_cast<const float4 *>(A.a + (size_t)rc * A.D + kq);
+            }
+        }
+        if constexpr (HAS_TAIL) rt = ws_fetch_tail<AMODE>(A, m0 + min(tid, BM - 1), M);
+    };
+    int tile = worker;
+    if (tile < tiles) fetch(tile * BM);
+    for (; tile < tiles; tile += nworkers) {
+        const int m0 = tile * BM;
+        // pooled gradient / arg-max of the tile's neighbour groups at this thread's columns (L2-resident tables)
+        float4 gdm[GPT];
+        int4 garg[GPT];
+        if constexpr (AMODE == A_DZ_POOL) {
+            if (pool_fast) {
+#pragma unroll
+                for (int g = 0; g < GPT; ++g) {
+                    const size_t gi = (size_t)min(m0 / 32 + g, (M - 1) / 32) * A.lda + kq;
+                    gdm[g] = *reinterpret_cast<const float4 *>(A.a + gi);
+                    garg[g] = *reinterpret_cast<const int4 *>(A.arg + gi);
+                }
+            }
+        }
+        __syncthreads();  // previous tile's operand reads are done (and, first time, the weights are staged)
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int r = r_base + i * RPP, row = m0 + r;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (row < M) {
+                if constexpr (AMODE == A_PLAIN || AMODE == A_GATHER || AMODE == A_CONCAT) {
+                    v[0] = rp[i].x, v[1] = rp[i].y, v[2] = rp[i].z, v[3] = rp[i].w;
+                } else if constexpr (AMODE == A_BNRELU) {
+                    v[0] = fmaxf(fmaf(rp[i].x, c_sc.x, c_sh.x), 0.f);
+                    v[1] = fmaxf(fmaf(rp[i].y, c_sc.y, c_sh.y), 0.f);
+                    v[2] = fmaxf(fmaf(rp[i].z, c_sc.z, c_sh.z), 0.f);
+                    v[3] = fmaxf(fmaf(rp[i].w, c_sc.w, c_sh.w), 0.f);
+                } else {
+                    float4 dy, z;
+                    if constexpr (AMODE == A_DZ) {
+                        dy = rp[i], z = rq[i];
+                    } else {
+                        z = rp[i];
+                        float4 dm;
+                        int4 ia;
+                        int kk;
+                        if (pool_fast) {
+                            // neighbour group of this row inside the tile: a constant per unrolled pass when RPP | 32
+                            const int g = (RPP >= 32) ? r / 32 : (i * RPP) / 32;
+                            dm = gdm[0], ia = garg[0];
+#pragma unroll
+                            for (int gg = 1; gg < GPT; ++gg)
+                                if (g == gg) dm = gdm[gg], ia = garg[gg];
+                            kk = r - g * 32;
+                        } else {
+                            const int g = row / A.K;
+                            kk = row - g * A.K;
+                            dm = *reinterpret_cast<const float4 *>(A.a + (size_t)g * A.lda + kq);
+                            ia = *reinterpret_cast<const int4 *>(A.arg + (size_t)g * A.lda + kq);
+                        }
+                        dy.x = kk == ia.x ? dm.x : 0.f, dy.y = kk == ia.y ? dm.y : 0.f;
+                        dy.z = kk == ia.z ? dm.z : 0.f, dy.w = kk == ia.w ? dm.w : 0.f;
+                    }
+                    v[0] = c_g.x * (dy.x - c_c1.x - (z.x - c_mu.x) * c_is.x * c_c2.x);
+                    v[1] = c_g.y * (dy.y - c_c1.y - (z.y - c_mu.y) * c_is.y * c_c2.y);
+                    v[2] = c_g.z * (dy.z - c_c1.z - (z.z - c_mu.z) * c_is.z * c_c2.z);
+                    v[3] = c_g.w * (dy.w - c_c1.w - (z.w - c_mu.w) * c_is.w * c_c2.w);
+                }
+            }
+            float *d = As + r * KP + kq;
+            d[0] = v[0], d[1] = v[1], d[2] = v[2], d[3] = v[3];
+        }
+        if constexpr (HAS_TAIL) {
+            if (tid < BM) {
+                const bool ok = m0 + tid < M;
+                float *d = As + tid * KP + KMAIN;  // [x-cx, y-cy, z-cz, 0]: float32 subtraction, pointnet_pp_8dir.py:32
+                d[0] = ok ? __fsub_rn(rt.x0, rt.c0) : 0.f;
+                d[1] = ok ? __fsub_rn(rt.x1, rt.c1) : 0.f;
+                d[2] = ok ? __fsub_rn(rt.x2, rt.c2) : 0.f;
+                d[3] = 0.f;
+            }
+        }
+        __syncthreads();
+        if (tile + nworkers < tiles) fetch((tile + nworkers) * BM);  // next tile's HBM stream flies during the MFMA loop
+
+        // the ReLU-mask operand of the epilogue is fetched now and lands while the MFMA loop runs
+        float zp[MT][NT][16];
+        if constexpr (EMODE == E_MASK_STATS) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int cc = min(n0 + wn * TN + j * 32 + l31, Nout - 1);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        zp[i][j][r] = E.zp[(size_t)min(row, M - 1) * E.ldc + cc];
+                    }
+                }
+        }
+
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const float *ap = As + (wm * TM + l31) * KP + lh;
+        const float *bp = Ws + lh * BN + wn * TN + l31;
+#pragma unroll 8
+        for (int s = 0; s < KD / 2; ++s) {
+            float a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = ap[i * 32 * KP + 2 * s];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = bp[2 * s * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+
+        // epilogue: each accumulator register is one row; a half-wave writes 32 consecutive floats (128 B)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = n0 + wn * TN + j * 32 + l31;
+                float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
+                if constexpr (EMODE == E_MASK_STATS) {
+                    const int cc = min(col, Nout - 1);
+                    sc = E.scale[cc], sh = E.shift[cc], mu = E.mu[cc], is = E.istd[cc];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const bool ok = row < M && col < Nout;
+                    float v = ok ? acc[i][j][r] : 0.f;
+                    if constexpr (EMODE == E_STORE_STATS) {
+                        s1[j] += (double)v;
+                        s2[j] += (double)v * (double)v;
+                    } else if constexpr (EMODE == E_MASK_STATS) {
+                        const float z0 = zp[i][j][r];
+                        v = (fmaf(z0, sc, sh) > 0.f) ? v : 0.f;
+                        s1[j] += (double)v;
+                        s2[j] += (double)v * (double)((z0 - mu) * is);
+                    }
+                    if (ok) E.c[(size_t)row * E.ldc + col] = v;
+                }
+            }
+    }
+
+    if constexpr (EMODE != E_STORE) {
+        __syncthreads();
+        double *red = reinterpret_cast<double *>(lds);  // [WM][2][BN]; the launcher sizes the LDS for it as well
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            double a = s1[j] + shfl_xor_f64(s1[j], 32);
+            double b = s2[j] + shfl_xor_f64(s2[j], 32);
+            if (lh == 0) {
+                const int cl = wn * TN + j * 32 + l31;
+                red[(wm * 2 + 0) * BN + cl] = a;
+                red[(wm * 2 + 1) * BN + cl] = b;
+            }
+        }
+        __syncthreads();
+        for (int f = tid; f < 2 * BN; f += 256) {
+            const int which = f / BN, cl = f % BN;
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + cl];
+            if (n0 + cl < Nout) E.slab[((size_t)worker * 2 + which) * Nout + n0 + cl] = t;
+        }
+    }
+}
+
+template <int KD, int BM, int BN, int WM, int WN, int AM, int EM>
+static int launch_ws_one(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int *nslab, hipStream_t st) {
+    const int tiles = cdiv(M, BM), ncol = cdiv(Nout, BN);
+    int workers = 768 / ncol;  // up to three workgroups per CU (LDS and registers permitting)
+    if (workers > tiles) workers = tiles;
+    if (workers > kMaxStatBlocks) workers = kMaxStatBlocks;
+    if (workers < 1) workers = 1;
+    if (nslab) *nslab = workers;
+    size_t lds = ((size_t)KD * BN + (size_t)BM * (KD + 1)) * sizeof(float);
+    const size_t red_bytes = (size_t)WM * 2 * BN * sizeof(double);  // column-statistics reduction reuses the LDS
+    if (lds < red_bytes) lds = red_bytes;
+    ProfScope ps(st, "gemm_ws_kernel<%d,%d,%d,A%d,E%d> M=%d N=%d K=%d", KD, BM, BN, AM, EM, M, Nout, KD);
+    auto kfn = gemm_ws_kernel<KD, BM, BN, WM, WN, AM, EM>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, dim3(workers * ncol), dim3(256), lds, st, A, B, M, Nout, ncol, E);
+    PNPP_CHECK_LAUNCH("gemm_ws");
+    return PNPP_OK;
+}
+
+template <int KD, int BM, int BN, int WM, int WN, int AM>
+static int launch_ws_e(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int *nslab, hipStream_t st) {
+    switch (E.mode) {
+        case E_STORE: return launch_ws_one<KD, BM, BN, WM, WN, AM, E_STORE>(A, B, M, Nout, E, nslab, st);
+        case E_STORE_STATS: return launch_ws_one<KD, BM, BN, WM, WN, AM, E_STORE_STATS>(A, B, M, Nout, E, nslab, st);
+        case E_MASK_STATS: return launch_ws_one<KD, BM, BN, WM, WN, AM, E_MASK_STATS>(A, B, M, Nout, E, nslab, st);
+    }
+    set_error("gemm_ws: bad epilogue mode %d", E.mode);
+    return PNPP_ERR_ARG;
+}
+
+// dense (non-grouped) operands: K in {64, 128, 256}
+template <int KD, int BM, int BN, int WM, int WN>
+static int launch_ws_dense(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int *nslab, hipStream_t st) {
+    switch (A.mode) {
+        case A_PLAIN: return launch_ws_e<KD, BM, BN, WM, WN, A_PLAIN>(A, B, M, Nout, E, nslab, st);
+        case A_BNRELU: return launch_ws_e<KD, BM, BN, WM, WN, A_BNRELU>(A, B, M, Nout, E, nslab, st);
+        case A_DZ: return launch_ws_e<KD, BM, BN, WM, WN, A_DZ>(A, B, M, Nout, E, nslab, st);
+        case A_DZ_POOL: return launch_ws_e<KD, BM, BN, WM, WN, A_DZ_POOL>(A, B, M, Nout, E, nslab, st);
+    }
+    set_error("gemm_ws: bad A mode %d", A.mode);
+    return PNPP_ERR_ARG;
+}
+
+// picks a weights-stationary configuration, or returns false when the shape does not qualify (the chunked kernel
+// then handles it): the reference models' grouped layers all qualify
+static bool try_launch_ws(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab,
+                          hipStream_t st, int *rc) {
+    if (M < 8192 || Nout % 64 != 0) return false;
+    const bool grouped = A.mode == A_GATHER || A.mode == A_CONCAT;
+    if (grouped) {
+        if (Kd != A.D + 4) return false;
+        if (A.mode != A_GATHER) return false;
+        if (A.D == 0) {  // xyz only
+            if (Nout % 128 == 0) *rc = launch_ws_e<4, 128, 128, 4, 1, A_GATHER>(A, B, M, Nout, E, nslab, st);
+            else *rc = launch_ws_e<4, 128, 64, 4, 1, A_GATHER>(A, B, M, Nout, E, nslab, st);
+            return true;
+        }
+        if (A.D == 128 && ((uintptr_t)A.a & 15) == 0) {
+            *rc = launch_ws_e<132, 64, 64, 2, 2, A_GATHER>(A, B, M, Nout, E, nslab, st);
+            return true;
+        }
+        return false;
+    }
+    if (A.lda % 4 != 0 || ((uintptr_t)A.a & 15) != 0) return false;
+    if (Kd == 64) {
+        if (Nout % 128 == 0) *rc = launch_ws_dense<64, 128, 128, 4, 1>(A, B, M, Nout, E, nslab, st);
+        else *rc = launch_ws_dense<64, 128, 64, 4, 1>(A, B, M, Nout, E, nslab, st);
+        return true;
+    }
+    if (Kd == 128) {
+        *rc = launch_ws_dense<128, 64, 64, 2, 2>(A, B, M, Nout, E, nslab, st);
+        return true;
+    }
+    if (Kd == 256) {
+        *rc = launch_ws_dense<256, 64, 64, 2, 2>(A, B, M, Nout, E, nslab, st);
+        return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------
 // small-M GEMM (fully connected head: M = batch rows).  One 32x32 output tile per workgroup; the
 // reduction dimension is split over the 4 waves (chunk-interleaved), so a K=1024 layer is 8 chunks
 // deep instead of 32.  A chunks go through wave-private LDS (row-major global -> lane-per-row
@@ -537,6 +995,10 @@ int launch_gemm(const AOperand &A, const BOperand &Bin, int M, int Nout, int Kd,
     PNPP_REQUIRE(Kd % 4 == 0, PNPP_ERR_ARG, "gemm: K=%d must be a multiple of 4", Kd);
     BOperand B = Bin;
     if (B.rows <= 0 || B.rows > Kd) B.rows = Kd;
+    {
+        int rc = PNPP_OK;
+        if (try_launch_ws(A, B, M, Nout, Kd, E, nslab, st, &rc)) return rc;
+    }
     const bool b_aligned = (B.ldb % 4 == 0) && (((uintptr_t)B.b & 15) == 0) && B.perm_D < 0;
     if (A.mode == A_PLAIN && E.mode != E_MASK_STATS && M <= 512 && cdiv(M, 32) <= kMaxStatBlocks && b_aligned) {
         PNPP_REQUIRE(A.lda % 4 == 0 && ((uintptr_t)A.a & 15) == 0, PNPP_ERR_ARG, "gemm(small M): A pitch/alignment");
