@@ -862,9 +862,9 @@ static bool try_launch_ws(const AOperand &A, const BOperand &B, int M, int Nout,
 // operand), B (weights, [k][n] row-major) is read straight into the MFMA operand layout (the lane
 // index is n: one 128-byte segment per half-wave).  Next chunk's loads fly during the MFMA loop.
 // ---------------------------------------------------------------------------------------------
-template <int EMODE, bool BT>
+template <int AMODE, int EMODE, bool BT>
 __global__ void __launch_bounds__(256)
-gemm_smallm_kernel(const float *__restrict__ Am, int lda, const BOperand B, int M, int Nout, int Kd, const Epilogue E) {
+gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, const Epilogue E) {
     // per wave: A chunk [32][33], (BT only) weight chunk [32 n][33]; then the K-split partials [4][32][32]
     __shared__ __attribute__((aligned(16))) float lds[8 * 32 * APITCH + 4 * 32 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -880,7 +880,7 @@ gemm_smallm_kernel(const float *__restrict__ Am, int lda, const BOperand B, int 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    float4 na[4];
+    RawA na[4];
     float4 nw[4];        // BT: weight rows, same (row, 4k) mapping as the A chunk
     float nb[KC / 2];    // !BT: weights already in operand layout
     auto fetch = [&](int c) {
@@ -888,28 +888,37 @@ gemm_smallm_kernel(const float *__restrict__ Am, int lda, const BOperand B, int 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = (lane >> 3) + 8 * i, k = k0 + 4 * (lane & 7);
-            na[i] = (m0 + r < M && k < Kd) ? *reinterpret_cast<const float4 *>(Am + (size_t)(m0 + r) * lda + k)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            na[i] = fetch_a4<AMODE>(A, m0 + r, k, M, Kd);
             if constexpr (BT)
-                nw[i] = (n0 + r < Nout && k < B.rows) ? *reinterpret_cast<const float4 *>(Bm + (size_t)(n0 + r) * ldb + k)
-                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                nw[i] = *reinterpret_cast<const float4 *>(Bm + (size_t)min(n0 + r, Nout - 1) * ldb + min(k, B.rows - 4));
         }
         if constexpr (!BT) {
 #pragma unroll
             for (int s2 = 0; s2 < KC / 2; ++s2) {
                 const int k = k0 + 2 * s2 + lh;
-                nb[s2] = (k < B.rows && n0 + l31 < Nout) ? Bm[(size_t)k * ldb + n0 + l31] : 0.f;
+                const float v = Bm[(size_t)min(k, B.rows - 1) * ldb + min(n0 + l31, Nout - 1)];
+                nb[s2] = (k < B.rows && n0 + l31 < Nout) ? v : 0.f;
             }
         }
     };
     if (wave < nchunks) fetch(wave);
     for (int c = wave; c < nchunks; c += 4) {
         float cb[KC / 2];
+        const int k0 = c * KC;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int o = ((lane >> 3) + 8 * i) * APITCH + 4 * (lane & 7);
-            As[o] = na[i].x, As[o + 1] = na[i].y, As[o + 2] = na[i].z, As[o + 3] = na[i].w;
-            if constexpr (BT) Ws[o] = nw[i].x, Ws[o + 1] = nw[i].y, Ws[o + 2] = nw[i].z, Ws[o + 3] = nw[i].w;
+            const int r = (lane >> 3) + 8 * i, k = k0 + 4 * (lane & 7);
+            const int o = r * APITCH + 4 * (lane & 7);
+            float v[4];
+            xform_a4<AMODE>(A, na[i], m0 + r, k, M, Kd, v);
+            As[o] = v[0], As[o + 1] = v[1], As[o + 2] = v[2], As[o + 3] = v[3];
+            if constexpr (BT) {
+                const bool okw = n0 + r < Nout;
+                Ws[o] = (okw && k < B.rows) ? nw[i].x : 0.f;
+                Ws[o + 1] = (okw && k + 1 < B.rows) ? nw[i].y : 0.f;
+                Ws[o + 2] = (okw && k + 2 < B.rows) ? nw[i].z : 0.f;
+                Ws[o + 3] = (okw && k + 3 < B.rows) ? nw[i].w : 0.f;
+            }
         }
         if constexpr (!BT) {
 #pragma unroll
@@ -926,32 +935,61 @@ gemm_smallm_kernel(const float *__restrict__ Am, int lda, const BOperand B, int 
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + l31] = acc[r];
     __syncthreads();
-    float v[4];
+    float v[4], w2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int e = tid + 256 * j;
         v[j] = (part[e] + part[1024 + e]) + (part[2048 + e] + part[3072 + e]);
+        w2[j] = 0.f;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int e = tid + 256 * j, row = m0 + e / 32, col = n0 + e % 32;
-        part[e] = (row < M) ? v[j] : 0.f;
-        if (row < M && col < Nout) E.c[(size_t)row * E.ldc + col] = v[j];
+        const bool ok = row < M && col < Nout;
+        float x = ok ? v[j] : 0.f;
+        if constexpr (EMODE == E_MASK_STATS) {
+            const int cc = min(col, Nout - 1);
+            const float zp = E.zp[(size_t)min(row, M - 1) * E.ldc + cc];
+            x = (fmaf(zp, E.scale[cc], E.shift[cc]) > 0.f) ? x : 0.f;
+            w2[j] = x * ((zp - E.mu[cc]) * E.istd[cc]);
+            part[1024 + e] = w2[j];
+        }
+        part[e] = x;
+        if (ok) E.c[(size_t)row * E.ldc + col] = x;
     }
-    if constexpr (EMODE == E_STORE_STATS) {
+    if constexpr (EMODE != E_STORE) {
         __syncthreads();
         if (tid < 32 && n0 + tid < Nout) {
             double s1 = 0.0, s2 = 0.0;
             for (int r = 0; r < 32; ++r) {
                 const double x = (double)part[r * 32 + tid];
                 s1 += x;
-                s2 += x * x;
+                if constexpr (EMODE == E_STORE_STATS) s2 += x * x;
+                else s2 += (double)part[1024 + r * 32 + tid];
             }
             E.slab[((size_t)blockIdx.y * 2 + 0) * Nout + n0 + tid] = s1;
             E.slab[((size_t)blockIdx.y * 2 + 1) * Nout + n0 + tid] = s2;
         }
     }
+}
+
+template <int AM, int EM>
+static void launch_smallm_t(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, dim3 grid,
+                            hipStream_t st) {
+    if (B.trans) hipLaunchKernelGGL((gemm_smallm_kernel<AM, EM, true>), grid, dim3(256), 0, st, A, B, M, Nout, Kd, E);
+    else hipLaunchKernelGGL((gemm_smallm_kernel<AM, EM, false>), grid, dim3(256), 0, st, A, B, M, Nout, Kd, E);
+}
+template <int AM>
+static int launch_smallm_e(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, dim3 grid,
+                           hipStream_t st) {
+    switch (E.mode) {
+        case E_STORE: launch_smallm_t<AM, E_STORE>(A, B, M, Nout, Kd, E, grid, st); return PNPP_OK;
+        case E_STORE_STATS: launch_smallm_t<AM, E_STORE_STATS>(A, B, M, Nout, Kd, E, grid, st); return PNPP_OK;
+        case E_MASK_STATS: launch_smallm_t<AM, E_MASK_STATS>(A, B, M, Nout, Kd, E, grid, st); return PNPP_OK;
+    }
+    set_error("gemm(small M): bad epilogue mode %d", E.mode);
+    return PNPP_ERR_ARG;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -1000,18 +1038,22 @@ int launch_gemm(const AOperand &A, const BOperand &Bin, int M, int Nout, int Kd,
         if (try_launch_ws(A, B, M, Nout, Kd, E, nslab, st, &rc)) return rc;
     }
     const bool b_aligned = (B.ldb % 4 == 0) && (((uintptr_t)B.b & 15) == 0) && B.perm_D < 0;
-    if (A.mode == A_PLAIN && E.mode != E_MASK_STATS && M <= 512 && cdiv(M, 32) <= kMaxStatBlocks && b_aligned) {
-        PNPP_REQUIRE(A.lda % 4 == 0 && ((uintptr_t)A.a & 15) == 0, PNPP_ERR_ARG, "gemm(small M): A pitch/alignment");
+    const bool a_aligned = (A.mode == A_CONCAT || A.mode == A_GATHER) || (A.lda % 4 == 0 && ((uintptr_t)A.a & 15) == 0);
+    if (M <= 4096 && cdiv(M, 32) <= kMaxStatBlocks && b_aligned && a_aligned && A.mode != A_GATHER) {
+        // split-K 32x32 tiles: the fully connected head (M = batch) and the group_all layers (M = B * 32)
         const dim3 grid(cdiv(Nout, 32), cdiv(M, 32));
         if (nslab) *nslab = grid.y;
-        ProfScope ps(st, "gemm_smallm_kernel<E%d,T%d> M=%d N=%d K=%d", E.mode, B.trans, M, Nout, Kd);
-        if (E.mode == E_STORE_STATS) {
-            if (B.trans) hipLaunchKernelGGL((gemm_smallm_kernel<E_STORE_STATS, true>), grid, dim3(256), 0, st, A.a, A.lda, B, M, Nout, Kd, E);
-            else hipLaunchKernelGGL((gemm_smallm_kernel<E_STORE_STATS, false>), grid, dim3(256), 0, st, A.a, A.lda, B, M, Nout, Kd, E);
-        } else {
-            if (B.trans) hipLaunchKernelGGL((gemm_smallm_kernel<E_STORE, true>), grid, dim3(256), 0, st, A.a, A.lda, B, M, Nout, Kd, E);
-            else hipLaunchKernelGGL((gemm_smallm_kernel<E_STORE, false>), grid, dim3(256), 0, st, A.a, A.lda, B, M, Nout, Kd, E);
+        ProfScope ps(st, "gemm_smallm_kernel<A%d,E%d,T%d> M=%d N=%d K=%d", A.mode, E.mode, B.trans, M, Nout, Kd);
+        int rc = PNPP_OK;
+        switch (A.mode) {
+            case A_PLAIN: rc = launch_smallm_e<A_PLAIN>(A, B, M, Nout, Kd, E, grid, st); break;
+            case A_BNRELU: rc = launch_smallm_e<A_BNRELU>(A, B, M, Nout, Kd, E, grid, st); break;
+            case A_CONCAT: rc = launch_smallm_e<A_CONCAT>(A, B, M, Nout, Kd, E, grid, st); break;
+            case A_DZ: rc = launch_smallm_e<A_DZ>(A, B, M, Nout, Kd, E, grid, st); break;
+            case A_DZ_POOL: rc = launch_smallm_e<A_DZ_POOL>(A, B, M, Nout, Kd, E, grid, st); break;
+            default: set_error("gemm(small M): bad A mode %d", A.mode); return PNPP_ERR_ARG;
         }
+        if (rc != PNPP_OK) return rc;
         PNPP_CHECK_LAUNCH("gemm(small M)");
         return PNPP_OK;
     }
