@@ -1,0 +1,55 @@
+"""dataloader_multi_peak_vonMises.py -- drop-in for the reference module of the same name (lines 28-86).
+
+PointCloudDatasetMvM(samples, num_points, max_K=4, label_map=None):
+    samples  [(ply_path, gt_txt_path, category), ...]
+    item ->  (xyz (N,3), vm_params (max_K,3) rows [mu, kappa, weight] zero padded, K int, label LongTensor scalar)
+GT text: first non-comment line "K <int>", second line a header, then one "mu kappa weight" row per peak
+(reference lines 36-64).  Missing files raise FileNotFoundError, malformed ones RuntimeError, as in the reference.
+"""
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from dataloader_common import read_ply, sample_pts  # noqa: F401
+
+
+class PointCloudDatasetMvM(Dataset):
+    def __init__(self, samples, num_points, max_K=4, label_map=None):
+        self.samples = list(samples)
+        self.num_points = num_points
+        self.max_K = max_K
+        self.label_map = label_map or {cat: i for i, cat in enumerate(sorted(set(s[2] for s in samples)))}
+
+    @staticmethod
+    def _read_mvM(gt_path, max_K=4):
+        with open(gt_path, "r", encoding="utf-8") as f:
+            lines = [ln.strip() for ln in f if ln.strip() and not ln.startswith("#")]
+        if len(lines) < 2:
+            raise RuntimeError(f"GT file too short or malformed: {gt_path}")
+        parts = lines[0].split()
+        if len(parts) < 2:
+            raise RuntimeError(f"GT file K line malformed: {gt_path}")
+        K = int(parts[1])
+        rows = []
+        for ln in lines[2:]:
+            vals = ln.split()
+            if len(vals) >= 3:
+                rows.append([float(vals[0]), float(vals[1]), float(vals[2])])
+        while len(rows) < max_K:
+            rows.append([0.0, 0.0, 0.0])
+        return torch.tensor(np.asarray(rows, dtype=np.float64)[:max_K], dtype=torch.float32), K
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, idx):
+        ply_p, gt_txt, category = self.samples[idx]
+        if not os.path.exists(ply_p):
+            raise FileNotFoundError(f"PLY not found: {ply_p}")
+        xyz = torch.from_numpy(np.ascontiguousarray(sample_pts(read_ply(ply_p), self.num_points), dtype=np.float32))
+        if not os.path.exists(gt_txt):
+            raise FileNotFoundError(f"GT txt not found: {gt_txt}, for ply: {ply_p}")
+        vm_params, K = self._read_mvM(gt_txt, self.max_K)
+        return xyz, vm_params, K, torch.tensor(self.label_map[category], dtype=torch.long)

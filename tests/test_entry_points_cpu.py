@@ -1,0 +1,126 @@
+"""CPU tests of the drop-in entry points: dataloader_* (reference tuple layouts, error behaviour) and the
+module-level surface of the train_* scripts.  The reference's own behaviour for each case is cited inline."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+PLY_HEADER = "ply\nformat ascii 1.0\nelement vertex {n}\nproperty float x\nproperty float y\nproperty float z\nend_header\n"
+
+
+def _write_ply(path, pts, extra_cols=0):
+    with open(path, "w") as f:
+        f.write(PLY_HEADER.format(n=len(pts)))
+        for p in pts:
+            f.write(" ".join(f"{v:.6f}" for v in list(p) + [0.5] * extra_cols) + "\n")
+
+
+@pytest.fixture()
+def cloud(tmp_path):
+    pts = np.random.RandomState(0).rand(50, 3).astype(np.float32)
+    p = tmp_path / "chair_0001.ply"
+    _write_ply(p, pts, extra_cols=3)        # normals after xyz are ignored (first three columns only)
+    return p, pts
+
+
+def test_read_ply_and_sampling(cloud, tmp_path, monkeypatch):
+    import dataloader_common as dc
+    p, pts = cloud
+    got = dc.read_ply(p)
+    assert got.shape == (50, 3) and np.allclose(got, pts, atol=1e-6)
+    np.random.seed(0)
+    s = dc.sample_pts(got, 20)
+    assert s.shape == (20, 3) and len({tuple(r) for r in s.tolist()}) == 20          # without replacement when enough points
+    s = dc.sample_pts(got, 200)
+    assert s.shape == (200, 3)                                                        # with replacement otherwise
+    monkeypatch.setenv("PNPP_PLY_CACHE_DIR", str(tmp_path / "cache"))
+    a = dc.read_ply(p)
+    b = dc.read_ply(p)                                                                # second read is served by the cache
+    assert np.array_equal(np.asarray(a), np.asarray(b)) and len(os.listdir(tmp_path / "cache")) == 1
+
+
+def test_single_peak_dataset(cloud):
+    from dataloader_single_peak_vonMises import PointCloudDatasetVonMises, read_ply, sample_pts  # noqa: F401
+    p, _ = cloud
+    gt = p.with_name(p.stem + "_single_peak_vM_gt.txt")
+    gt.write_text("# mu(rad)\tkappa\n-0.84729610\t8.000000\n")
+    ds = PointCloudDatasetVonMises([(p, "chair")], 64)
+    xyz, vm, lbl = ds[0]
+    assert xyz.shape == (64, 3) and xyz.dtype == torch.float32 and vm.dtype == torch.float32 and lbl == 0
+    assert torch.allclose(vm, torch.tensor([-0.84729610, 8.0]))
+    gt.write_text("# nothing parsable\nfoo bar\n")                                     # reference: silently (0, 0)
+    assert torch.equal(ds[0][1], torch.zeros(2))
+    gt.write_text("0.5 -3.0\n")                                                        # kappa clamped at 0
+    assert torch.allclose(ds[0][1], torch.tensor([0.5, 0.0]))
+    gt.unlink()
+    assert torch.equal(ds[0][1], torch.zeros(2))                                        # missing file too
+    ds2 = PointCloudDatasetVonMises([(p, "sofa"), (p, "chair")], 8, label_map={"chair": 5, "sofa": 7})
+    assert ds2[0][2] == 7 and len(ds2) == 2
+
+
+def test_multi_peak_dataset(cloud, tmp_path):
+    from dataloader_multi_peak_vonMises import PointCloudDatasetMvM
+    p, _ = cloud
+    gt = tmp_path / "chair_0001_multi_peak_vM_gt.txt"
+    gt.write_text("K 2\nmu kappa weight\n0.100 8.0 0.5\n-3.0415 8.0 0.5\n")
+    ds = PointCloudDatasetMvM([(str(p), str(gt), "chair")], 32, max_K=4)
+    xyz, vm, K, lbl = ds[0]
+    assert xyz.shape == (32, 3) and vm.shape == (4, 3) and K == 2 and lbl.dtype == torch.long and int(lbl) == 0
+    assert torch.allclose(vm[:2], torch.tensor([[0.1, 8.0, 0.5], [-3.0415, 8.0, 0.5]])) and torch.all(vm[2:] == 0)
+    gt.write_text("K 2\n")
+    with pytest.raises(RuntimeError, match="too short"):
+        ds[0]
+    gt.write_text("K\nheader\n")
+    with pytest.raises(RuntimeError, match="K line"):
+        ds[0]
+    with pytest.raises(FileNotFoundError):
+        PointCloudDatasetMvM([(str(p) + ".missing", str(gt), "chair")], 32)[0]
+    with pytest.raises(FileNotFoundError):
+        PointCloudDatasetMvM([(str(p), str(gt) + ".missing", "chair")], 32)[0]
+
+
+def test_8dir_dataset(cloud, tmp_path):
+    from dataloader_8dir_sampled import PointCloudDataset
+    p, _ = cloud
+    prob = tmp_path / "chair_0001_8dir.txt"
+    vals = np.array([0.5, 0.25, 0, 0, 0, 0, 0, 0.25], np.float32)
+    np.savetxt(prob, vals)
+    ds = PointCloudDataset([(p, prob, "chair"), (p, prob, "bottle"), (p, str(prob) + ".missing", "chair")], 16, {"bottle"})
+    xyz, pr, lbl = ds[0]
+    assert xyz.shape == (16, 3) and torch.allclose(pr, torch.from_numpy(vals)) and lbl == 0
+    assert torch.allclose(ds[1][1], torch.full((8,), 0.125)) and ds[1][2] == 1       # symmetric class -> uniform
+    assert torch.allclose(ds[2][1], torch.full((8,), 0.125))                           # missing file -> uniform
+    prob.write_text("not numbers\n")
+    assert torch.allclose(ds[0][1], torch.full((8,), 0.125))                           # unreadable -> uniform
+
+
+def test_train_scripts_surface(monkeypatch):
+    """Names the reference scripts define at module level; importing must not start training."""
+    import train_single_peak_vonMises_KL as t1
+    import train_multi_peaks_vonMises_KL as t2
+    import train_8dir_KL as t3
+    for name in ("ROOT", "RES", "FIGS", "NUM_POINTS", "BATCH", "EPOCHS", "LR", "SEED", "device", "kl_von_mises", "plot_curve"):
+        assert hasattr(t1, name), name
+    assert (t1.NUM_POINTS, t1.BATCH, t1.EPOCHS, t1.LR, t1.SEED) == (10_000, 16, 200, 1e-3, 42)       # reference lines 18-19
+    for name in ("ROOT", "PLY_ROOT", "RES", "kl_von_mises", "match_loss", "write_summary_txt", "main"):
+        assert hasattr(t2, name), name
+    assert (t2.NUM_POINTS, t2.BATCH, t2.EPOCHS) == (10_000, 16, 100)
+    assert hasattr(t3, "kl_loss_per_sample_from_logits")
+    # multi-peak KL helper vs the first block of the reference's debug log (kappa_g = 0 -> clamp to 1e-6)
+    v = t2.kl_von_mises(torch.tensor([0.0]), torch.tensor([1.2209635]), torch.tensor([-0.5524741]), torch.tensor([0.0]))
+    assert abs(float(v) - 0.29115965962409973) < 2e-6
+
+
+def test_results_txt_format(tmp_path):
+    import train_multi_peaks_vonMises_KL as t2
+    hist = {"total": {"train": [0.2, 0.084364], "val": [0.3, 0.083457]}, "bathtub": {"train": [0.7, 0.71], "val": [0.8, 0.77]},
+            "empty": {"train": [], "val": []}}
+    out = tmp_path / "results.txt"
+    t2.write_summary_txt(out, ["bathtub", "empty"], hist, test_kl=0.077724, best_val_epoch=55)
+    lines = out.read_text().splitlines()
+    # results/multi_peak_vonMises_KL/results.txt:1-6 of the reference
+    assert lines[0] == "=== Multi-Peak von Mises KL Summary ===" and lines[1] == "Best Total Val Epoch: 55"
+    assert lines[2] == "Test KL: 0.077724" and lines[4] == "-- Per-Category (last epoch) --"
+    assert lines[5] == "[TOTAL] Train=0.084364 Val=0.083457" and lines[6] == "[bathtub] Train=0.710000 Val=0.770000"
+    assert lines[7] == "[empty] Train=nan Val=nan"
