@@ -786,7 +786,7 @@ static int launch_ws_one(const AOperand &A, const BOperand &B, int M, int Nout, 
     size_t lds = ((size_t)KD * BN + (size_t)BM * (KD + 1)) * sizeof(float);
     const size_t red_bytes = (size_t)WM * 2 * BN * sizeof(double);  // column-statistics reduction reuses the LDS
     if (lds < red_bytes) lds = red_bytes;
-    ProfScope ps(st, "gemm_ws_kernel<%d,%d,%d,A%d,E%d> M=%d N=%d K=%d", KD, BM, BN, AM, EM, M, Nout, KD);
+    ProfScope ps(st, "gemm_ws_kernel<%d,%d,%d,A%d,E%d> M=%d N=%d K=%d grid=%dx1", KD, BM, BN, AM, EM, M, Nout, KD, workers * ncol);
     auto kfn = gemm_ws_kernel<KD, BM, BN, WM, WN, AM, EM>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, dim3(workers * ncol), dim3(256), lds, st, A, B, M, Nout, ncol, E);
@@ -999,7 +999,8 @@ static int launch_gemm_cfg(const AOperand &A, const BOperand &B, int M, int Nout
     const int gx = tiles < kMaxStatBlocks ? tiles : kMaxStatBlocks;
     const dim3 grid(gx, cdiv(Nout, BN)), block(WM * WN * 64);
     if (nslab) *nslab = gx;
-    ProfScope ps(st, "gemm_kernel<%d,%d,%d,%d,A%d,E%d> M=%d N=%d K=%d", BM, BN, WM, WN, A.mode, E.mode, M, Nout, Kd);
+    ProfScope ps(st, "gemm_kernel<%d,%d,%d,%d,A%d,E%d> M=%d N=%d K=%d grid=%dx%d", BM, BN, WM, WN, A.mode, E.mode, M, Nout, Kd,
+                 grid.x, grid.y);
 #define PNPP_LAUNCH(AM, EM)                                                                                   \
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AM, EM>), grid, block, 0, st, A, B, M, Nout, Kd, E); \
     break;
@@ -1043,7 +1044,8 @@ int launch_gemm(const AOperand &A, const BOperand &Bin, int M, int Nout, int Kd,
         // split-K 32x32 tiles: the fully connected head (M = batch) and the group_all layers (M = B * 32)
         const dim3 grid(cdiv(Nout, 32), cdiv(M, 32));
         if (nslab) *nslab = grid.y;
-        ProfScope ps(st, "gemm_smallm_kernel<A%d,E%d,T%d> M=%d N=%d K=%d", A.mode, E.mode, B.trans, M, Nout, Kd);
+        ProfScope ps(st, "gemm_smallm_kernel<A%d,E%d,T%d> M=%d N=%d K=%d grid=%dx%d", A.mode, E.mode, B.trans, M, Nout, Kd, grid.x,
+                     grid.y);
         int rc = PNPP_OK;
         switch (A.mode) {
             case A_PLAIN: rc = launch_smallm_e<A_PLAIN>(A, B, M, Nout, Kd, E, grid, st); break;
@@ -1189,7 +1191,7 @@ int launch_dw(const AOperand &dz, int Nc, const AOperand &a2, int Kp, int M, flo
     rps = (rps + 7) & ~7;  // multiple of 8: a fetch batch (4 row pairs) never straddles two splits or two groups
     const int waves = tilesC * tilesK * nsplit;
     const dim3 grid(cdiv(waves, 4)), block(256);
-    ProfScope ps(st, "dw_kernel<A%d,A%d> M=%d N=%d K=%d split=%d", dz.mode, a2.mode, M, Nc, Kp, nsplit);
+    ProfScope ps(st, "dw_kernel<A%d,A%d> M=%d N=%d K=%d split=%d grid=%dx1", dz.mode, a2.mode, M, Nc, Kp, nsplit, grid.x);
 #define PNPP_DW(DM, AM)                                                                                              \
     hipLaunchKernelGGL((dw_kernel<DM, AM, 2, 2>), grid, block, 0, st, dz, a2, M, Nc, Kp, tilesC, tilesK, rps, kp_pad, slab); \
     break;

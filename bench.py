@@ -121,10 +121,16 @@ def roofline_leg(step, nsteps=5):
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
         roof.update(kernel=tag, avg_us=sec * 1e6, launches_per_step=cnt / nsteps, share_of_kernel_time=ms / total,
                     alg_flops=flops, alg_bytes=byts, traffic=None)
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from a separate --pmc pass
+        # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/summarize_rocprof.py), keyed by the
+        # kernel instantiation and its grid
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        key = re.sub(r" M=\d+ N=\d+ K=\d+( split=\d+)?", "", tag)
+        g = re.search(r"grid=(\d+)x(\d+)", key)
+        if g:
+            key = key[:g.start()] + f"grid={int(g.group(1)) * int(g.group(2))}"
         if os.path.exists(pmc):
             try:
-                roof["traffic"] = json.load(open(pmc)).get(tag)
+                roof["traffic"] = json.load(open(pmc)).get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 pass
         return roof, table
