@@ -497,8 +497,8 @@ __device__ __forceinline__ RawTail ws_fetch_tail(const AOperand &A, int row, int
 // Thread -> (column group kq = tid % G4, rows tid / G4 + i * RPP): every thread keeps ONE column group
 // for the whole kernel, so its per-channel constants live in registers, and with K_nbr == 32 the
 // pooled-gradient / arg-max entries of a tile's few neighbour groups are fetched once per tile.
-template <int KD, int BM, int BN, int WM, int WN, int AMODE, int EMODE>
-__global__ void __launch_bounds__(256, 2)
+template <int KD, int BM, int BN, int WM, int WN, int AMODE, int EMODE, bool FDW>
+__global__ void __launch_bounds__(256, (KD >= 256 ? 1 : 2))  // the K=256 panels leave room for one workgroup per CU anyway
 gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, const Epilogue E) {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
     constexpr bool HAS_TAIL = (AMODE == A_GATHER || AMODE == A_CONCAT);
@@ -506,13 +506,21 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     constexpr int G4 = KMAIN / 4;                  // column groups per row
     constexpr int RPP = G4 > 0 ? 256 / (G4 > 0 ? G4 : 1) : 1;  // rows staged per pass
     constexpr int NG = G4 > 0 ? BM / RPP : 0;      // passes per tile
-    constexpr int KP = KD + 1;                     // odd A pitch: conflict-free lane-per-row operand reads
+    // A tile addressing: element (r, k) lives at r*KP + (k ^ (r & 31)) when KD is a multiple of 32 (XOR swizzle, no
+    // padding: lane-per-row reads (fixed k) and lane-per-column reads (fixed r) are both conflict-free), else at
+    // r*(KD+1) + k (odd pitch)
+    constexpr bool SWZ = (KD % 32 == 0);
+    constexpr int KP = SWZ ? KD : KD + 1;
     constexpr int GPT = (BM + 31) / 32;            // neighbour groups per tile when nsample == 32
+    constexpr int DW_TILES = FDW ? (KD / 32) * (BN / 32) : 0, DT = FDW ? (DW_TILES + 3) / 4 : 1;
+    static_assert(!FDW || (EMODE == E_MASK_STATS && SWZ && DW_TILES % 4 == 0), "fused dW needs the ReLU-mask epilogue");
     static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "tile configuration");
     static_assert(G4 == 0 || (256 % G4 == 0 && BM % RPP == 0 && (32 % RPP == 0 || RPP % 32 == 0)), "staging map");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Ws = lds;            // [KD][BN]
     float *As = lds + KD * BN;  // [BM][KP]
+    float *Ap = As + BM * KP;   // FDW: [BM][BN] = relu(bn(zp)) tile, the dW GEMM's second operand
+    auto a_idx = [](int r, int k) { return r * KP + (SWZ ? (k ^ (r & 31)) : k); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -580,6 +588,12 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     double s1[NT], s2[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) s1[i] = s2[i] = 0.0;
+
+    f32x16 dwacc[DT];  // FDW: this wave's (32 x 32) tiles of dW, accumulated over every row tile of the worker
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dwacc[t][r] = 0.f;
 
     const int tiles = (M + BM - 1) / BM;
     const bool pool_fast = (AMODE == A_DZ_POOL) && A.K == 32;  // tiles start on neighbour-group boundaries (BM % 32 == 0)
@@ -667,17 +681,17 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                     v[3] = c_g.w * (dy.w - c_c1.w - (z.w - c_mu.w) * c_is.w * c_c2.w);
                 }
             }
-            float *d = As + r * KP + kq;
-            d[0] = v[0], d[1] = v[1], d[2] = v[2], d[3] = v[3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) As[a_idx(r, kq + e)] = v[e];
         }
         if constexpr (HAS_TAIL) {
             if (tid < BM) {
                 const bool ok = m0 + tid < M;
-                float *d = As + tid * KP + KMAIN;  // [x-cx, y-cy, z-cz, 0]: float32 subtraction, pointnet_pp_8dir.py:32
-                d[0] = ok ? __fsub_rn(rt.x0, rt.c0) : 0.f;
-                d[1] = ok ? __fsub_rn(rt.x1, rt.c1) : 0.f;
-                d[2] = ok ? __fsub_rn(rt.x2, rt.c2) : 0.f;
-                d[3] = 0.f;
+                // [x-cx, y-cy, z-cz, 0]: float32 subtraction, pointnet_pp_8dir.py:32
+                As[a_idx(tid, KMAIN + 0)] = ok ? __fsub_rn(rt.x0, rt.c0) : 0.f;
+                As[a_idx(tid, KMAIN + 1)] = ok ? __fsub_rn(rt.x1, rt.c1) : 0.f;
+                As[a_idx(tid, KMAIN + 2)] = ok ? __fsub_rn(rt.x2, rt.c2) : 0.f;
+                As[a_idx(tid, KMAIN + 3)] = 0.f;
             }
         }
         __syncthreads();
@@ -706,13 +720,12 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const float *ap = As + (wm * TM + l31) * KP + lh;
         const float *bp = Ws + lh * BN + wn * TN + l31;
 #pragma unroll 8
         for (int s = 0; s < KD / 2; ++s) {
             float a[MT], b[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = ap[i * 32 * KP + 2 * s];
+            for (int i = 0; i < MT; ++i) a[i] = As[a_idx(wm * TM + i * 32 + l31, 2 * s + lh)];
 #pragma unroll
             for (int j = 0; j < NT; ++j) b[j] = bp[2 * s * BN + j * 32];
 #pragma unroll
@@ -747,8 +760,37 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                         s2[j] += (double)v * (double)((z0 - mu) * is);
                     }
                     if (ok) E.c[(size_t)row * E.ldc + col] = v;
+                    if constexpr (FDW) {  // a_{l-1} = relu(bn(z_{l-1})), the operand dW_l is contracted with
+                        const int rl = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        Ap[rl * BN + wn * TN + j * 32 + l31] = fmaxf(fmaf(zp[i][j][r], sc, sh), 0.f);
+                    }
                 }
             }
+        if constexpr (FDW) {
+            __syncthreads();  // the whole relu(bn(zp)) tile is in LDS; the dZ tile still is
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const int tile_id = wave + 4 * t, ct = tile_id / (BN / 32), kt = tile_id % (BN / 32);
+#pragma unroll 8
+                for (int s = 0; s < BM / 2; ++s) {
+                    const int m = 2 * s + lh;
+                    dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[a_idx(m, ct * 32 + l31)], Ap[m * BN + kt * 32 + l31],
+                                                                     dwacc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    if constexpr (FDW) {  // one partial dW per worker: dwslab[worker][c][n0 + k]
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const int tile_id = wave + 4 * t, ct = tile_id / (BN / 32), kt = tile_id % (BN / 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, k = n0 + kt * 32 + l31;
+                if (k < Nout) E.dwslab[((size_t)worker * KD + c) * E.dw_ld + k] = dwacc[t][r];
+            }
+        }
     }
 
     if constexpr (EMODE != E_STORE) {
@@ -775,31 +817,50 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     }
 }
 
-template <int KD, int BM, int BN, int WM, int WN, int AM, int EM>
-static int launch_ws_one(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int *nslab, hipStream_t st) {
+template <int KD, int BM, int BN, int WM, int WN, int AM, int EM, bool FDW>
+static int launch_ws_one(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int *nslab, hipStream_t st,
+                         int *dw_slabs) {
     const int tiles = cdiv(M, BM), ncol = cdiv(Nout, BN);
-    int workers = 768 / ncol;  // up to three workgroups per CU (LDS and registers permitting)
+    size_t lds = ((size_t)KD * BN + (size_t)BM * (KD % 32 == 0 ? KD : KD + 1) + (FDW ? (size_t)BM * BN : 0)) * sizeof(float);
+    const size_t red_bytes = (size_t)WM * 2 * BN * sizeof(double);  // column-statistics reduction reuses the LDS
+    if (lds < red_bytes) lds = red_bytes;
+    // persistent workers: as many workgroups as the LDS lets the chip hold at once (dW slabs and statistic slabs are
+    // per worker, so fewer is cheaper), at most three per CU
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 3) per_cu = 3;
+    if (per_cu < 1) per_cu = 1;
+    int workers = (256 * per_cu) / ncol;
     if (workers > tiles) workers = tiles;
     if (workers > kMaxStatBlocks) workers = kMaxStatBlocks;
     if (workers < 1) workers = 1;
     if (nslab) *nslab = workers;
-    size_t lds = ((size_t)KD * BN + (size_t)BM * (KD + 1)) * sizeof(float);
-    const size_t red_bytes = (size_t)WM * 2 * BN * sizeof(double);  // column-statistics reduction reuses the LDS
-    if (lds < red_bytes) lds = red_bytes;
-    ProfScope ps(st, "gemm_ws_kernel<%d,%d,%d,A%d,E%d> M=%d N=%d K=%d grid=%dx1", KD, BM, BN, AM, EM, M, Nout, KD, workers * ncol);
-    auto kfn = gemm_ws_kernel<KD, BM, BN, WM, WN, AM, EM>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (dw_slabs) *dw_slabs = FDW ? workers : 0;
+    ProfScope ps(st, "gemm_ws_kernel<%d,%d,%d,A%d,E%d%s> M=%d N=%d K=%d grid=%dx1", KD, BM, BN, AM, EM, FDW ? ",dW" : "", M, Nout,
+                 KD, workers * ncol);
+    auto kfn = gemm_ws_kernel<KD, BM, BN, WM, WN, AM, EM, FDW>;
+    static size_t lds_granted = 0;  // per instantiation; the attribute call is a host-side setting, made once per size
+    if (lds > 48 * 1024 && lds > lds_granted) {
+        (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_granted = lds;
+    }
     hipLaunchKernelGGL(kfn, dim3(workers * ncol), dim3(256), lds, st, A, B, M, Nout, ncol, E);
     PNPP_CHECK_LAUNCH("gemm_ws");
     return PNPP_OK;
 }
 
 template <int KD, int BM, int BN, int WM, int WN, int AM>
-static int launch_ws_e(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int *nslab, hipStream_t st) {
+static int launch_ws_e(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int *nslab, hipStream_t st,
+                       int *dw_slabs = nullptr) {
+    if (dw_slabs) *dw_slabs = 0;
     switch (E.mode) {
-        case E_STORE: return launch_ws_one<KD, BM, BN, WM, WN, AM, E_STORE>(A, B, M, Nout, E, nslab, st);
-        case E_STORE_STATS: return launch_ws_one<KD, BM, BN, WM, WN, AM, E_STORE_STATS>(A, B, M, Nout, E, nslab, st);
-        case E_MASK_STATS: return launch_ws_one<KD, BM, BN, WM, WN, AM, E_MASK_STATS>(A, B, M, Nout, E, nslab, st);
+        case E_STORE: return launch_ws_one<KD, BM, BN, WM, WN, AM, E_STORE, false>(A, B, M, Nout, E, nslab, st, nullptr);
+        case E_STORE_STATS: return launch_ws_one<KD, BM, BN, WM, WN, AM, E_STORE_STATS, false>(A, B, M, Nout, E, nslab, st, nullptr);
+        case E_MASK_STATS:
+            if constexpr ((AM == A_DZ || AM == A_DZ_POOL) && KD % 32 == 0 && ((KD / 32) * (BN / 32)) % 4 == 0) {
+                if (E.dwslab && dw_slabs)
+                    return launch_ws_one<KD, BM, BN, WM, WN, AM, E_MASK_STATS, true>(A, B, M, Nout, E, nslab, st, dw_slabs);
+            }
+            return launch_ws_one<KD, BM, BN, WM, WN, AM, E_MASK_STATS, false>(A, B, M, Nout, E, nslab, st, nullptr);
     }
     set_error("gemm_ws: bad epilogue mode %d", E.mode);
     return PNPP_ERR_ARG;
@@ -807,12 +868,13 @@ static int launch_ws_e(const AOperand &A, const BOperand &B, int M, int Nout, co
 
 // dense (non-grouped) operands: K in {64, 128, 256}
 template <int KD, int BM, int BN, int WM, int WN>
-static int launch_ws_dense(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int *nslab, hipStream_t st) {
+static int launch_ws_dense(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int *nslab, hipStream_t st,
+                           int *dw_slabs) {
     switch (A.mode) {
         case A_PLAIN: return launch_ws_e<KD, BM, BN, WM, WN, A_PLAIN>(A, B, M, Nout, E, nslab, st);
         case A_BNRELU: return launch_ws_e<KD, BM, BN, WM, WN, A_BNRELU>(A, B, M, Nout, E, nslab, st);
-        case A_DZ: return launch_ws_e<KD, BM, BN, WM, WN, A_DZ>(A, B, M, Nout, E, nslab, st);
-        case A_DZ_POOL: return launch_ws_e<KD, BM, BN, WM, WN, A_DZ_POOL>(A, B, M, Nout, E, nslab, st);
+        case A_DZ: return launch_ws_e<KD, BM, BN, WM, WN, A_DZ>(A, B, M, Nout, E, nslab, st, dw_slabs);
+        case A_DZ_POOL: return launch_ws_e<KD, BM, BN, WM, WN, A_DZ_POOL>(A, B, M, Nout, E, nslab, st, dw_slabs);
     }
     set_error("gemm_ws: bad A mode %d", A.mode);
     return PNPP_ERR_ARG;
@@ -821,7 +883,7 @@ static int launch_ws_dense(const AOperand &A, const BOperand &B, int M, int Nout
 // picks a weights-stationary configuration, or returns false when the shape does not qualify (the chunked kernel
 // then handles it): the reference models' grouped layers all qualify
 static bool try_launch_ws(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab,
-                          hipStream_t st, int *rc) {
+                          hipStream_t st, int *rc, int *dw_slabs) {
     if (M < 8192 || Nout % 64 != 0) return false;
     const bool grouped = A.mode == A_GATHER || A.mode == A_CONCAT;
     if (grouped) {
@@ -840,16 +902,16 @@ static bool try_launch_ws(const AOperand &A, const BOperand &B, int M, int Nout,
     }
     if (A.lda % 4 != 0 || ((uintptr_t)A.a & 15) != 0) return false;
     if (Kd == 64) {
-        if (Nout % 128 == 0) *rc = launch_ws_dense<64, 128, 128, 4, 1>(A, B, M, Nout, E, nslab, st);
-        else *rc = launch_ws_dense<64, 128, 64, 4, 1>(A, B, M, Nout, E, nslab, st);
+        if (Nout % 128 == 0) *rc = launch_ws_dense<64, 128, 128, 4, 1>(A, B, M, Nout, E, nslab, st, dw_slabs);
+        else *rc = launch_ws_dense<64, 128, 64, 4, 1>(A, B, M, Nout, E, nslab, st, dw_slabs);
         return true;
     }
     if (Kd == 128) {
-        *rc = launch_ws_dense<128, 64, 64, 2, 2>(A, B, M, Nout, E, nslab, st);
+        *rc = launch_ws_dense<128, 64, 64, 2, 2>(A, B, M, Nout, E, nslab, st, dw_slabs);
         return true;
     }
     if (Kd == 256) {
-        *rc = launch_ws_dense<256, 64, 64, 2, 2>(A, B, M, Nout, E, nslab, st);
+        *rc = launch_ws_dense<256, 64, 64, 2, 2>(A, B, M, Nout, E, nslab, st, dw_slabs);
         return true;
     }
     return false;
@@ -1028,7 +1090,8 @@ static int launch_gemm_cfg(const AOperand &A, const BOperand &B, int M, int Nout
 }
 
 int launch_gemm(const AOperand &A, const BOperand &Bin, int M, int Nout, int Kd, const Epilogue &E, int *nslab,
-                hipStream_t st) {
+                hipStream_t st, int *dw_slabs) {
+    if (dw_slabs) *dw_slabs = 0;
     PNPP_REQUIRE(M > 0 && Nout > 0 && Kd > 0, PNPP_ERR_ARG, "gemm: non-positive size M=%d N=%d K=%d", M, Nout, Kd);
     PNPP_REQUIRE(Bin.b && Bin.ldb > 0, PNPP_ERR_ARG, "gemm: null B operand");
     PNPP_REQUIRE(Kd % 4 == 0, PNPP_ERR_ARG, "gemm: K=%d must be a multiple of 4", Kd);
@@ -1036,7 +1099,7 @@ int launch_gemm(const AOperand &A, const BOperand &Bin, int M, int Nout, int Kd,
     if (B.rows <= 0 || B.rows > Kd) B.rows = Kd;
     {
         int rc = PNPP_OK;
-        if (try_launch_ws(A, B, M, Nout, Kd, E, nslab, st, &rc)) return rc;
+        if (try_launch_ws(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;
     }
     const bool b_aligned = (B.ldb % 4 == 0) && (((uintptr_t)B.b & 15) == 0) && B.perm_D < 0;
     const bool a_aligned = (A.mode == A_CONCAT || A.mode == A_GATHER) || (A.lda % 4 == 0 && ((uintptr_t)A.a & 15) == 0);

@@ -324,9 +324,14 @@ __device__ __forceinline__ unsigned philox_key(unsigned c0, unsigned c1, unsigne
 }
 
 __global__ void __launch_bounds__(256) sample_random_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_lo,
-                                                            unsigned str_hi, int N, int npoint, int32_t *__restrict__ out) {
+                                                            unsigned str_hi, const unsigned long long *__restrict__ str_dev,
+                                                            int N, int npoint, int32_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned keys[];
     const int b = blockIdx.y;
+    if (str_dev) {  // stream id lives in device memory (graph replays draw fresh centres): *str_dev + (str_hi:str_lo)
+        const unsigned long long sid = *str_dev + (((unsigned long long)str_hi << 32) | str_lo);
+        str_lo = (unsigned)sid, str_hi = (unsigned)(sid >> 32);
+    }
     for (int n = threadIdx.x; n < N; n += 256) keys[n] = philox_key((unsigned)n, (unsigned)b, str_lo, str_hi, seed_lo, seed_hi);
     __syncthreads();
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -490,7 +495,21 @@ extern "C" int pnpp_ball_query(const float *new_xyz, const float *xyz, int B, in
     return PNPP_OK;
 }
 
+static int sample_random_impl(uint64_t seed, uint64_t stream_id, const uint64_t *stream_id_dev, int B, int N, int npoint,
+                              int32_t *out, void *stream);
+
 extern "C" int pnpp_sample_random(uint64_t seed, uint64_t stream_id, int B, int N, int npoint, int32_t *out, void *stream) {
+    return sample_random_impl(seed, stream_id, nullptr, B, N, npoint, out, stream);
+}
+
+extern "C" int pnpp_sample_random_dev(uint64_t seed, const uint64_t *stream_id_dev, uint64_t offset, int B, int N, int npoint,
+                                      int32_t *out, void *stream) {
+    PNPP_REQUIRE(stream_id_dev, PNPP_ERR_ARG, "sample_random_dev: null counter pointer");
+    return sample_random_impl(seed, offset, stream_id_dev, B, N, npoint, out, stream);
+}
+
+static int sample_random_impl(uint64_t seed, uint64_t stream_id, const uint64_t *stream_id_dev, int B, int N, int npoint,
+                              int32_t *out, void *stream) {
     PNPP_REQUIRE(out, PNPP_ERR_ARG, "sample_random: null pointer");
     PNPP_REQUIRE(B > 0 && N > 0 && npoint > 0, PNPP_ERR_ARG, "sample_random: non-positive size");
     PNPP_REQUIRE(npoint <= N, PNPP_ERR_RANGE, "sample_random: npoint=%d > N=%d", npoint, N);
@@ -500,7 +519,8 @@ extern "C" int pnpp_sample_random(uint64_t seed, uint64_t stream_id, int B, int 
     if (lds > 48 * 1024)
         hipFuncSetAttribute((const void *)sample_random_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(sample_random_kernel, dim3(cdiv(N, 256), B), dim3(256), lds, as_stream(stream), (unsigned)seed,
-                       (unsigned)(seed >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32), N, npoint, out);
+                       (unsigned)(seed >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32),
+                       reinterpret_cast<const unsigned long long *>(stream_id_dev), N, npoint, out);
     PNPP_CHECK_LAUNCH("sample_random");
     return PNPP_OK;
 }

@@ -49,6 +49,10 @@ struct Epilogue {
     double *slab = nullptr;  // [gridDim.x][2][Nout]
     const float *zp = nullptr;  // MASK_STATS: previous layer's pre-BN activations, pitch ldc
     const float *scale = nullptr, *shift = nullptr, *mu = nullptr, *istd = nullptr;
+    // MASK_STATS, optional: fuse dW = dZ^T * relu(bn(zp)) into the same launch (the dZ tile is already in LDS);
+    // partial sums go to dwslab[worker][Kd][dw_ld] and are combined by launch_slab_reduce
+    float *dwslab = nullptr;
+    int dw_ld = 0;
 };
 
 // The B operand (weights) is read in place from its state_dict layout -- no transposed copies are made.
@@ -63,8 +67,9 @@ struct BOperand {
 
 // C[M x Nout] = A'[M x Kd] * B[Kd x Nout].  Returns the number of statistic slabs written (gridDim.x)
 // through *nslab when the epilogue collects statistics.
+// *dw_slabs (optional) receives the number of dW partial slabs written when E.dwslab was honoured, else 0.
 int launch_gemm(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab,
-                hipStream_t st);
+                hipStream_t st, int *dw_slabs = nullptr);
 
 // dW[Nc x Kp] = dZ^T[Nc x M] * A2[M x Kp], split over `nsplit` row ranges into slab[nsplit][Nc][kp_pad].
 // dz is produced as in A_DZ (or read directly when dz.mode == A_PLAIN); A2 by its own AOperand.

@@ -242,7 +242,7 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
     const SaScratch sc = sa_scratch_layout(d, g, a->scratch);
 
     const int Lm = d->L - 1;
-    int cur = 0, nslab = 0;
+    int cur = 0, nslab = 0, nslab_next = 0;
     PNPP_TRY(launch_pool_bwd(a->dout, sv.arg, sv.z[Lm], sv.scale[Lm], sv.shift[Lm], sv.mean[Lm], sv.istd[Lm], g.G, d->K,
                              d->C[Lm], sc.dm, sc.slab, &nslab, st));
     for (int l = Lm; l >= 0; --l) {
@@ -269,14 +269,12 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             a2.scale = sv.scale[l - 1];
             a2.shift = sv.shift[l - 1];
         }
-        // dW_l = dZ_l^T * A_l
         int nsplit, kp_pad;
         dw_plan(g.M, C, g.Cin[l], &nsplit, &kp_pad);
-        PNPP_TRY(launch_dw(dz, C, a2, g.Cin[l], g.M, sc.dwslab, nsplit, kp_pad, st));
-        PNPP_TRY(launch_slab_reduce(sc.dwslab, nsplit, C, kp_pad, g.Cin[l], l == 0 ? d->D : -1, a->d_conv_w[l], g.Cin[l], st));
-
+        bool dw_done = false;
         if (l > 0) {
-            // dY_{l-1} = (dZ_l * W_l) masked by ReLU'(layer l-1), with layer l-1's BN-backward sums
+            // dY_{l-1} = (dZ_l * W_l) masked by ReLU'(layer l-1), with layer l-1's BN-backward sums; where the
+            // weights-stationary kernel applies, dW_l = dZ_l^T * relu(bn(Z_{l-1})) is accumulated in the same launch
             Epilogue E;
             E.mode = E_MASK_STATS;
             E.c = sc.dy[cur ^ 1];
@@ -287,11 +285,26 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             E.shift = sv.shift[l - 1];
             E.mu = sv.mean[l - 1];
             E.istd = sv.istd[l - 1];
-            BOperand W;  // dY_{l-1} = dZ_l * W_l with W_l (C_l x C_{l-1}) row-major as stored
+            E.dwslab = sc.dwslab;
+            E.dw_ld = d->C[l - 1];
+            BOperand W;  // W_l (C_l x C_{l-1}) row-major as stored
             W.b = a->conv_w[l];
             W.ldb = d->C[l - 1];
             W.rows = C;
-            PNPP_TRY(launch_gemm(dz, W, g.M, d->C[l - 1], C, E, &nslab, st));
+            int dw_slabs = 0;
+            PNPP_TRY(launch_gemm(dz, W, g.M, d->C[l - 1], C, E, &nslab_next, st, &dw_slabs));
+            if (dw_slabs > 0) {
+                PNPP_TRY(launch_slab_reduce(sc.dwslab, dw_slabs, C, d->C[l - 1], d->C[l - 1], -1, a->d_conv_w[l], d->C[l - 1], st));
+                dw_done = true;
+            }
+        }
+        if (!dw_done) {  // dW_l = dZ_l^T * A_l as its own launch (layer 0, group_all layers, odd shapes)
+            PNPP_TRY(launch_dw(dz, C, a2, g.Cin[l], g.M, sc.dwslab, nsplit, kp_pad, st));
+            PNPP_TRY(launch_slab_reduce(sc.dwslab, nsplit, C, kp_pad, g.Cin[l], l == 0 ? d->D : -1, a->d_conv_w[l], g.Cin[l], st));
+        }
+
+        if (l > 0) {
+            nslab = nslab_next;
             cur ^= 1;
         } else if (want_dpoints) {
             Epilogue E;

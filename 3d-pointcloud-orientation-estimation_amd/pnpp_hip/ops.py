@@ -109,6 +109,14 @@ def sample_random(seed: int, stream_id: int, B: int, N: int, npoint: int, device
     return out
 
 
+def sample_random_dev(seed: int, counter: torch.Tensor, offset: int, B: int, N: int, npoint: int) -> torch.Tensor:
+    """Like sample_random, with the stream id read from the int64 device tensor `counter` at kernel time."""
+    out = torch.empty(B, npoint, device=counter.device, dtype=torch.int32)
+    L.check(L.lib().pnpp_sample_random_dev(int(seed) & (2**64 - 1), counter.data_ptr(), int(offset) & (2**64 - 1), B, N,
+                                           int(npoint), out.data_ptr(), _stream()))
+    return out
+
+
 class _IndexPoints(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points, idx):

@@ -1,13 +1,14 @@
 """Device-side centre sampling (throughput mode of models/pointnet_pp_8dir.py:28).
 
-`torch.manual_seed(s)` still controls the draw: the kernel's Philox key is the CPU generator's
-initial seed, its counter carries (rank, call number), so every call -- and every rank under data
-parallelism -- gets an independent, reproducible stream without touching the host generator."""
+`torch.manual_seed(s)` still controls the draw: the kernel's Philox key is the CPU generator's initial seed, its
+counter is (rank << 40) + a call counter.  The call counter lives in DEVICE memory and is bumped by a device-side
+add before every draw, so a step captured into a hipGraph draws fresh, reproducible centres on every replay and
+every rank under data parallelism gets an independent stream -- all without touching the host generator."""
 import torch
 
 from . import ops
 
-_state = {"calls": 0, "rank": 0}
+_state = {"rank": 0, "counters": {}}
 
 
 def set_rank(rank: int) -> None:
@@ -15,10 +16,21 @@ def set_rank(rank: int) -> None:
 
 
 def reset(calls: int = 0) -> None:
-    _state["calls"] = int(calls)
+    for c in _state["counters"].values():
+        c.fill_(int(calls))
+
+
+def _counter(device) -> torch.Tensor:
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    c = _state["counters"].get(key)
+    if c is None:
+        c = torch.zeros(1, dtype=torch.int64, device=device)
+        _state["counters"][key] = c
+    return c
 
 
 def device_random_centres(B: int, N: int, npoint: int, device) -> torch.Tensor:
-    _state["calls"] += 1
-    stream_id = (_state["rank"] << 40) | _state["calls"]
-    return ops.sample_random(torch.initial_seed(), stream_id, B, N, npoint, device)
+    c = _counter(device)
+    c.add_(1)                                   # device-side: captured into graphs like any other launch
+    return ops.sample_random_dev(torch.initial_seed(), c, _state["rank"] << 40, B, N, npoint)

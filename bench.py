@@ -35,19 +35,36 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32x32x2_f32)
 
 
-def build_step(model, opt, xyz, mu_gt, kappa_gt, world):
+def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph):
+    """Returns (step, launch_mode).  zero_grad + forward + loss + backward are replayed from one hipGraph when
+    capture succeeds (falls back to eager launches otherwise); the all-reduce and the fused Adam follow eagerly."""
     from pnpp_hip import ops, dist as pdist
 
+    def loss_fn(x, m, k):
+        mu, kappa = model(x)
+        return ops.kl_von_mises_single(mu, kappa, m, k).mean()
+
+    graphed = None
+    if use_graph:
+        try:
+            from pnpp_hip.graph import GraphedStep
+            graphed = GraphedStep(opt, loss_fn, [xyz, mu_gt, kappa_gt])
+        except Exception as e:  # capture is an optimisation, never a requirement
+            print(f"[bench] hipGraph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr)
+            graphed = None
+
     def step():
-        opt.zero_grad()
-        mu, kappa = model(xyz)
-        loss = ops.kl_von_mises_single(mu, kappa, mu_gt, kappa_gt).mean()
-        loss.backward()
+        if graphed is not None:
+            loss = graphed(xyz, mu_gt, kappa_gt)
+        else:
+            opt.zero_grad()
+            loss = loss_fn(xyz, mu_gt, kappa_gt)
+            loss.backward()
         pdist.all_reduce_flat_grad(opt.flat_g)
         opt.step(grad_scale=1.0 / world)
         return loss
 
-    return step
+    return step, ("hipGraph(zero_grad+fwd+loss+bwd) + eager all-reduce/Adam" if graphed is not None else "eager")
 
 
 def kernel_cost(tag: str):
@@ -180,6 +197,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU (config 2: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -203,7 +221,8 @@ def main():
     B = args.batch
     xyz, mu_gt, kappa_gt, _ = synthetic.rotated_clouds(B, N_POINTS, seed=1234 + rank)
     xyz, mu_gt, kappa_gt = xyz.to(dev), mu_gt.to(dev), kappa_gt.to(dev)
-    step = build_step(model, opt, xyz, mu_gt, kappa_gt, world)
+    step, launch_mode = build_step(model, opt, xyz, mu_gt, kappa_gt, world, not args.no_graph)
+    eager_step, _ = build_step(model, opt, xyz, mu_gt, kappa_gt, world, False) if launch_mode != "eager" else (step, None)
 
     for _ in range(args.warmup):
         step()
@@ -227,7 +246,7 @@ def main():
 
     roof, table = (None, [])
     if not args.no_roofline and rank == 0:
-        roof, table = roofline_leg(step)
+        roof, table = roofline_leg(eager_step)     # per-launch events need individual launches, not a graph replay
     cpu = None
     if world > 1:
         tdist.barrier()
@@ -242,7 +261,7 @@ def main():
             "config": {"workload": "configs[1]: models/pointnet_pp_vonMises.py single-peak KL, N=1024, batch=32 per GPU, "
                                    "fwd+loss+bwd+allreduce+Adam, random-init weights (seed 42), device-side centre sampling",
                        "per_gpu_batch": B, "global_batch": B * world, "points": N_POINTS,
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
+                       "parallelism": f"dp{world}" if world > 1 else "single", "launch": launch_mode},
             "final_loss": final_loss, "roofline": roof, "cpu_baseline": cpu, "top_kernels": table,
         }
         print(json.dumps(out))

@@ -75,6 +75,11 @@ int pnpp_ball_query(const float *new_xyz, const float *xyz, int B, int S, int N,
  * calls (throughput mode; parity mode replays the CPU generator on the host and passes the indices in).
  * Counter-based: the result is a pure function of (seed, stream_id, b).  out (B,npoint) int32. */
 int pnpp_sample_random(uint64_t seed, uint64_t stream_id, int B, int N, int npoint, int32_t *out, void *stream);
+/* Same, with the stream id read from DEVICE memory at kernel time (stream_id = *stream_id_dev + offset): the launch
+ * can be captured into a hipGraph and still draw fresh centres on every replay (the host bumps the counter with a
+ * captured device-side add). */
+int pnpp_sample_random_dev(uint64_t seed, const uint64_t *stream_id_dev, uint64_t offset, int B, int N, int npoint,
+                           int32_t *out, void *stream);
 
 /* models/base.py:4-18  index_points(points (B,N,C), idx (B,M)) -> out (B,M,C); idx is int32, flattened
  * over its trailing dims.  _bwd accumulates dpoints (B,N,C) += scatter(dout) deterministically

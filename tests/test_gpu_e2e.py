@@ -247,3 +247,47 @@ def test_flat_adam_matches_torch_adam(oracle):
                 assert float((a - b).abs().max()) <= 2.5e-3, (it, n)   # never more than the two +-lr steps apart
     for a, b in zip(m1.buffers(), m2.buffers()):
         assert torch.allclose(a.double(), b.double(), rtol=1e-5, atol=1e-6)
+
+
+def test_hipgraph_step_equals_eager(oracle):
+    """zero_grad + forward + loss + backward captured into one hipGraph: replays reproduce the eager launches
+    bit for bit, and because the sampler's counter lives in device memory every replay draws fresh centres."""
+    import copy
+    from models.pointnet_pp_vonMises import PointNetPPVonMises
+    from models.pointnet_pp_8dir import PointNetSetAbstraction
+    from pnpp_hip import ops, optim, sampling
+    from pnpp_hip.graph import GraphedStep
+    old = PointNetSetAbstraction.sampler
+    PointNetSetAbstraction.sampler = "device"
+    try:
+        torch.manual_seed(42)
+        m1 = PointNetPPVonMises().cuda().train()
+        m1.drop.p = 0.0                                    # dropout draws differ between capture and eager streams
+        m2 = copy.deepcopy(m1)
+        o1, o2 = optim.FlatAdam(m1.parameters()), optim.FlatAdam(m2.parameters())
+        xyz, mu_gt, kappa_gt, _ = oracle.synthetic_clouds(8, 1024, seed=3)
+        xyz, mu_gt, kappa_gt = xyz.cuda(), mu_gt.cuda(), kappa_gt.cuda()
+
+        def loss_fn(model):
+            return lambda x, m, k: ops.kl_von_mises_single(*model(x), m, k).mean()
+
+        g = GraphedStep(o1, loss_fn(m1), [xyz, mu_gt, kappa_gt])
+        for p, q in zip(m1.buffers(), m2.buffers()):       # warm-up / capture advanced m1's running statistics
+            p.copy_(q)
+        losses = []
+        for it in range(3):
+            sampling.reset(100 * it)
+            l1 = float(g(xyz, mu_gt, kappa_gt))
+            sampling.reset(100 * it)
+            o2.zero_grad()
+            l2 = loss_fn(m2)(xyz, mu_gt, kappa_gt)
+            l2.backward()
+            assert l1 == float(l2), (it, l1, float(l2))
+            assert torch.equal(o1.flat_g, o2.flat_g)
+            losses.append(l1)
+        assert len(set(losses)) == 3                       # different counters -> different centres -> different losses
+        a = float(g(xyz, mu_gt, kappa_gt))
+        b = float(g(xyz, mu_gt, kappa_gt))
+        assert a != b                                      # consecutive replays keep drawing
+    finally:
+        PointNetSetAbstraction.sampler = old
