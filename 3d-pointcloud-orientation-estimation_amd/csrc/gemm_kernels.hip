@@ -506,9 +506,11 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     constexpr int G4 = KMAIN / 4;                  // column groups per row
     constexpr int RPP = G4 > 0 ? 256 / (G4 > 0 ? G4 : 1) : 1;  // rows staged per pass
     constexpr int NG = G4 > 0 ? BM / RPP : 0;      // passes per tile
-    // A tile addressing: element (r, k) lives at r*KP + (k ^ (r & 31)) when KD is a multiple of 32 (XOR swizzle, no
-    // padding: lane-per-row reads (fixed k) and lane-per-column reads (fixed r) are both conflict-free), else at
-    // r*(KD+1) + k (odd pitch)
+    // A tile addressing: element (r, k) lives at r*KP + (k ^ f(r)), f(r) = ((r & 7) << 2) | ((r >> 3) & 3), when KD is a
+    // multiple of 32 (XOR swizzle, no padding).  f is a bijection of r mod 32 onto 0..31, so lane-per-row reads (fixed
+    // k, the dA operand) and lane-per-column reads (fixed r, the dW operand) are both conflict-free; its upper bits
+    // move whole 16-byte groups and its low two bits only permute inside a group, so a staged float4 is still ONE
+    // ds_write_b128 (of the permuted register quad).  Otherwise (KD = D + 4) element (r, k) is at r*(KD+1) + k.
     constexpr bool SWZ = (KD % 32 == 0);
     constexpr int KP = SWZ ? KD : KD + 1;
     constexpr int GPT = (BM + 31) / 32;            // neighbour groups per tile when nsample == 32
@@ -520,7 +522,8 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     float *Ws = lds;            // [KD][BN]
     float *As = lds + KD * BN;  // [BM][KP]
     float *Ap = As + BM * KP;   // FDW: [BM][BN] = relu(bn(zp)) tile, the dW GEMM's second operand
-    auto a_idx = [](int r, int k) { return r * KP + (SWZ ? (k ^ (r & 31)) : k); };
+    auto a_swz = [](int r) { return ((r & 7) << 2) | ((r >> 3) & 3); };
+    auto a_idx = [&](int r, int k) { return r * KP + (SWZ ? (k ^ a_swz(r)) : k); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -681,8 +684,21 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                     v[3] = c_g.w * (dy.w - c_c1.w - (z.w - c_mu.w) * c_is.w * c_c2.w);
                 }
             }
+            if constexpr (SWZ) {
+                const int f = a_swz(r);
+                if (f & 1) {
+                    float t = v[0]; v[0] = v[1]; v[1] = t;
+                    t = v[2]; v[2] = v[3]; v[3] = t;
+                }
+                if (f & 2) {
+                    float t = v[0]; v[0] = v[2]; v[2] = t;
+                    t = v[1]; v[1] = v[3]; v[3] = t;
+                }
+                *reinterpret_cast<float4 *>(As + r * KP + (kq ^ (f & ~3))) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) As[a_idx(r, kq + e)] = v[e];
+                for (int e = 0; e < 4; ++e) As[a_idx(r, kq + e)] = v[e];
+            }
         }
         if constexpr (HAS_TAIL) {
             if (tid < BM) {
@@ -927,12 +943,13 @@ static bool try_launch_ws(const AOperand &A, const BOperand &B, int M, int Nout,
 template <int AMODE, int EMODE, bool BT>
 __global__ void __launch_bounds__(256)
 gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, const Epilogue E) {
-    // per wave: A chunk [32][33], (BT only) weight chunk [32 n][33]; then the K-split partials [4][32][32]
-    __shared__ __attribute__((aligned(16))) float lds[8 * 32 * APITCH + 4 * 32 * 32];
+    // per wave: A chunk [32][33] and weight chunk [32 n][33] (BT only); after the K loop the first 4 x 1024 floats
+    // are reused for the K-split partials [4][32][32] (a wave's partial overwrites only its own A chunk)
+    __shared__ __attribute__((aligned(16))) float lds[8 * 32 * APITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     float *As = lds + wave * 32 * APITCH;
     float *Ws = lds + (4 + wave) * 32 * APITCH;
-    float *part = lds + 8 * 32 * APITCH;  // [4][32][32]
+    float *part = lds;  // [4][32][32], wave w at part + w * 1056: inside its own A chunk region (32*33 = 1056 floats)
     const float *__restrict__ Bm = B.b;
     const int ldb = B.ldb;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
@@ -995,13 +1012,13 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
     }
     // K-split reduction in fixed wave order, then the epilogue on the summed tile
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + l31] = acc[r];
+    for (int r = 0; r < 16; ++r) part[wave * 32 * APITCH + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + l31] = acc[r];
     __syncthreads();
     float v[4], w2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int e = tid + 256 * j;
-        v[j] = (part[e] + part[1024 + e]) + (part[2048 + e] + part[3072 + e]);
+        v[j] = (part[e] + part[32 * APITCH + e]) + (part[2 * 32 * APITCH + e] + part[3 * 32 * APITCH + e]);
         w2[j] = 0.f;
     }
     __syncthreads();
@@ -1136,6 +1153,33 @@ int launch_gemm(const AOperand &A, const BOperand &Bin, int M, int Nout, int Kd,
     }
     if (Nout % 128 == 0) return launch_gemm_cfg<32, 128, 1, 4>(A, B, M, Nout, Kd, E, nslab, st);
     return launch_gemm_cfg<128, 32, 4, 1>(A, B, M, Nout, Kd, E, nslab, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// small-M layers (group_all: M = 32 * B): the BatchNorm-backward operand dZ is materialised once (a few MB)
+// instead of being rebuilt by every 32 x 32 output tile of the dA and dW GEMMs that consume it
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256) dz_materialize_kernel(const AOperand A, int M, int C, float *__restrict__ out) {
+    const size_t total = (size_t)M * (C / 4);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int row = (int)(i / (C / 4)), k = 4 * (int)(i % (C / 4));
+        const RawA r = fetch_a4<MODE>(A, row, k, M, C);
+        float v[4];
+        xform_a4<MODE>(A, r, row, k, M, C, v);
+        *reinterpret_cast<float4 *>(out + (size_t)row * C + k) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+int launch_dz_materialize(const AOperand &dz, int M, int C, float *out, hipStream_t st) {
+    PNPP_REQUIRE(C % 4 == 0 && (dz.mode == A_DZ || dz.mode == A_DZ_POOL), PNPP_ERR_ARG, "dz_materialize: bad operand");
+    const size_t total = (size_t)M * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    ProfScope ps(st, "dz_materialize_kernel M=%d C=%d", M, C);
+    if (dz.mode == A_DZ) hipLaunchKernelGGL(dz_materialize_kernel<A_DZ>, dim3(grid), dim3(256), 0, st, dz, M, C, out);
+    else hipLaunchKernelGGL(dz_materialize_kernel<A_DZ_POOL>, dim3(grid), dim3(256), 0, st, dz, M, C, out);
+    PNPP_CHECK_LAUNCH("dz_materialize");
+    return PNPP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1279,14 +1323,17 @@ int launch_dw(const AOperand &dz, int Nc, const AOperand &a2, int Kp, int M, flo
     return PNPP_OK;
 }
 
-// out[c][perm(k)] = sum_s slab[s][c][k], fixed summation order: block = 64 outputs x 4 split lanes,
-// every lane strides the splits by 4 with four independent partial sums, the 4 lanes are combined in order
+// out[c][perm(k)] = sum_s slab[s][c][k], fixed summation order: block = EPB outputs x (256/EPB) split lanes,
+// every lane strides the splits with four independent partial sums, the lanes are combined in lane order.
+// Small outputs (a 64 x 3 weight) take 16 outputs per block so that the splits, not the outputs, fill the chip.
+template <int EPB>
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float *__restrict__ slab, int nsplit, int Nc, int kp_pad,
                                                           int Kvalid, int perm_D, float *__restrict__ out, int ldo) {
-    __shared__ float red[4][64];
+    constexpr int SL = 256 / EPB;
+    __shared__ float red[SL][EPB];
     const int total = Nc * Kvalid;
-    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + e;
+    const int e = threadIdx.x % EPB, sl = threadIdx.x / EPB;
+    const int i = blockIdx.x * EPB + e;
     float acc = 0.f;
     int c = 0, k = 0;
     if (i < total) {
@@ -1295,21 +1342,24 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float *__restric
         const size_t stride = (size_t)Nc * kp_pad;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int s = sl;
-        for (; s + 12 < nsplit; s += 16) {
+        for (; s + 3 * SL < nsplit; s += 4 * SL) {
             a0 += p[(size_t)s * stride];
-            a1 += p[(size_t)(s + 4) * stride];
-            a2 += p[(size_t)(s + 8) * stride];
-            a3 += p[(size_t)(s + 12) * stride];
+            a1 += p[(size_t)(s + SL) * stride];
+            a2 += p[(size_t)(s + 2 * SL) * stride];
+            a3 += p[(size_t)(s + 3 * SL) * stride];
         }
-        for (; s < nsplit; s += 4) a0 += p[(size_t)s * stride];
+        for (; s < nsplit; s += SL) a0 += p[(size_t)s * stride];
         acc = (a0 + a1) + (a2 + a3);
     }
     red[sl][e] = acc;
     __syncthreads();
     if (sl == 0 && i < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < SL; ++j) t += red[j][e];
         int ko = k;
         if (perm_D >= 0) ko = k < perm_D ? k + 3 : k - perm_D;  // features-first -> xyz-first (state_dict order)
-        out[(size_t)c * ldo + ko] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        out[(size_t)c * ldo + ko] = t;
     }
 }
 
@@ -1317,8 +1367,12 @@ int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kv
                        hipStream_t st) {
     const int total = Nc * Kvalid;
     ProfScope ps(st, "slab_reduce_kernel N=%d K=%d split=%d", Nc, Kvalid, nsplit);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, slab, nsplit, Nc, kp_pad, Kvalid, perm_D, out,
-                       ldo);
+    if (total >= 16384 || nsplit <= 8)
+        hipLaunchKernelGGL(slab_reduce_kernel<64>, dim3(cdiv(total, 64)), dim3(256), 0, st, slab, nsplit, Nc, kp_pad, Kvalid, perm_D,
+                           out, ldo);
+    else
+        hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3(cdiv(total, 16)), dim3(256), 0, st, slab, nsplit, Nc, kp_pad, Kvalid, perm_D,
+                           out, ldo);
     PNPP_CHECK_LAUNCH("slab_reduce");
     return PNPP_OK;
 }
@@ -1482,7 +1536,18 @@ __global__ void __launch_bounds__(256) pool_fwd_kernel(const float *__restrict__
         const float *p = z + g * K * C + c;
         float best = -INFINITY;
         int bi = 0;
-        for (int k = 0; k < K; ++k) {
+        int k = 0;
+        for (; k + 8 <= K; k += 8) {  // eight independent strided loads in flight per lane
+            float z[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) z[u] = p[(size_t)(k + u) * C];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float v = fmaxf(fmaf(z[u], sc, sh), 0.f);
+                if (v > best) best = v, bi = k + u;
+            }
+        }
+        for (; k < K; ++k) {
             const float v = fmaxf(fmaf(p[(size_t)k * C], sc, sh), 0.f);
             if (v > best) best = v, bi = k;
         }

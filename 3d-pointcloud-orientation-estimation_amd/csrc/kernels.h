@@ -75,6 +75,8 @@ int launch_gemm(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, c
 // dz is produced as in A_DZ (or read directly when dz.mode == A_PLAIN); A2 by its own AOperand.
 int launch_dw(const AOperand &dz, int Nc, const AOperand &a2, int Kp, int M, float *slab, int nsplit, int kp_pad,
               hipStream_t st);
+// out[M x C] = the A_DZ / A_DZ_POOL operand written out densely (used for small M, see gemm_kernels.hip)
+int launch_dz_materialize(const AOperand &dz, int M, int C, float *out, hipStream_t st);
 // picks the split count / padded pitch launch_dw will use (so callers can size the slab)
 void dw_plan(int M, int Nc, int Kp, int *nsplit, int *kp_pad);
 // out[c][perm(k)] = sum_s slab[s][c][k]; perm_D < 0: identity; else feature-first -> xyz-first column order.

@@ -113,9 +113,12 @@ static SaSaved sa_saved_layout(const pnpp_sa_desc *d, const SaGeom &g, void *bas
     return s;
 }
 
+constexpr int kSmallM = 4096;  // at or below this many rows dZ is materialised once per layer (group_all layers)
+
 struct SaScratch {
     double *slab;
     float *dy[2];
+    float *dzbuf;  // small-M layers only: materialised dZ
     float *dm;
     float *cst;
     float *dwslab;
@@ -129,6 +132,7 @@ static SaScratch sa_scratch_layout(const pnpp_sa_desc *d, const SaGeom &g, void 
     const int wide = g.maxC > d->D ? g.maxC : d->D;
     s.dy[0] = cv.take<float>((size_t)g.M * wide);
     s.dy[1] = cv.take<float>((size_t)g.M * wide);
+    s.dzbuf = cv.take<float>(g.M <= kSmallM ? (size_t)g.M * g.maxC : 0);
     s.dm = cv.take<float>((size_t)g.G * d->C[d->L - 1]);
     s.cst = cv.take<float>((size_t)5 * g.maxC);
     size_t dwmax = 0;
@@ -258,6 +262,13 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
         dz.z = sv.z[l];
         dz.cst = sc.cst;
         dz.C = C;
+        if (g.M <= kSmallM) {  // every consumer would rebuild dZ per 32 x 32 tile: write it out once instead
+            PNPP_TRY(launch_dz_materialize(dz, g.M, C, sc.dzbuf, st));
+            dz = AOperand();
+            dz.mode = A_PLAIN;
+            dz.a = sc.dzbuf;
+            dz.lda = C;
+        }
 
         AOperand a2;
         if (l == 0) {
