@@ -188,15 +188,17 @@ __device__ __forceinline__ float2 fetch_a1(const AOperand &A, int row, int k, in
 
 template <int MODE>
 __device__ __forceinline__ float xform_a1(const float2 r, const ChanConst &c, int k, int Kvalid, bool ok) {
-    if (!ok || k >= Kvalid) return 0.f;
+    // out-of-range lanes were loaded from clamped (valid, finite) addresses and are zeroed by a multiplication: a
+    // select here lets hipcc sink the loads into a per-lane branch and wait for each of them separately
+    const float m = (ok && k < Kvalid) ? 1.f : 0.f;
     if constexpr (MODE == A_PLAIN) {
-        return r.x;
+        return r.x * m;
     } else if constexpr (MODE == A_BNRELU) {
-        return fmaxf(fmaf(r.x, c.sc, c.sh), 0.f);
+        return fmaxf(fmaf(r.x, c.sc, c.sh), 0.f) * m;
     } else if constexpr (MODE == A_DZ || MODE == A_DZ_POOL) {
-        return c.g * (r.x - c.c1 - (r.y - c.mu) * c.is * c.c2);
+        return c.g * (r.x - c.c1 - (r.y - c.mu) * c.is * c.c2) * m;
     } else {
-        return __fsub_rn(r.x, r.y);
+        return __fsub_rn(r.x, r.y) * m;
     }
 }
 
@@ -262,7 +264,7 @@ gemm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, const E
                     }
                     const bool okk = kk < B.rows;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = (okk && n + e < Nout) ? t[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) t[e] *= (okk && n + e < Nout) ? 1.f : 0.f;
                 } else {  // [n][k]: four consecutive reduction indices of one output column; n runs fastest over the
                           // lanes so that the transposing LDS stores below are conflict-free
                     const int n = n0 + f % BN, kq = k0 + 4 * (f / BN);
@@ -281,7 +283,7 @@ gemm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, const E
                     }
                     const bool okn = n < Nout;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = (okn && kq + e < B.rows) ? t[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) t[e] *= (okn && kq + e < B.rows) ? 1.f : 0.f;
                 }
                 rb[i] = make_float4(t[0], t[1], t[2], t[3]);
             }
@@ -551,7 +553,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                     for (int e = 0; e < 4; ++e) t[e] = src[min(n + e, Nout - 1)];
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = (kk < B.rows && n + e < Nout) ? t[e] : 0.f;
+                for (int e = 0; e < 4; ++e) t[e] *= (kk < B.rows && n + e < Nout) ? 1.f : 0.f;
                 *reinterpret_cast<float4 *>(Ws + kk * BN + 4 * (f % (BN / 4))) = make_float4(t[0], t[1], t[2], t[3]);
             } else {
                 const int nl = f % BN, k4 = 4 * (f / BN), n = n0 + nl;
@@ -569,7 +571,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Ws[(k4 + e) * BN + nl] = (n < Nout && k4 + e < B.rows) ? t[e] : 0.f;
+                for (int e = 0; e < 4; ++e) Ws[(k4 + e) * BN + nl] = t[e] * ((n < Nout && k4 + e < B.rows) ? 1.f : 0.f);
             }
         }
     }
@@ -737,17 +739,38 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         const float *bp = Ws + lh * BN + wn * TN + l31;
-#pragma unroll 8
-        for (int s = 0; s < KD / 2; ++s) {
-            float a[MT], b[NT];
+        {
+            // K loop, software-pipelined by hand: the LDS operand reads of block b+1 (SB k-steps) are issued before
+            // the MFMAs of block b, so an MFMA never waits for a read issued right in front of it
+            constexpr int SB = (KD / 2) % 4 == 0 ? 4 : 2, NBLK = (KD / 2) / SB;
+            float ra[2][SB][MT], rb[2][SB][NT];
+            auto ld = [&](int buf, int s0) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = As[a_idx(wm * TM + i * 32 + l31, 2 * s + lh)];
+                for (int u = 0; u < SB; ++u) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = bp[2 * s * BN + j * 32];
+                    for (int i = 0; i < MT; ++i) ra[buf][u][i] = As[a_idx(wm * TM + i * 32 + l31, 2 * (s0 + u) + lh)];
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                    for (int j = 0; j < NT; ++j) rb[buf][u][j] = bp[2 * (s0 + u) * BN + j * 32];
+                }
+            };
+            auto mm = [&](int buf) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int u = 0; u < SB; ++u)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][u][i], rb[buf][u][j], acc[i][j], 0, 0, 0);
+            };
+            ld(0, 0);
+#pragma unroll 1
+            for (int blk = 0; blk + 1 < NBLK; blk += 2) {  // rolled: a fully unrolled loop lets the scheduler hoist reads until it spills
+                ld(1, (blk + 1) * SB);
+                mm(0);
+                if (blk + 2 < NBLK) ld(0, (blk + 2) * SB);
+                mm(1);
+            }
+            if constexpr (NBLK % 2 == 1) mm(0);
         }
 
         // epilogue: each accumulator register is one row; a half-wave writes 32 consecutive floats (128 B)
@@ -787,11 +810,27 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
                 const int tile_id = wave + 4 * t, ct = tile_id / (BN / 32), kt = tile_id % (BN / 32);
-#pragma unroll 8
-                for (int s = 0; s < BM / 2; ++s) {
-                    const int m = 2 * s + lh;
-                    dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[a_idx(m, ct * 32 + l31)], Ap[m * BN + kt * 32 + l31],
-                                                                     dwacc[t], 0, 0, 0);
+                constexpr int SB = 4, NBLK = (BM / 2) / SB;
+                float da[2][SB], db[2][SB];
+                auto ld = [&](int buf, int s0) {
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+                        const int m = 2 * (s0 + u) + lh;
+                        da[buf][u] = As[a_idx(m, ct * 32 + l31)];
+                        db[buf][u] = Ap[m * BN + kt * 32 + l31];
+                    }
+                };
+                ld(0, 0);
+#pragma unroll 1
+                for (int blk = 0; blk < NBLK; blk += 2) {
+                    ld(1, (blk + 1) * SB);
+#pragma unroll
+                    for (int u = 0; u < SB; ++u)
+                        dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[0][u], db[0][u], dwacc[t], 0, 0, 0);
+                    if (blk + 2 < NBLK) ld(0, (blk + 2) * SB);
+#pragma unroll
+                    for (int u = 0; u < SB; ++u)
+                        dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[1][u], db[1][u], dwacc[t], 0, 0, 0);
                 }
             }
         }
@@ -872,11 +911,14 @@ static int launch_ws_e(const AOperand &A, const BOperand &B, int M, int Nout, co
         case E_STORE: return launch_ws_one<KD, BM, BN, WM, WN, AM, E_STORE, false>(A, B, M, Nout, E, nslab, st, nullptr);
         case E_STORE_STATS: return launch_ws_one<KD, BM, BN, WM, WN, AM, E_STORE_STATS, false>(A, B, M, Nout, E, nslab, st, nullptr);
         case E_MASK_STATS:
-            if constexpr ((AM == A_DZ || AM == A_DZ_POOL) && KD % 32 == 0 && ((KD / 32) * (BN / 32)) % 4 == 0) {
+            // the 128x128 tile has no registers to spare for the masked epilogue (it spills): use the 128x64 one
+            if constexpr (KD == 64 && BN == 128) return launch_ws_e<64, 128, 64, 4, 1, AM>(A, B, M, Nout, E, nslab, st, dw_slabs);
+            else if constexpr ((AM == A_DZ || AM == A_DZ_POOL) && KD % 32 == 0 && ((KD / 32) * (BN / 32)) % 4 == 0) {
                 if (E.dwslab && dw_slabs)
                     return launch_ws_one<KD, BM, BN, WM, WN, AM, E_MASK_STATS, true>(A, B, M, Nout, E, nslab, st, dw_slabs);
             }
-            return launch_ws_one<KD, BM, BN, WM, WN, AM, E_MASK_STATS, false>(A, B, M, Nout, E, nslab, st, nullptr);
+            if constexpr (!(KD == 64 && BN == 128))
+                return launch_ws_one<KD, BM, BN, WM, WN, AM, E_MASK_STATS, false>(A, B, M, Nout, E, nslab, st, nullptr);
     }
     set_error("gemm_ws: bad epilogue mode %d", E.mode);
     return PNPP_ERR_ARG;
@@ -975,8 +1017,10 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
 #pragma unroll
             for (int s2 = 0; s2 < KC / 2; ++s2) {
                 const int k = k0 + 2 * s2 + lh;
+                // mask by multiplication, not by a select: hipcc turns "cond ? loaded : 0" into a branch around the load
+                // with its own vmcnt(0), which serialises the sixteen operand loads of a chunk
                 const float v = Bm[(size_t)min(k, B.rows - 1) * ldb + min(n0 + l31, Nout - 1)];
-                nb[s2] = (k < B.rows && n0 + l31 < Nout) ? v : 0.f;
+                nb[s2] = v * ((k < B.rows && n0 + l31 < Nout) ? 1.f : 0.f);
             }
         }
     };
