@@ -339,7 +339,7 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
             E.mode = E_STORE;
             PNPP_TRY(launch_gemm(A, W, d->M, d->N, d->K, E, nullptr, st));
         }
-        PNPP_TRY(launch_bn_finalize_fwd(sc.slab, nslab, d->N, (double)d->M, a->b, a->nw, a->nb, a->rm, a->rv, d->momentum, d->eps,
+        PNPP_TRY(launch_bn_finalize_fwd(sc.slab, nslab, d->N, (double)d->M, a->b, a->nw, a->nb, a->rm, a->rv, (long long *)a->nbt, d->momentum, d->eps,
                                         d->training, sv.mean, sv.istd, sv.scale, sv.shift, st));
         hipLaunchKernelGGL(fc_apply_cols_kernel, dim3(grid), dim3(256), 0, st, sv.z, sv.scale, sv.shift, a->mask, d->drop_scale,
                            d->relu, d->M, d->N, a->y);

@@ -1370,29 +1370,35 @@ int launch_dw(const AOperand &dz, int Nc, const AOperand &a2, int Kp, int M, flo
 // out[c][perm(k)] = sum_s slab[s][c][k], fixed summation order: block = EPB outputs x (256/EPB) split lanes,
 // every lane strides the splits with four independent partial sums, the lanes are combined in lane order.
 // Small outputs (a 64 x 3 weight) take 16 outputs per block so that the splits, not the outputs, fill the chip.
+struct SlabReduceArgs {
+    const float *slab;
+    int nsplit, Nc, kp_pad, Kvalid, perm_D;
+    float *out;
+    int ldo;
+};
+
 template <int EPB>
-__global__ void __launch_bounds__(256) slab_reduce_kernel(const float *__restrict__ slab, int nsplit, int Nc, int kp_pad,
-                                                          int Kvalid, int perm_D, float *__restrict__ out, int ldo) {
+__device__ __forceinline__ void slab_reduce_block(const SlabReduceArgs &R, int bid) {
     constexpr int SL = 256 / EPB;
     __shared__ float red[SL][EPB];
-    const int total = Nc * Kvalid;
+    const int total = R.Nc * R.Kvalid;
     const int e = threadIdx.x % EPB, sl = threadIdx.x / EPB;
-    const int i = blockIdx.x * EPB + e;
+    const int i = bid * EPB + e;
     float acc = 0.f;
     int c = 0, k = 0;
     if (i < total) {
-        c = i / Kvalid, k = i - c * Kvalid;
-        const float *p = slab + (size_t)c * kp_pad + k;
-        const size_t stride = (size_t)Nc * kp_pad;
+        c = i / R.Kvalid, k = i - c * R.Kvalid;
+        const float *p = R.slab + (size_t)c * R.kp_pad + k;
+        const size_t stride = (size_t)R.Nc * R.kp_pad;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int s = sl;
-        for (; s + 3 * SL < nsplit; s += 4 * SL) {
+        for (; s + 3 * SL < R.nsplit; s += 4 * SL) {
             a0 += p[(size_t)s * stride];
             a1 += p[(size_t)(s + SL) * stride];
             a2 += p[(size_t)(s + 2 * SL) * stride];
             a3 += p[(size_t)(s + 3 * SL) * stride];
         }
-        for (; s < nsplit; s += SL) a0 += p[(size_t)s * stride];
+        for (; s < R.nsplit; s += SL) a0 += p[(size_t)s * stride];
         acc = (a0 + a1) + (a2 + a3);
     }
     red[sl][e] = acc;
@@ -1402,59 +1408,28 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float *__restric
 #pragma unroll
         for (int j = 0; j < SL; ++j) t += red[j][e];
         int ko = k;
-        if (perm_D >= 0) ko = k < perm_D ? k + 3 : k - perm_D;  // features-first -> xyz-first (state_dict order)
-        out[(size_t)c * ldo + ko] = t;
+        if (R.perm_D >= 0) ko = k < R.perm_D ? k + 3 : k - R.perm_D;  // features-first -> xyz-first (state_dict order)
+        R.out[(size_t)c * R.ldo + ko] = t;
     }
 }
+
+template <int EPB>
+__global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduceArgs R) {
+    slab_reduce_block<EPB>(R, blockIdx.x);
+}
+
+static inline bool slab_reduce_wide(int total, int nsplit) { return total >= 16384 || nsplit <= 8; }
 
 int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kvalid, int perm_D, float *out, int ldo,
                        hipStream_t st) {
     const int total = Nc * Kvalid;
+    const SlabReduceArgs R{slab, nsplit, Nc, kp_pad, Kvalid, perm_D, out, ldo};
     ProfScope ps(st, "slab_reduce_kernel N=%d K=%d split=%d", Nc, Kvalid, nsplit);
-    if (total >= 16384 || nsplit <= 8)
-        hipLaunchKernelGGL(slab_reduce_kernel<64>, dim3(cdiv(total, 64)), dim3(256), 0, st, slab, nsplit, Nc, kp_pad, Kvalid, perm_D,
-                           out, ldo);
+    if (slab_reduce_wide(total, nsplit))
+        hipLaunchKernelGGL(slab_reduce_kernel<64>, dim3(cdiv(total, 64)), dim3(256), 0, st, R);
     else
-        hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3(cdiv(total, 16)), dim3(256), 0, st, slab, nsplit, Nc, kp_pad, Kvalid, perm_D,
-                           out, ldo);
+        hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3(cdiv(total, 16)), dim3(256), 0, st, R);
     PNPP_CHECK_LAUNCH("slab_reduce");
-    return PNPP_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// weight preparation: W (Cout x Cin) -> W^T (Kd x Cout) [+ features-first row-major copy]
-// ---------------------------------------------------------------------------------------------
-struct PrepPack {
-    PrepItem it[PNPP_MAX_LAYERS];
-    int n;
-};
-
-__global__ void __launch_bounds__(256) prep_weights_kernel(const PrepPack P) {
-    const PrepItem it = P.it[blockIdx.y];
-    const int total = it.Kd * it.Cout;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int kp = i / it.Cout, n = i - kp * it.Cout;  // writes coalesced along n
-        int ksrc = kp;                       // column of the state_dict weight this row comes from
-        if (it.perm_D >= 0) ksrc = kp < it.perm_D ? kp + 3 : kp - it.perm_D;  // features first, then xyz
-        const float v = kp < it.Cin ? it.w[(size_t)n * it.Cin + ksrc] : 0.f;   // rows Cin..Kd-1 are zero padding
-        it.wt[(size_t)kp * it.Cout + n] = v;
-        if (it.wperm) it.wperm[(size_t)n * it.Kd + kp] = v;
-    }
-}
-
-int launch_prep_weights(const PrepItem *items, int n, hipStream_t st) {
-    PNPP_REQUIRE(n > 0 && n <= PNPP_MAX_LAYERS, PNPP_ERR_ARG, "prep_weights: bad item count %d", n);
-    PrepPack P;
-    P.n = n;
-    int maxtot = 0;
-    for (int i = 0; i < n; ++i) {
-        P.it[i] = items[i];
-        maxtot = items[i].Kd * items[i].Cout > maxtot ? items[i].Kd * items[i].Cout : maxtot;
-    }
-    const int gx = cdiv(maxtot, 256) < 256 ? cdiv(maxtot, 256) : 256;
-    ProfScope ps(st, "prep_weights_kernel n=%d", n);
-    hipLaunchKernelGGL(prep_weights_kernel, dim3(gx, n), dim3(256), 0, st, P);
-    PNPP_CHECK_LAUNCH("prep_weights");
     return PNPP_OK;
 }
 
@@ -1490,9 +1465,11 @@ __device__ __forceinline__ void slab_column_sums(const double *__restrict__ slab
 __global__ void __launch_bounds__(256)
 bn_finalize_fwd_kernel(const double *__restrict__ slab, int nslab, int C, double count, const float *__restrict__ bias,
                        const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ rm,
-                       float *__restrict__ rv, float momentum, float eps, int training, float *__restrict__ mean,
-                       float *__restrict__ istd, float *__restrict__ scale, float *__restrict__ shift) {
+                       float *__restrict__ rv, long long *__restrict__ nbt, float momentum, float eps, int training,
+                       float *__restrict__ mean, float *__restrict__ istd, float *__restrict__ scale,
+                       float *__restrict__ shift) {
     __shared__ double red[32][2][FIN_COLS];
+    if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;  // num_batches_tracked (nn.BatchNorm forward)
     const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
     double mu, var;
     if (training) {
@@ -1522,35 +1499,52 @@ bn_finalize_fwd_kernel(const double *__restrict__ slab, int nslab, int C, double
     }
 }
 
-__global__ void __launch_bounds__(256)
-bn_finalize_bwd_kernel(const double *__restrict__ slab, int nslab, int C, double count, int training,
-                       const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ istd,
-                       float *__restrict__ cst, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                       float *__restrict__ dbias) {
+struct BnFinalizeBwdArgs {
+    const double *slab;
+    int nslab, C;
+    double count;
+    int training;
+    const float *gamma, *mean, *istd;
+    float *cst, *dgamma, *dbeta, *dbias;
+};
+
+__device__ __forceinline__ void bn_finalize_bwd_block(const BnFinalizeBwdArgs &F, int bid) {
     __shared__ double red[32][2][FIN_COLS];
-    const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
+    const int C = F.C;
+    const int c = bid * FIN_COLS + (threadIdx.x % FIN_COLS);
     double s1, s2;
-    slab_column_sums(slab, nslab, C, c, s1, s2, red);
+    slab_column_sums(F.slab, F.nslab, C, c, s1, s2, red);
     if (threadIdx.x >= FIN_COLS || c >= C) return;
-    const float g = gamma ? gamma[c] : 1.f;
-    cst[c] = g * istd[c];
-    cst[C + c] = mean[c];
-    cst[2 * C + c] = istd[c];
-    cst[3 * C + c] = training ? (float)(s1 / count) : 0.f;
-    cst[4 * C + c] = training ? (float)(s2 / count) : 0.f;
-    if (dgamma) dgamma[c] = (float)s2;
-    if (dbeta) dbeta[c] = (float)s1;
+    const float g = F.gamma ? F.gamma[c] : 1.f;
+    float *cst = F.cst;
+    cst[c] = g * F.istd[c];
+    cst[C + c] = F.mean[c];
+    cst[2 * C + c] = F.istd[c];
+    cst[3 * C + c] = F.training ? (float)(s1 / F.count) : 0.f;
+    cst[4 * C + c] = F.training ? (float)(s2 / F.count) : 0.f;
+    if (F.dgamma) F.dgamma[c] = (float)s2;
+    if (F.dbeta) F.dbeta[c] = (float)s1;
     // a bias in front of a train-mode BatchNorm has exactly zero gradient; with running
     // statistics the layer is affine and d(bias) = sum_m dz = g * sum_m dy
-    if (dbias) dbias[c] = training ? 0.f : (float)((double)cst[c] * s1);
+    if (F.dbias) F.dbias[c] = F.training ? 0.f : (float)((double)cst[c] * s1);
+}
+
+__global__ void __launch_bounds__(256) bn_finalize_bwd_kernel(BnFinalizeBwdArgs F) { bn_finalize_bwd_block(F, blockIdx.x); }
+
+// the two reductions that follow a backward GEMM -- the weight-gradient partials of layer l and the BatchNorm-backward
+// column sums of layer l-1 -- share one launch: the first nfin workgroups finalise, the rest reduce slabs
+template <int EPB>
+__global__ void __launch_bounds__(256) post_gemm_kernel(BnFinalizeBwdArgs F, int nfin, SlabReduceArgs R) {
+    if ((int)blockIdx.x < nfin) bn_finalize_bwd_block(F, blockIdx.x);
+    else slab_reduce_block<EPB>(R, blockIdx.x - nfin);
 }
 
 int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, const float *bias, const float *gamma,
-                           const float *beta, float *rm, float *rv, float momentum, float eps, int training, float *mean,
-                           float *istd, float *scale, float *shift, hipStream_t st) {
+                           const float *beta, float *rm, float *rv, long long *nbt, float momentum, float eps, int training,
+                           float *mean, float *istd, float *scale, float *shift, hipStream_t st) {
     ProfScope ps(st, "bn_finalize_fwd_kernel C=%d", C);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, st, slab, nslab, C, count, bias, gamma, beta,
-                       rm, rv, momentum, eps, training, mean, istd, scale, shift);
+                       rm, rv, nbt, momentum, eps, training, mean, istd, scale, shift);
     PNPP_CHECK_LAUNCH("bn_finalize_fwd");
     return PNPP_OK;
 }
@@ -1558,10 +1552,25 @@ int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, c
 int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, int training, const float *gamma,
                            const float *mean, const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias,
                            hipStream_t st) {
+    const BnFinalizeBwdArgs F{slab, nslab, C, count, training, gamma, mean, istd, cst, dgamma, dbeta, dbias};
     ProfScope ps(st, "bn_finalize_bwd_kernel C=%d", C);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, st, slab, nslab, C, count, training, gamma,
-                       mean, istd, cst, dgamma, dbeta, dbias);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, st, F);
     PNPP_CHECK_LAUNCH("bn_finalize_bwd");
+    return PNPP_OK;
+}
+
+int launch_post_gemm(const double *slab, int nslab, int C, double count, int training, const float *gamma, const float *mean,
+                     const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias, const float *dwslab, int nsplit,
+                     int Nc, int kp_pad, int Kvalid, int perm_D, float *dw, int ldo, hipStream_t st) {
+    const BnFinalizeBwdArgs F{slab, nslab, C, count, training, gamma, mean, istd, cst, dgamma, dbeta, dbias};
+    const SlabReduceArgs R{dwslab, nsplit, Nc, kp_pad, Kvalid, perm_D, dw, ldo};
+    const int total = Nc * Kvalid, nfin = cdiv(C, FIN_COLS);
+    ProfScope ps(st, "post_gemm_kernel C=%d | N=%d K=%d split=%d", C, Nc, Kvalid, nsplit);
+    if (slab_reduce_wide(total, nsplit))
+        hipLaunchKernelGGL(post_gemm_kernel<64>, dim3(nfin + cdiv(total, 64)), dim3(256), 0, st, F, nfin, R);
+    else
+        hipLaunchKernelGGL(post_gemm_kernel<16>, dim3(nfin + cdiv(total, 16)), dim3(256), 0, st, F, nfin, R);
+    PNPP_CHECK_LAUNCH("post_gemm");
     return PNPP_OK;
 }
 

@@ -324,25 +324,47 @@ __device__ __forceinline__ unsigned philox_key(unsigned c0, unsigned c1, unsigne
 }
 
 __global__ void __launch_bounds__(256) sample_random_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_lo,
-                                                            unsigned str_hi, const unsigned long long *__restrict__ str_dev,
+                                                            unsigned str_hi, unsigned long long *__restrict__ str_dev,
                                                             int N, int npoint, int32_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned keys[];
     const int b = blockIdx.y;
-    if (str_dev) {  // stream id lives in device memory (graph replays draw fresh centres): *str_dev + (str_hi:str_lo)
-        const unsigned long long sid = *str_dev + (((unsigned long long)str_hi << 32) | str_lo);
+    if (str_dev) {  // stream id lives in device memory (graph replays draw fresh centres): str_dev[0] + (str_hi:str_lo)
+        const unsigned long long sid = str_dev[0] + (((unsigned long long)str_hi << 32) | str_lo);
         str_lo = (unsigned)sid, str_hi = (unsigned)(sid >> 32);
     }
-    for (int n = threadIdx.x; n < N; n += 256) keys[n] = philox_key((unsigned)n, (unsigned)b, str_lo, str_hi, seed_lo, seed_hi);
+    const int Np = (N + 3) & ~3;  // padding keys are the maximum and sit behind every real index: they never count
+    for (int n = threadIdx.x; n < Np; n += 256)
+        keys[n] = n < N ? philox_key((unsigned)n, (unsigned)b, str_lo, str_hi, seed_lo, seed_hi) : 0xffffffffu;
     __syncthreads();
     const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    const unsigned mine = keys[n];
-    int rank = 0;
-    for (int m = 0; m < N; ++m) {
-        const unsigned o = keys[m];
-        rank += (o < mine) || (o == mine && m < n);
+    if (n < N) {
+        const unsigned mine = keys[n];
+        int rank = 0;
+        const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+#pragma unroll 4
+        for (int m4 = 0; m4 < Np / 4; ++m4) {  // one 16-byte LDS broadcast per four candidates
+            const uint4 o = k4[m4];
+            const int m = 4 * m4;
+            rank += (o.x < mine) || (o.x == mine && m < n);
+            rank += (o.y < mine) || (o.y == mine && m + 1 < n);
+            rank += (o.z < mine) || (o.z == mine && m + 2 < n);
+            rank += (o.w < mine) || (o.w == mine && m + 3 < n);
+        }
+        if (rank < npoint) out[(size_t)b * npoint + rank] = n;
     }
-    if (rank < npoint) out[(size_t)b * npoint + rank] = n;
+    if (str_dev) {
+        // post-increment of the device counter: every workgroup has read str_dev[0] before it takes a ticket, so
+        // the workgroup that takes the last ticket can bump the counter (and clear the ticket word for the next launch)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned total = gridDim.x * gridDim.y;
+            const unsigned long long t = atomicAdd(&str_dev[1], 1ull);
+            if (t == total - 1) {
+                str_dev[1] = 0ull;
+                str_dev[0] += 1ull;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -401,17 +423,27 @@ __global__ void __launch_bounds__(64) scatter_rows_bwd_kernel(const float *__res
     }
 }
 
-// gather of centre coordinates new_xyz[b,s,:] = xyz[b, centre[b,s], :]
+// gather of centre coordinates new_xyz[b,s,:] = xyz[b, centre[b,s], :] into two destinations (the caller's output and
+// the copy kept for backward); centre == nullptr writes the origin (group_all, pointnet_pp_8dir.py:24)
 __global__ void __launch_bounds__(256) gather_centres_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ centre,
-                                                             int N, int S, int total, float *__restrict__ new_xyz) {
+                                                             int N, int S, int total, float *__restrict__ out_a,
+                                                             float *__restrict__ out_b) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int b = i / S;
-    const int n = centre[i];
-    const float *s = xyz + ((size_t)b * N + n) * 3;
-    new_xyz[(size_t)i * 3 + 0] = s[0];
-    new_xyz[(size_t)i * 3 + 1] = s[1];
-    new_xyz[(size_t)i * 3 + 2] = s[2];
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (centre) {
+        const int b = i / S;
+        const float *s = xyz + ((size_t)b * N + centre[i]) * 3;
+        x = s[0], y = s[1], z = s[2];
+    }
+    out_a[(size_t)i * 3 + 0] = x;
+    out_a[(size_t)i * 3 + 1] = y;
+    out_a[(size_t)i * 3 + 2] = z;
+    if (out_b) {
+        out_b[(size_t)i * 3 + 0] = x;
+        out_b[(size_t)i * 3 + 1] = y;
+        out_b[(size_t)i * 3 + 2] = z;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -429,9 +461,11 @@ int launch_knn(const float *new_xyz, const float *xyz, int B, int S, int N, int 
     return PNPP_OK;
 }
 
-int launch_gather_centres(const float *xyz, const int32_t *centre, int B, int N, int S, float *new_xyz, hipStream_t st) {
+int launch_gather_centres(const float *xyz, const int32_t *centre, int B, int N, int S, float *out_a, float *out_b,
+                          hipStream_t st) {
     const int total = B * S;
-    hipLaunchKernelGGL(gather_centres_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, xyz, centre, N, S, total, new_xyz);
+    ProfScope ps(st, "gather_centres_kernel B=%d S=%d", B, S);
+    hipLaunchKernelGGL(gather_centres_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, xyz, centre, N, S, total, out_a, out_b);
     PNPP_CHECK_LAUNCH("gather_centres");
     return PNPP_OK;
 }
@@ -495,32 +529,33 @@ extern "C" int pnpp_ball_query(const float *new_xyz, const float *xyz, int B, in
     return PNPP_OK;
 }
 
-static int sample_random_impl(uint64_t seed, uint64_t stream_id, const uint64_t *stream_id_dev, int B, int N, int npoint,
+static int sample_random_impl(uint64_t seed, uint64_t stream_id, uint64_t *stream_id_dev, int B, int N, int npoint,
                               int32_t *out, void *stream);
 
 extern "C" int pnpp_sample_random(uint64_t seed, uint64_t stream_id, int B, int N, int npoint, int32_t *out, void *stream) {
     return sample_random_impl(seed, stream_id, nullptr, B, N, npoint, out, stream);
 }
 
-extern "C" int pnpp_sample_random_dev(uint64_t seed, const uint64_t *stream_id_dev, uint64_t offset, int B, int N, int npoint,
+extern "C" int pnpp_sample_random_dev(uint64_t seed, uint64_t *stream_id_dev, uint64_t offset, int B, int N, int npoint,
                                       int32_t *out, void *stream) {
     PNPP_REQUIRE(stream_id_dev, PNPP_ERR_ARG, "sample_random_dev: null counter pointer");
     return sample_random_impl(seed, offset, stream_id_dev, B, N, npoint, out, stream);
 }
 
-static int sample_random_impl(uint64_t seed, uint64_t stream_id, const uint64_t *stream_id_dev, int B, int N, int npoint,
+static int sample_random_impl(uint64_t seed, uint64_t stream_id, uint64_t *stream_id_dev, int B, int N, int npoint,
                               int32_t *out, void *stream) {
     PNPP_REQUIRE(out, PNPP_ERR_ARG, "sample_random: null pointer");
     PNPP_REQUIRE(B > 0 && N > 0 && npoint > 0, PNPP_ERR_ARG, "sample_random: non-positive size");
     PNPP_REQUIRE(npoint <= N, PNPP_ERR_RANGE, "sample_random: npoint=%d > N=%d", npoint, N);
     PNPP_REQUIRE((size_t)N * 4 <= 128 * 1024, PNPP_ERR_ARG, "sample_random: N=%d too large", N);
     PNPP_REQUIRE(B <= 65535, PNPP_ERR_ARG, "sample_random: batch exceeds grid limit");
-    const size_t lds = (size_t)N * sizeof(unsigned);
+    const size_t lds = (size_t)((N + 3) & ~3) * sizeof(unsigned);
     if (lds > 48 * 1024)
         hipFuncSetAttribute((const void *)sample_random_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ProfScope ps(as_stream(stream), "sample_random_kernel B=%d N=%d npoint=%d", B, N, npoint);
     hipLaunchKernelGGL(sample_random_kernel, dim3(cdiv(N, 256), B), dim3(256), lds, as_stream(stream), (unsigned)seed,
                        (unsigned)(seed >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32),
-                       reinterpret_cast<const unsigned long long *>(stream_id_dev), N, npoint, out);
+                       reinterpret_cast<unsigned long long *>(stream_id_dev), N, npoint, out);
     PNPP_CHECK_LAUNCH("sample_random");
     return PNPP_OK;
 }

@@ -6,7 +6,7 @@ namespace pnpp {
 
 // ---- index_kernels.hip ----
 int launch_knn(const float *new_xyz, const float *xyz, int B, int S, int N, int k, int32_t *idx, hipStream_t st);
-int launch_gather_centres(const float *xyz, const int32_t *centre, int B, int N, int S, float *new_xyz, hipStream_t st);
+int launch_gather_centres(const float *xyz, const int32_t *centre, int B, int N, int S, float *out_a, float *out_b, hipStream_t st);
 int launch_scatter_rows_bwd(const float *dout, const int32_t *idx, int B, int N, int C, int M, float *dpoints, hipStream_t st);
 
 // ---- gemm_kernels.hip ----
@@ -83,20 +83,17 @@ void dw_plan(int M, int Nc, int Kp, int *nsplit, int *kp_pad);
 int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kvalid, int perm_D, float *out, int ldo,
                        hipStream_t st);
 
-struct PrepItem {
-    const float *w;  // (Cout, Cin) row-major
-    float *wt;       // out (Kd, Cout): transposed, features-first for layer 0
-    float *wperm;    // out (Cout, Kd) or nullptr: features-first copy (layer 0 only)
-    int Cout, Cin, Kd, perm_D;  // perm_D < 0: no permutation
-};
-int launch_prep_weights(const PrepItem *items, int n, hipStream_t st);
-
 int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, const float *bias, const float *gamma,
-                           const float *beta, float *rm, float *rv, float momentum, float eps, int training, float *mean,
-                           float *istd, float *scale, float *shift, hipStream_t st);
+                           const float *beta, float *rm, float *rv, long long *nbt, float momentum, float eps, int training,
+                           float *mean, float *istd, float *scale, float *shift, hipStream_t st);
 int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, int training, const float *gamma,
                            const float *mean, const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias,
                            hipStream_t st);
+
+// bn_finalize_bwd of one layer and the weight-gradient slab reduction of the layer above it, in one launch
+int launch_post_gemm(const double *slab, int nslab, int C, double count, int training, const float *gamma, const float *mean,
+                     const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias, const float *dwslab, int nsplit,
+                     int Nc, int kp_pad, int Kvalid, int perm_D, float *dw, int ldo, hipStream_t st);
 
 int launch_pool_fwd(const float *z, const float *scale, const float *shift, int G, int K, int C, float *out, int32_t *arg,
                     hipStream_t st);

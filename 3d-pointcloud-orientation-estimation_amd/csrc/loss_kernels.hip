@@ -125,6 +125,42 @@ __global__ void __launch_bounds__(256) vm_head_kl_kernel(const float *__restrict
     }
 }
 
+// head + KL + batch mean + gradient of the mean in ONE single-workgroup launch: the training step's loss tail
+// (head, KL, mean, and the three elementwise kernels of their autograd backward) collapses into this and one multiply.
+// The mean is a fixed-order fp64 tree, so it is deterministic.
+__global__ void __launch_bounds__(256) vm_head_kl_mean_kernel(const float *__restrict__ o, const float *__restrict__ mu_gt,
+                                                              const float *__restrict__ kappa_gt, int B, float *__restrict__ mu,
+                                                              float *__restrict__ kappa, float *__restrict__ loss_vec,
+                                                              float *__restrict__ loss_mean, float *__restrict__ d_o_mean) {
+    __shared__ double red[256];
+    const double inv_b = 1.0 / (double)B;
+    double part = 0.0;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const double o0 = (double)o[2 * i], o1 = (double)o[2 * i + 1];
+        const double th = tanh(o0);
+        const float mu_f = (float)(th * kPi);
+        const double sp = o1 > 20.0 ? o1 : log1p(exp(o1));
+        const float kap_f = (float)sp;
+        if (mu) mu[i] = mu_f;
+        if (kappa) kappa[i] = kap_f;
+        double v, a, b;
+        kl_single_eval((double)mu_f, (double)kap_f, (double)mu_gt[i], (double)kappa_gt[i], v, a, b);
+        const float vf = (float)v;
+        if (loss_vec) loss_vec[i] = vf;
+        part += (double)vf;
+        const double sig = o1 > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-o1));
+        d_o_mean[2 * i] = (float)(a * kPi * (1.0 - th * th) * inv_b);
+        d_o_mean[2 * i + 1] = (float)(b * sig * inv_b);
+    }
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss_mean = (float)(red[0] * inv_b);
+}
+
 __global__ void __launch_bounds__(256) vm_head_bwd_kernel(const float *__restrict__ o, const float *__restrict__ dmu,
                                                           const float *__restrict__ dkappa, int B, float *__restrict__ d_o) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -371,6 +407,16 @@ extern "C" int pnpp_vm_head_kl(const float *o, const float *mu_gt, const float *
     hipLaunchKernelGGL(vm_head_kl_kernel, dim3(cdiv(B, 256)), dim3(256), 0, as_stream(stream), o, mu_gt, kappa_gt, B, mu, kappa,
                        loss_vec, d_o);
     PNPP_CHECK_LAUNCH("vm_head_kl");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_vm_head_kl_mean(const float *o, const float *mu_gt, const float *kappa_gt, int B, float *mu, float *kappa,
+                                    float *loss_vec, float *loss_mean, float *d_o_mean, void *stream) {
+    PNPP_REQUIRE(o && mu_gt && kappa_gt && loss_mean && d_o_mean, PNPP_ERR_ARG, "vm_head_kl_mean: null pointer");
+    PNPP_REQUIRE(B > 0, PNPP_ERR_ARG, "vm_head_kl_mean: B must be positive");
+    hipLaunchKernelGGL(vm_head_kl_mean_kernel, dim3(1), dim3(256), 0, as_stream(stream), o, mu_gt, kappa_gt, B, mu, kappa,
+                       loss_vec, loss_mean, d_o_mean);
+    PNPP_CHECK_LAUNCH("vm_head_kl_mean");
     return PNPP_OK;
 }
 

@@ -175,12 +175,10 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
 
     // 1. centres and neighbours (pointnet_pp_8dir.py:23-31)
     if (d->group_all) {
-        PNPP_TRY(launch_fill_zero(a->new_xyz, (size_t)g.G * 3 * sizeof(float), st));
-        PNPP_TRY(launch_fill_zero(sv.new_xyz, (size_t)g.G * 3 * sizeof(float), st));
+        PNPP_TRY(launch_gather_centres(a->xyz, nullptr, d->B, d->N, 1, a->new_xyz, sv.new_xyz, st));  // the origin
     } else {
         PNPP_REQUIRE(d->S <= d->N, PNPP_ERR_RANGE, "sa_forward: npoint=%d > N=%d", d->S, d->N);
-        PNPP_TRY(launch_gather_centres(a->xyz, a->centre_idx, d->B, d->N, d->S, a->new_xyz, st));
-        PNPP_TRY(launch_gather_centres(a->xyz, a->centre_idx, d->B, d->N, d->S, sv.new_xyz, st));
+        PNPP_TRY(launch_gather_centres(a->xyz, a->centre_idx, d->B, d->N, d->S, a->new_xyz, sv.new_xyz, st));
         if (a->neighbour_idx) {
             hipError_t e = hipMemcpyAsync(sv.idx, a->neighbour_idx, (size_t)g.M * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
             PNPP_REQUIRE(e == hipSuccess, PNPP_ERR_LAUNCH, "sa_forward: neighbour copy failed: %s", hipGetErrorString(e));
@@ -216,12 +214,12 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
             E.slab = sc.slab;
             PNPP_TRY(launch_gemm(A, W, g.M, d->C[l], g.Kd[l], E, &nslab, st));
             PNPP_TRY(launch_bn_finalize_fwd(sc.slab, nslab, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
-                                            a->bn_rm[l], a->bn_rv[l], d->momentum, d->eps, 1, sv.mean[l], sv.istd[l],
+                                            a->bn_rm[l], a->bn_rv[l], (long long *)a->bn_nbt[l], d->momentum, d->eps, 1, sv.mean[l], sv.istd[l],
                                             sv.scale[l], sv.shift[l], st));
         } else {
             E.mode = E_STORE;
             PNPP_TRY(launch_bn_finalize_fwd(nullptr, 0, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
-                                            a->bn_rm[l], a->bn_rv[l], d->momentum, d->eps, 0, sv.mean[l], sv.istd[l],
+                                            a->bn_rm[l], a->bn_rv[l], nullptr, d->momentum, d->eps, 0, sv.mean[l], sv.istd[l],
                                             sv.scale[l], sv.shift[l], st));
             PNPP_TRY(launch_gemm(A, W, g.M, d->C[l], g.Kd[l], E, nullptr, st));
         }
@@ -249,10 +247,12 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
     int cur = 0, nslab = 0, nslab_next = 0;
     PNPP_TRY(launch_pool_bwd(a->dout, sv.arg, sv.z[Lm], sv.scale[Lm], sv.shift[Lm], sv.mean[Lm], sv.istd[Lm], g.G, d->K,
                              d->C[Lm], sc.dm, sc.slab, &nslab, st));
+    // sc.cst holds the BatchNorm-backward constants of the layer being processed; layer l-1's are produced (together with
+    // layer l's weight-gradient reduction) by the post-GEMM launch that ends iteration l
+    PNPP_TRY(launch_bn_finalize_bwd(sc.slab, nslab, d->C[Lm], (double)g.M, d->training, a->bn_w[Lm], sv.mean[Lm], sv.istd[Lm],
+                                    sc.cst, a->d_bn_w[Lm], a->d_bn_b[Lm], a->d_conv_b[Lm], st));
     for (int l = Lm; l >= 0; --l) {
         const int C = d->C[l];
-        PNPP_TRY(launch_bn_finalize_bwd(sc.slab, nslab, C, (double)g.M, d->training, a->bn_w[l], sv.mean[l], sv.istd[l], sc.cst,
-                                        a->d_bn_w[l], a->d_bn_b[l], a->d_conv_b[l], st));
         AOperand dz;  // the top layer's dense gradient is never materialised (A_DZ_POOL rebuilds it from dm / arg)
         dz.mode = l == Lm ? A_DZ_POOL : A_DZ;
         dz.a = l == Lm ? sc.dm : sc.dy[cur];
@@ -282,7 +282,7 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
         }
         int nsplit, kp_pad;
         dw_plan(g.M, C, g.Cin[l], &nsplit, &kp_pad);
-        bool dw_done = false;
+        int fused_slabs = 0;
         if (l > 0) {
             // dY_{l-1} = (dZ_l * W_l) masked by ReLU'(layer l-1), with layer l-1's BN-backward sums; where the
             // weights-stationary kernel applies, dW_l = dZ_l^T * relu(bn(Z_{l-1})) is accumulated in the same launch
@@ -304,14 +304,18 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             W.rows = C;
             int dw_slabs = 0;
             PNPP_TRY(launch_gemm(dz, W, g.M, d->C[l - 1], C, E, &nslab_next, st, &dw_slabs));
-            if (dw_slabs > 0) {
-                PNPP_TRY(launch_slab_reduce(sc.dwslab, dw_slabs, C, d->C[l - 1], d->C[l - 1], -1, a->d_conv_w[l], d->C[l - 1], st));
-                dw_done = true;
-            }
+            fused_slabs = dw_slabs;
         }
-        if (!dw_done) {  // dW_l = dZ_l^T * A_l as its own launch (layer 0, group_all layers, odd shapes)
+        if (fused_slabs == 0)  // dW_l = dZ_l^T * A_l as its own launch (layer 0, group_all layers, odd shapes)
             PNPP_TRY(launch_dw(dz, C, a2, g.Cin[l], g.M, sc.dwslab, nsplit, kp_pad, st));
-            PNPP_TRY(launch_slab_reduce(sc.dwslab, nsplit, C, kp_pad, g.Cin[l], l == 0 ? d->D : -1, a->d_conv_w[l], g.Cin[l], st));
+        if (l > 0) {  // reduce dW_l's partials and finalise layer l-1's BatchNorm-backward sums in one launch
+            const int Cp = d->C[l - 1];
+            PNPP_TRY(launch_post_gemm(sc.slab, nslab_next, Cp, (double)g.M, d->training, a->bn_w[l - 1], sv.mean[l - 1],
+                                      sv.istd[l - 1], sc.cst, a->d_bn_w[l - 1], a->d_bn_b[l - 1],
+                                      a->d_conv_b[l - 1], sc.dwslab, fused_slabs > 0 ? fused_slabs : nsplit, C,
+                                      fused_slabs > 0 ? Cp : kp_pad, g.Cin[l], -1, a->d_conv_w[l], g.Cin[l], st));
+        } else {
+            PNPP_TRY(launch_slab_reduce(sc.dwslab, nsplit, C, kp_pad, g.Cin[l], d->D, a->d_conv_w[l], g.Cin[l], st));
         }
 
         if (l > 0) {

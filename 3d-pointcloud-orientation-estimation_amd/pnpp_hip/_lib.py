@@ -29,7 +29,7 @@ _PL = _fp * PNPP_MAX_LAYERS
 
 class SaFwdArgs(C.Structure):
     _fields_ = [("xyz", _fp), ("points", _fp), ("centre_idx", _fp), ("neighbour_idx", _fp),
-                ("conv_w", _PL), ("conv_b", _PL), ("bn_w", _PL), ("bn_b", _PL), ("bn_rm", _PL), ("bn_rv", _PL),
+                ("conv_w", _PL), ("conv_b", _PL), ("bn_w", _PL), ("bn_b", _PL), ("bn_rm", _PL), ("bn_rv", _PL), ("bn_nbt", _PL),
                 ("new_xyz", _fp), ("out", _fp), ("saved", _fp), ("scratch", _fp)]
 
 
@@ -45,7 +45,7 @@ class FcDesc(C.Structure):
 
 
 class FcFwdArgs(C.Structure):
-    _fields_ = [("x", _fp), ("w", _fp), ("b", _fp), ("nw", _fp), ("nb", _fp), ("rm", _fp), ("rv", _fp),
+    _fields_ = [("x", _fp), ("w", _fp), ("b", _fp), ("nw", _fp), ("nb", _fp), ("rm", _fp), ("rv", _fp), ("nbt", _fp),
                 ("mask", _fp), ("y", _fp), ("saved", _fp), ("scratch", _fp)]
 
 
@@ -79,6 +79,7 @@ SIGNATURES = {
     "pnpp_fc_forward": (_i, [C.POINTER(FcDesc), C.POINTER(FcFwdArgs), _fp]),
     "pnpp_fc_backward": (_i, [C.POINTER(FcDesc), C.POINTER(FcBwdArgs), _fp]),
     "pnpp_vm_head_kl": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp]),
+    "pnpp_vm_head_kl_mean": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp]),
     "pnpp_vm_head_bwd": (_i, [_fp, _fp, _fp, _i, _fp, _fp]),
     "pnpp_vm_kl_single": (_i, [_fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp]),
     "pnpp_vm_match_loss": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp]),

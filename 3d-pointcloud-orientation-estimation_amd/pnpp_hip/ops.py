@@ -46,6 +46,17 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _nbt(bn) -> Optional[torch.Tensor]:
+    """A BatchNorm's num_batches_tracked as the int64 device scalar the kernels increment (None when it is not tracked)."""
+    t = getattr(bn, "num_batches_tracked", None)
+    if t is None:
+        return None
+    _need_gpu(t, "num_batches_tracked")
+    if t.dtype != torch.int64:
+        raise TypeError(f"num_batches_tracked must be int64, got {t.dtype}")
+    return t
+
+
 _scratch_cache = {}
 
 
@@ -110,7 +121,11 @@ def sample_random(seed: int, stream_id: int, B: int, N: int, npoint: int, device
 
 
 def sample_random_dev(seed: int, counter: torch.Tensor, offset: int, B: int, N: int, npoint: int) -> torch.Tensor:
-    """Like sample_random, with the stream id read from the int64 device tensor `counter` at kernel time."""
+    """Like sample_random, with stream id = counter[0] + offset read at kernel time; the kernel then adds 1 to
+    counter[0].  `counter` is an int64 device tensor of two words (call counter, ticket word kept at zero)."""
+    _need_gpu(counter, "counter")
+    if counter.dtype != torch.int64 or counter.numel() != 2 or not counter.is_contiguous():
+        raise ValueError("counter must be a contiguous int64 tensor of 2 elements")
     out = torch.empty(B, npoint, device=counter.device, dtype=torch.int32)
     L.check(L.lib().pnpp_sample_random_dev(int(seed) & (2**64 - 1), counter.data_ptr(), int(offset) & (2**64 - 1), B, N,
                                            int(npoint), out.data_ptr(), _stream()))
@@ -170,7 +185,7 @@ class _SetAbstraction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, points, centre_idx, neighbour_idx, cfg, running, *params):
         # params: L x (conv_w, conv_b, bn_w, bn_b); running: L x (running_mean, running_var)
-        K, group_all, training, eps, momentum, sinks = cfg
+        K, group_all, training, eps, momentum, sinks, nbt = cfg
         Lh = len(params) // 4
         xyz = _f32(xyz, "xyz")
         B, N, _ = xyz.shape
@@ -206,6 +221,7 @@ class _SetAbstraction(torch.autograd.Function):
         a.conv_w, a.conv_b, a.bn_w, a.bn_b = _ptr_array(conv_w), _ptr_array(conv_b), _ptr_array(bn_w), _ptr_array(bn_b)
         a.bn_rm = _ptr_array([running[2 * l] for l in range(Lh)])
         a.bn_rv = _ptr_array([running[2 * l + 1] for l in range(Lh)])
+        a.bn_nbt = _ptr_array(nbt if nbt is not None else [None] * Lh)
         a.new_xyz, a.out, a.saved, a.scratch = new_xyz.data_ptr(), out.data_ptr(), saved.data_ptr(), scratch.data_ptr()
         L.check(lib.pnpp_sa_forward(C.byref(desc), C.byref(a), _stream()))
         ctx.desc = desc
@@ -218,12 +234,15 @@ class _SetAbstraction(torch.autograd.Function):
             off = lib.pnpp_sa_saved_neighbours(C.byref(desc), saved.data_ptr()) - saved.data_ptr()
             nbr = saved[off:off + 4 * B * S * Kk].view(torch.int32).view(B, S, Kk)
         ctx.mark_non_differentiable(new_xyz, nbr)
+        ctx.set_materialize_grads(False)  # no zero tensors (= fill launches) for the two outputs that carry no gradient
         return new_xyz, out, nbr
 
     @staticmethod
     def backward(ctx, _dnew_xyz, dout, _dnbr):
         desc = ctx.desc
         Lh = desc.L
+        if dout is None:
+            return (None,) * (6 + 4 * Lh)
         t = ctx.saved_tensors
         xyz, points, saved = t[0], (t[1] if ctx.has_points else None), t[2]
         conv_w, bn_w, bn_b = t[3:3 + Lh], t[3 + Lh:3 + 2 * Lh], t[3 + 2 * Lh:3 + 3 * Lh]
@@ -269,12 +288,9 @@ def set_abstraction(xyz, points, centre_idx, nsample, group_all, training, convs
     eps = bns[0].eps
     momentum = bns[0].momentum if bns[0].momentum is not None else 0.1
     sinks = [getattr(p, "_pnpp_grad_sink", None) for p in params]
-    cfg = (nsample, bool(group_all), bool(training), eps, momentum, sinks if any(s is not None for s in sinks) else None)
+    nbt = [_nbt(bn) for bn in bns] if training else None   # bumped by the statistics kernels themselves
+    cfg = (nsample, bool(group_all), bool(training), eps, momentum, sinks if any(s is not None for s in sinks) else None, nbt)
     new_xyz, out, nbr = _SetAbstraction.apply(xyz, points, centre_idx, neighbour_idx, cfg, running, *params)
-    if training:
-        nbt = [bn.num_batches_tracked for bn in bns if bn.num_batches_tracked is not None]
-        if nbt:
-            torch._foreach_add_(nbt, 1)
     if return_neighbours:
         return new_xyz, out, (None if group_all else nbr)
     return new_xyz, out
@@ -286,7 +302,7 @@ def set_abstraction(xyz, points, centre_idx, nsample, group_all, training, convs
 class _FcBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, nw, nb, rm, rv, mask, cfg):
-        norm, relu, training, eps, momentum, drop_scale, sinks = cfg
+        norm, relu, training, eps, momentum, drop_scale, sinks, nbt = cfg
         x, w, b = _f32(x, "x"), _f32(w, "weight"), _f32(b, "bias")
         M, K = x.shape
         N = w.shape[0]
@@ -306,7 +322,7 @@ class _FcBlock(torch.autograd.Function):
             mask = mask.contiguous()
         a = L.FcFwdArgs()
         a.x, a.w, a.b, a.nw, a.nb = x.data_ptr(), w.data_ptr(), b.data_ptr(), _p(nw), _p(nb)
-        a.rm, a.rv, a.mask = _p(rm), _p(rv), _p(mask)
+        a.rm, a.rv, a.nbt, a.mask = _p(rm), _p(rv), _p(nbt), _p(mask)
         a.y, a.saved, a.scratch = y.data_ptr(), saved.data_ptr(), scratch.data_ptr()
         L.check(lib.pnpp_fc_forward(C.byref(d), C.byref(a), _stream()))
         ctx.desc = d
@@ -361,7 +377,7 @@ def fc_block(x, linear, norm=None, relu=False, dropout=None, training=True, mask
         raise TypeError(f"unsupported norm module {type(norm).__name__}")
     drop_scale = 1.0
     if training and mask is None and dropout is not None and dropout.p > 0:
-        mask = (torch.rand(x.shape[0], linear.weight.shape[0], device=x.device) >= dropout.p).to(torch.uint8)
+        mask = torch.empty(x.shape[0], linear.weight.shape[0], device=x.device, dtype=torch.uint8).bernoulli_(1.0 - dropout.p)
     if mask is not None:
         if not training:
             mask = None
@@ -370,11 +386,9 @@ def fc_block(x, linear, norm=None, relu=False, dropout=None, training=True, mask
             drop_scale = 1.0 / (1.0 - p)
             mask = mask.to(device=x.device, dtype=torch.uint8)
     sinks = tuple(getattr(p, "_pnpp_grad_sink", None) if p is not None else None for p in (linear.weight, linear.bias, nw, nb))
-    cfg = (kind, relu, training, eps, momentum, drop_scale, sinks if any(s is not None for s in sinks) else None)
-    y = _FcBlock.apply(x, linear.weight, linear.bias, nw, nb, rm, rv, mask, cfg)
-    if training and kind == L.NORM_BATCH and norm.num_batches_tracked is not None:
-        norm.num_batches_tracked += 1
-    return y
+    nbt = _nbt(norm) if (training and kind == L.NORM_BATCH) else None   # bumped by the statistics kernel itself
+    cfg = (kind, relu, training, eps, momentum, drop_scale, sinks if any(s is not None for s in sinks) else None, nbt)
+    return _FcBlock.apply(x, linear.weight, linear.bias, nw, nb, rm, rv, mask, cfg)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -439,6 +453,44 @@ def vm_head_kl_fused(o, mu_gt, kappa_gt):
     L.check(L.lib().pnpp_vm_head_kl(o.data_ptr(), mu_gt.data_ptr(), kappa_gt.data_ptr(), B, mu.data_ptr(), kappa.data_ptr(),
                                     lv.data_ptr(), d_o.data_ptr(), _stream()))
     return mu, kappa, lv, d_o
+
+
+class _VmHeadKlLoss(torch.autograd.Function):
+    """Raw fc3 output -> KL loss (per sample or batch mean) with the head, the loss and their gradient in one launch."""
+
+    @staticmethod
+    def forward(ctx, o, mu_gt, kappa_gt, mean):
+        o, mu_gt, kappa_gt = _f32(o, "o"), _f32(mu_gt, "mu_gt"), _f32(kappa_gt, "kappa_gt")
+        B = o.shape[0]
+        if o.dim() != 2 or o.shape[1] != 2 or mu_gt.numel() != B or kappa_gt.numel() != B:
+            raise ValueError(f"vm_head_kl_loss: o must be (B,2) and the targets (B,), got {tuple(o.shape)}, "
+                             f"{tuple(mu_gt.shape)}, {tuple(kappa_gt.shape)}")
+        d_o = torch.empty_like(o)
+        ctx.mean = bool(mean)
+        if mean:
+            loss = torch.empty((), device=o.device, dtype=torch.float32)
+            L.check(L.lib().pnpp_vm_head_kl_mean(o.data_ptr(), mu_gt.data_ptr(), kappa_gt.data_ptr(), B, None, None, None,
+                                                 loss.data_ptr(), d_o.data_ptr(), _stream()))
+        else:
+            loss = torch.empty(B, device=o.device, dtype=torch.float32)
+            mu, kappa = torch.empty_like(loss), torch.empty_like(loss)
+            L.check(L.lib().pnpp_vm_head_kl(o.data_ptr(), mu_gt.data_ptr(), kappa_gt.data_ptr(), B, mu.data_ptr(),
+                                            kappa.data_ptr(), loss.data_ptr(), d_o.data_ptr(), _stream()))
+        ctx.save_for_backward(d_o)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_o,) = ctx.saved_tensors
+        return (g * d_o if ctx.mean else g[:, None] * d_o), None, None, None
+
+
+def vm_head_kl_loss(o, mu_gt, kappa_gt, reduction: str = "mean"):
+    """KL(vM(head(o)) || vM(mu_gt, kappa_gt)) from the raw fc3 output `o` (B,2): pointnet_pp_vonMises.py:36-37 +
+    train_single_peak_vonMises_KL.py:23-28 (+ the `.mean()` of line 83 for reduction="mean") in one launch."""
+    if reduction not in ("mean", "none"):
+        raise ValueError(f"reduction must be 'mean' or 'none', got {reduction!r}")
+    return _VmHeadKlLoss.apply(o, mu_gt, kappa_gt, reduction == "mean")
 
 
 class _MatchLoss(torch.autograd.Function):

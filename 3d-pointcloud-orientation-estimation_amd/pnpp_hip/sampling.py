@@ -1,8 +1,8 @@
 """Device-side centre sampling (throughput mode of models/pointnet_pp_8dir.py:28).
 
 `torch.manual_seed(s)` still controls the draw: the kernel's Philox key is the CPU generator's initial seed, its
-counter is (rank << 40) + a call counter.  The call counter lives in DEVICE memory and is bumped by a device-side
-add before every draw, so a step captured into a hipGraph draws fresh, reproducible centres on every replay and
+counter is (rank << 40) + a call counter.  The call counter lives in DEVICE memory and is post-incremented by the
+sampling kernel itself, so a step captured into a hipGraph draws fresh, reproducible centres on every replay and
 every rank under data parallelism gets an independent stream -- all without touching the host generator."""
 import torch
 
@@ -17,7 +17,7 @@ def set_rank(rank: int) -> None:
 
 def reset(calls: int = 0) -> None:
     for c in _state["counters"].values():
-        c.fill_(int(calls))
+        c.copy_(torch.tensor([int(calls), 0], dtype=torch.int64))   # [call counter, ticket word of the kernel]
 
 
 def _counter(device) -> torch.Tensor:
@@ -25,12 +25,11 @@ def _counter(device) -> torch.Tensor:
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     c = _state["counters"].get(key)
     if c is None:
-        c = torch.zeros(1, dtype=torch.int64, device=device)
+        c = torch.zeros(2, dtype=torch.int64, device=device)         # [call counter, ticket word of the kernel]
         _state["counters"][key] = c
     return c
 
 
 def device_random_centres(B: int, N: int, npoint: int, device) -> torch.Tensor:
-    c = _counter(device)
-    c.add_(1)                                   # device-side: captured into graphs like any other launch
-    return ops.sample_random_dev(torch.initial_seed(), c, _state["rank"] << 40, B, N, npoint)
+    # stream id = (rank << 40) + 1 + calls so far; the kernel bumps the counter after reading it
+    return ops.sample_random_dev(torch.initial_seed(), _counter(device), (_state["rank"] << 40) + 1, B, N, npoint)

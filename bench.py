@@ -40,9 +40,8 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph):
     capture succeeds (falls back to eager launches otherwise); the all-reduce and the fused Adam follow eagerly."""
     from pnpp_hip import ops, dist as pdist
 
-    def loss_fn(x, m, k):
-        mu, kappa = model(x)
-        return ops.kl_von_mises_single(mu, kappa, m, k).mean()
+    def loss_fn(x, m, k):   # head + KL + .mean() (train_single_peak_vonMises_KL.py:82-83) as one fused launch
+        return ops.vm_head_kl_loss(model.features(x), m, k, reduction="mean")
 
     graphed = None
     if use_graph:
@@ -74,9 +73,8 @@ def kernel_cost(tag: str):
         return None
     M, N, K = (int(x) for x in m.groups())
     flops = 2.0 * M * N * K
-    if tag.startswith("gemm_kernel"):
-        e = int(re.search(r",E(\d)>", tag).group(1))
-        a = int(re.search(r",A(\d),", tag).group(1))
+    if tag.startswith(("gemm_kernel", "gemm_ws_kernel", "gemm_smallm_kernel")):
+        a, e = (int(x) for x in re.search(r"A(\d),E(\d)", tag).groups())
         byts = 4.0 * (M * N + K * N)                      # write C, read weights
         byts += 4.0 * M * K * (2 if a == 4 else 1)        # read A (dy and z for the BatchNorm-backward operand; A5: z only,
                                                            # the pooled gradient it is rebuilt from is G x C and L2-resident)
@@ -84,6 +82,10 @@ def kernel_cost(tag: str):
             byts = 4.0 * (M * N + K * N) + 4.0 * M
         if e == 2:
             byts += 4.0 * M * N                            # read the previous layer's z for the ReLU mask
+        if ",dW>" in tag:                                  # fused weight gradient: second GEMM on the tiles already in LDS,
+            flops *= 2.0                                   # one K x N partial per persistent worker
+            g = re.search(r"grid=(\d+)x(\d+)", tag)
+            byts += 4.0 * K * N * int(g.group(1)) * int(g.group(2)) / max(1, N // 64)
         return flops, byts
     if tag.startswith("dw_kernel"):
         a2 = int(re.search(r",A(\d)>", tag).group(1))

@@ -75,10 +75,11 @@ int pnpp_ball_query(const float *new_xyz, const float *xyz, int B, int S, int N,
  * calls (throughput mode; parity mode replays the CPU generator on the host and passes the indices in).
  * Counter-based: the result is a pure function of (seed, stream_id, b).  out (B,npoint) int32. */
 int pnpp_sample_random(uint64_t seed, uint64_t stream_id, int B, int N, int npoint, int32_t *out, void *stream);
-/* Same, with the stream id read from DEVICE memory at kernel time (stream_id = *stream_id_dev + offset): the launch
- * can be captured into a hipGraph and still draw fresh centres on every replay (the host bumps the counter with a
- * captured device-side add). */
-int pnpp_sample_random_dev(uint64_t seed, const uint64_t *stream_id_dev, uint64_t offset, int B, int N, int npoint,
+/* Same, with the stream id read from DEVICE memory at kernel time: stream_id = stream_id_dev[0] + offset, and the
+ * kernel post-increments stream_id_dev[0] once every workgroup has read it -- the launch can be captured into a
+ * hipGraph and still draws fresh centres on every replay.  stream_id_dev points at TWO uint64 words: the counter and
+ * a ticket word that must be zero before the first call (the kernel leaves it zero). */
+int pnpp_sample_random_dev(uint64_t seed, uint64_t *stream_id_dev, uint64_t offset, int B, int N, int npoint,
                            int32_t *out, void *stream);
 
 /* models/base.py:4-18  index_points(points (B,N,C), idx (B,M)) -> out (B,M,C); idx is int32, flattened
@@ -120,6 +121,7 @@ typedef struct {
     const float *bn_b[PNPP_MAX_LAYERS];     /* beta                                                 */
     float *bn_rm[PNPP_MAX_LAYERS];          /* running_mean (updated in training)                   */
     float *bn_rv[PNPP_MAX_LAYERS];          /* running_var  (updated in training)                   */
+    int64_t *bn_nbt[PNPP_MAX_LAYERS];       /* num_batches_tracked (+1 in training) or NULL         */
     float *new_xyz;            /* out (B,S,3)                                                      */
     float *out;                /* out (B,S,C[L-1])                                                 */
     void *saved;               /* activations kept for backward, pnpp_sa_saved_bytes()             */
@@ -170,6 +172,7 @@ typedef struct {
     const float *b;      /* (N)                                                                    */
     const float *nw, *nb;/* norm affine (N) or NULL                                                */
     float *rm, *rv;      /* BatchNorm running stats or NULL                                        */
+    int64_t *nbt;        /* BatchNorm num_batches_tracked (+1 in training) or NULL                 */
     const uint8_t *mask; /* (M,N) dropout keep-mask or NULL                                        */
     float *y;            /* out (M,N)                                                              */
     void *saved;         /* pnpp_fc_saved_bytes()                                                  */
@@ -203,6 +206,11 @@ int pnpp_fc_backward(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, void *str
  * d_o (B,2) = d loss_vec[b] / d o[b,:]  (the host scales by the upstream gradient, 1/B for .mean()). */
 int pnpp_vm_head_kl(const float *o, const float *mu_gt, const float *kappa_gt, int B, float *mu, float *kappa,
                     float *loss_vec, float *d_o, void *stream);
+/* The same, followed by the batch mean of train_single_peak_vonMises_KL.py:83 (`loss = kl_von_mises(...).mean()`),
+ * in one single-workgroup launch: loss_mean[0] = mean_b loss_vec[b] (fixed-order fp64 sum),
+ * d_o_mean (B,2) = d loss_mean / d o.  mu, kappa and loss_vec may be NULL. */
+int pnpp_vm_head_kl_mean(const float *o, const float *mu_gt, const float *kappa_gt, int B, float *mu, float *kappa,
+                         float *loss_vec, float *loss_mean, float *d_o_mean, void *stream);
 /* backward of the activation alone: d_o[b] = (dmu[b]*pi*(1-tanh^2 o0), dkappa[b]*sigmoid(o1)). */
 int pnpp_vm_head_bwd(const float *o, const float *dmu, const float *dkappa, int B, float *d_o, void *stream);
 

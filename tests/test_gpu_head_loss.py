@@ -79,6 +79,42 @@ def test_vm_head_and_fused_head_kl(ops, oracle):
     assert torch.allclose(d_o, og.grad, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("B", [1, 32, 300])
+def test_vm_head_kl_loss_op(ops, oracle, B):
+    """Head + KL (+ batch mean) and their gradient in one launch, against the fp64 oracle; B=300 exercises the
+    strided loop and the fixed-order reduction of the single-workgroup kernel."""
+    g = torch.Generator().manual_seed(B)
+    o = torch.randn(B, 2, generator=g) * 3
+    mu_gt = (torch.rand(B, generator=g) * 2 - 1) * math.pi
+    kap_gt = torch.where(torch.rand(B, generator=g) < 0.3, torch.zeros(B), torch.full((B,), 8.0))
+    od = o.double().requires_grad_(True)
+    lv_ref = oracle.kl_single(torch.tanh(od[:, 0]) * math.pi, torch.nn.functional.softplus(od[:, 1]), mu_gt.double(),
+                              kap_gt.double())
+    lv_ref.mean().backward()
+    og = o.clone().cuda().requires_grad_(True)
+    loss = ops.vm_head_kl_loss(og, mu_gt.cuda(), kap_gt.cuda(), reduction="mean")
+    assert loss.shape == ()
+    loss.backward()
+    assert abs(float(loss) - float(lv_ref.mean())) <= 1e-5 * max(1.0, abs(float(lv_ref.mean())))
+    gref = od.grad.numpy()
+    assert np.all(np.abs(og.grad.cpu().double().numpy() - gref) <= 1e-5 * np.maximum(1.0 / B, np.abs(gref)))
+    # per-sample form, with a non-trivial upstream gradient
+    og2 = o.clone().cuda().requires_grad_(True)
+    lv = ops.vm_head_kl_loss(og2, mu_gt.cuda(), kap_gt.cuda(), reduction="none")
+    wts = torch.rand(B, generator=g)
+    (lv * wts.cuda()).sum().backward()
+    od2 = o.double().requires_grad_(True)
+    (oracle.kl_single(torch.tanh(od2[:, 0]) * math.pi, torch.nn.functional.softplus(od2[:, 1]), mu_gt.double(),
+                      kap_gt.double()) * wts.double()).sum().backward()
+    assert np.all(np.abs(lv.detach().cpu().double().numpy() - lv_ref.detach().numpy())
+                  <= 1e-5 * np.maximum(1, np.abs(lv_ref.detach().numpy())))
+    assert np.all(np.abs(og2.grad.cpu().double().numpy() - od2.grad.numpy()) <= 1e-5 * np.maximum(1, np.abs(od2.grad.numpy())))
+    with pytest.raises(ValueError):
+        ops.vm_head_kl_loss(og, mu_gt.cuda(), kap_gt.cuda(), reduction="sum")
+    with pytest.raises(ValueError):
+        ops.vm_head_kl_loss(og, mu_gt[:-1].cuda() if B > 1 else torch.zeros(2).cuda(), kap_gt.cuda())
+
+
 def test_match_loss_vs_reference_fp64(ops, golden):
     g = golden("kl.npz")
     mu, kap, w = (_t(g[k]).cuda().requires_grad_(True) for k in ("match_mu", "match_kappa", "match_w"))

@@ -135,6 +135,19 @@ def test_sample_random_is_a_uniform_ordered_subset(ops):
     assert all(sorted(r) == list(range(200)) for r in p)
 
 
+def test_sample_random_device_counter(ops):
+    """The graph-capturable variant: stream id read from device memory, post-incremented by the kernel itself."""
+    B, N, S = 32, 1021, 128                                    # N not a multiple of 4: padded key slots never win
+    c = torch.tensor([5, 0], dtype=torch.int64, device="cuda")
+    for call in range(3):
+        got = ops.sample_random_dev(42, c, 1 << 40, B, N, S)
+        want = ops.sample_random(42, (1 << 40) + 5 + call, B, N, S, "cuda")
+        assert torch.equal(got, want)
+        assert c.tolist() == [5 + call + 1, 0]                 # counter bumped once per launch, ticket word back at zero
+    with pytest.raises(ValueError):
+        ops.sample_random_dev(42, torch.zeros(1, dtype=torch.int64, device="cuda"), 0, B, N, S)
+
+
 def test_index_points_forward_backward(ops, oracle):
     g = torch.Generator().manual_seed(3)
     for C in (3, 64, 130):

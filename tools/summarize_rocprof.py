@@ -29,9 +29,10 @@ def tag_of(name, gx, gy, wg):
     """bench.py-style key "<kernel and template arguments> grid=<workgroups>"; None for kernels without
     a cost model.  bench.py builds the same key from its launch tags (kernel part + grid part)."""
     g = f"grid={(gx // wg) * gy}"   # total workgroups (the counter CSV only has the flattened grid size)
-    m = re.search(r"gemm_ws_kernel<(\d+), (\d+), (\d+), \d+, \d+, (\d+), (\d+)>", name)
+    m = re.search(r"gemm_ws_kernel<(\d+), (\d+), (\d+), \d+, \d+, (\d+), (\d+), (true|false)>", name)
     if m:
-        return f"gemm_ws_kernel<{m.group(1)},{m.group(2)},{m.group(3)},A{m.group(4)},E{m.group(5)}> {g}"
+        dw = ",dW" if m.group(6) == "true" else ""
+        return f"gemm_ws_kernel<{m.group(1)},{m.group(2)},{m.group(3)},A{m.group(4)},E{m.group(5)}{dw}> {g}"
     m = re.search(r"gemm_smallm_kernel<(\d+), (\d+), (true|false)>", name)
     if m:
         return f"gemm_smallm_kernel<A{m.group(1)},E{m.group(2)},T{1 if m.group(3) == 'true' else 0}> {g}"
