@@ -215,34 +215,44 @@ __device__ __forceinline__ float fc_small_dz(const float *dy, const float *z, co
     return g;
 }
 
-// dW[n][k] = sum_m dz[m][n] x[m][k];  db[n] = sum_m dz[m][n]      grid (N), threads over k
-__global__ void __launch_bounds__(256) fc_small_dw_kernel(const float *__restrict__ dy, const float *__restrict__ z,
-                                                          const float *__restrict__ b, const uint8_t *__restrict__ mask,
-                                                          float drop_scale, int relu, const float *__restrict__ x, int M,
-                                                          int K, int N, float *__restrict__ dw, float *__restrict__ db) {
-    const int n = blockIdx.x;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        double acc = 0.0;
-        for (int m = 0; m < M; ++m)
-            acc += (double)fc_small_dz(dy, z, b, mask, drop_scale, relu, (size_t)m * N + n, n) * (double)x[(size_t)m * K + k];
-        dw[(size_t)n * K + k] = (float)acc;
+// One launch for the whole backward of a narrow layer.  Workgroups [0, N * kparts): dW[n][k] = sum_m dz[m][n] x[m][k]
+// for one n and one 256-wide k range (the first range of every n also writes db[n] = sum_m dz[m][n]); the dz column
+// is staged in LDS once, so the m loop is independent loads.  Workgroups after those: dx[m][:] = sum_n dz[m][n] w[n][:].
+__global__ void __launch_bounds__(256) fc_small_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ z,
+                                                           const float *__restrict__ b, const uint8_t *__restrict__ mask,
+                                                           float drop_scale, int relu, const float *__restrict__ x,
+                                                           const float *__restrict__ w, int M, int K, int N, int kparts,
+                                                           float *__restrict__ dw, float *__restrict__ db,
+                                                           float *__restrict__ dx) {
+    __shared__ float dzc[1024];
+    const int ndw = N * kparts;
+    if ((int)blockIdx.x < ndw) {
+        const int n = blockIdx.x / kparts, k = (blockIdx.x % kparts) * 256 + threadIdx.x;
+        double acc = 0.0, accb = 0.0;
+        for (int m0 = 0; m0 < M; m0 += 1024) {  // M rows in LDS-sized pieces (a training batch is one piece)
+            const int mc = min(1024, M - m0);
+            __syncthreads();
+            for (int m = threadIdx.x; m < mc; m += 256)
+                dzc[m] = fc_small_dz(dy, z, b, mask, drop_scale, relu, (size_t)(m0 + m) * N + n, n);
+            __syncthreads();
+            if (k < K) {
+                const float *xc = x + (size_t)m0 * K + k;
+#pragma unroll 8
+                for (int m = 0; m < mc; ++m) acc += (double)dzc[m] * (double)xc[(size_t)m * K];
+            }
+            if (threadIdx.x == 0 && blockIdx.x % kparts == 0)
+                for (int m = 0; m < mc; ++m) accb += (double)dzc[m];
+        }
+        if (k < K) dw[(size_t)n * K + k] = (float)acc;
+        if (threadIdx.x == 0 && blockIdx.x % kparts == 0) db[n] = (float)accb;
+        return;
     }
-    if (threadIdx.x == 0) {
-        double acc = 0.0;
-        for (int m = 0; m < M; ++m) acc += (double)fc_small_dz(dy, z, b, mask, drop_scale, relu, (size_t)m * N + n, n);
-        db[n] = (float)acc;
-    }
-}
-
-// dx[m][k] = sum_n dz[m][n] w[n][k]      grid (M), threads over k
-__global__ void __launch_bounds__(256) fc_small_dx_kernel(const float *__restrict__ dy, const float *__restrict__ z,
-                                                          const float *__restrict__ b, const uint8_t *__restrict__ mask,
-                                                          float drop_scale, int relu, const float *__restrict__ w, int K, int N,
-                                                          float *__restrict__ dx) {
-    const int m = blockIdx.x;
+    if (!dx) return;
+    const int m = blockIdx.x - ndw;
     float g[FC_SMALL_N];
 #pragma unroll
-    for (int n = 0; n < FC_SMALL_N; ++n) g[n] = n < N ? fc_small_dz(dy, z, b, mask, drop_scale, relu, (size_t)m * N + n, n) : 0.f;
+    for (int n = 0; n < FC_SMALL_N; ++n)
+        g[n] = fc_small_dz(dy, z, b, mask, drop_scale, relu, (size_t)m * N + min(n, N - 1), min(n, N - 1)) * (n < N ? 1.f : 0.f);
     for (int k = threadIdx.x; k < K; k += 256) {
         float acc = 0.f;
 #pragma unroll
@@ -330,8 +340,18 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     if (d->norm == PNPP_NORM_BATCH) {
         int nslab = 0;
+        if (d->training) PNPP_REQUIRE(d->M > 1, PNPP_ERR_ARG, "Expected more than 1 value per channel when training");  // torch's message
+        if (d->training && d->M <= 32) {  // the whole batch fits one tile: statistics, affine, ReLU, dropout in the GEMM epilogue
+            E.mode = E_BN_APPLY;
+            BnTail &T = E.bn;
+            T.bias = a->b, T.gamma = a->nw, T.beta = a->nb;
+            T.rm = a->rm, T.rv = a->rv, T.nbt = (long long *)a->nbt;
+            T.momentum = d->momentum, T.eps = d->eps;
+            T.mean = sv.mean, T.istd = sv.istd, T.scale = sv.scale, T.shift = sv.shift;
+            T.mask = a->mask, T.drop_scale = d->drop_scale, T.relu = d->relu, T.y = a->y;
+            return launch_gemm(A, W, d->M, d->N, d->K, E, nullptr, st);
+        }
         if (d->training) {
-            PNPP_REQUIRE(d->M > 1, PNPP_ERR_ARG, "Expected more than 1 value per channel when training");  // torch's message
             E.mode = E_STORE_STATS;
             E.slab = sc.slab;
             PNPP_TRY(launch_gemm(A, W, d->M, d->N, d->K, E, &nslab, st));
@@ -368,11 +388,9 @@ static int fc_backward_impl(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, hi
 
     if (fc_is_small(d)) {
         ProfScope ps(st, "fc_small_bwd M=%d N=%d K=%d", d->M, d->N, d->K);
-        hipLaunchKernelGGL(fc_small_dw_kernel, dim3(d->N), dim3(256), 0, st, a->dy, sv.z, a->b, a->mask, d->drop_scale, d->relu,
-                           a->x, d->M, d->K, d->N, a->dw, a->db);
-        if (a->dx)
-            hipLaunchKernelGGL(fc_small_dx_kernel, dim3(d->M), dim3(256), 0, st, a->dy, sv.z, a->b, a->mask, d->drop_scale,
-                               d->relu, a->w, d->K, d->N, a->dx);
+        const int kparts = cdiv(d->K, 256);
+        hipLaunchKernelGGL(fc_small_bwd_kernel, dim3(d->N * kparts + (a->dx ? d->M : 0)), dim3(256), 0, st, a->dy, sv.z, a->b,
+                           a->mask, d->drop_scale, d->relu, a->x, a->w, d->M, d->K, d->N, kparts, a->dw, a->db, a->dx);
         PNPP_CHECK_LAUNCH("fc_backward(small)");
         return PNPP_OK;
     }
@@ -402,8 +420,12 @@ static int fc_backward_impl(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, hi
     x.lda = d->K;
     int nsplit, kp_pad;
     dw_plan(d->M, d->N, d->K, &nsplit, &kp_pad);
-    PNPP_TRY(launch_dw(dz, d->N, x, d->K, d->M, sc.dwslab, nsplit, kp_pad, st));
-    PNPP_TRY(launch_slab_reduce(sc.dwslab, nsplit, d->N, kp_pad, d->K, -1, a->dw, d->K, st));
+    if (nsplit == 1 && kp_pad == d->K) {  // a single partial in the gradient's own layout: write it in place
+        PNPP_TRY(launch_dw(dz, d->N, x, d->K, d->M, a->dw, 1, kp_pad, st));
+    } else {
+        PNPP_TRY(launch_dw(dz, d->N, x, d->K, d->M, sc.dwslab, nsplit, kp_pad, st));
+        PNPP_TRY(launch_slab_reduce(sc.dwslab, nsplit, d->N, kp_pad, d->K, -1, a->dw, d->K, st));
+    }
 
     // 3. dx = dz W
     if (a->dx) {

@@ -996,6 +996,7 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
     const int ldb = B.ldb;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
     const int nchunks = (Kd + KC - 1) / KC;
+    const bool bvec = (ldb & 3) == 0 && ((uintptr_t)Bm & 15) == 0 && B.perm_D < 0 && B.rows >= 4 && (B.rows & 3) == 0;  // uniform
 
     f32x16 acc;
 #pragma unroll
@@ -1010,8 +1011,20 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
         for (int i = 0; i < 4; ++i) {
             const int r = (lane >> 3) + 8 * i, k = k0 + 4 * (lane & 7);
             na[i] = fetch_a4<AMODE>(A, m0 + r, k, M, Kd);
-            if constexpr (BT)
-                nw[i] = *reinterpret_cast<const float4 *>(Bm + (size_t)min(n0 + r, Nout - 1) * ldb + min(k, B.rows - 4));
+            if constexpr (BT) {
+                const float *wrow = Bm + (size_t)min(n0 + r, Nout - 1) * ldb;
+                if (bvec) {
+                    nw[i] = *reinterpret_cast<const float4 *>(wrow + min(k, B.rows - 4));
+                } else {  // odd pitch or the layer-0 column permutation: four scalar loads (clamped; masked when staged)
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kp = min(k + e, B.rows - 1);
+                        t[e] = wrow[B.perm_D >= 0 ? (kp < B.perm_D ? kp + 3 : kp - B.perm_D) : kp];
+                    }
+                    nw[i] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
         }
         if constexpr (!BT) {
 #pragma unroll
@@ -1081,7 +1094,53 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
         part[e] = x;
         if (ok) E.c[(size_t)row * E.ldc + col] = x;
     }
-    if constexpr (EMODE != E_STORE) {
+    if constexpr (EMODE == E_BN_APPLY) {
+        // the whole batch is in this tile: finish the BatchNorm here (same fp64 sums, in the same order, as the
+        // slab + bn_finalize_fwd route), then normalise, ReLU and mask the tile
+        const BnTail &T = E.bn;
+        float *cs = part + 2048;  // [2][32] scale / shift of this column block
+        __syncthreads();
+        if (tid < 32 && n0 + tid < Nout) {
+            const int c = n0 + tid;
+            double s1 = 0.0, s2 = 0.0;
+            for (int r = 0; r < 32; ++r) {
+                const double x = (double)part[r * 32 + tid];
+                s1 += x;
+                s2 += x * x;
+            }
+            const double count = (double)M;
+            const double mu = s1 / count;
+            double var = s2 / count - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const double is = 1.0 / sqrt(var + (double)T.eps);
+            const double g = T.gamma ? (double)T.gamma[c] : 1.0, bt = T.beta ? (double)T.beta[c] : 0.0;
+            const float sc = (float)(g * is), sh = (float)(bt - mu * g * is);
+            T.mean[c] = (float)mu;
+            T.istd[c] = (float)is;
+            T.scale[c] = sc;
+            T.shift[c] = sh;
+            cs[tid] = sc;
+            cs[32 + tid] = sh;
+            if (T.rm) {
+                const double bmean = mu + (T.bias ? (double)T.bias[c] : 0.0);  // the linear bias was folded out of z
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                T.rm[c] = (float)((1.0 - (double)T.momentum) * (double)T.rm[c] + (double)T.momentum * bmean);
+                T.rv[c] = (float)((1.0 - (double)T.momentum) * (double)T.rv[c] + (double)T.momentum * unbiased);
+            }
+        }
+        if (T.nbt && blockIdx.x == 0 && tid == 0) *T.nbt += 1;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j, row = m0 + e / 32, col = n0 + e % 32;
+            if (row < M && col < Nout) {
+                float y = fmaf(part[e], cs[e % 32], cs[32 + e % 32]);
+                if (T.relu) y = fmaxf(y, 0.f);
+                if (T.mask) y = T.mask[(size_t)row * E.ldc + col] ? y * T.drop_scale : 0.f;
+                T.y[(size_t)row * E.ldc + col] = y;
+            }
+        }
+    } else if constexpr (EMODE != E_STORE) {
         __syncthreads();
         if (tid < 32 && n0 + tid < Nout) {
             double s1 = 0.0, s2 = 0.0;
@@ -1110,6 +1169,14 @@ static int launch_smallm_e(const AOperand &A, const BOperand &B, int M, int Nout
         case E_STORE: launch_smallm_t<AM, E_STORE>(A, B, M, Nout, Kd, E, grid, st); return PNPP_OK;
         case E_STORE_STATS: launch_smallm_t<AM, E_STORE_STATS>(A, B, M, Nout, Kd, E, grid, st); return PNPP_OK;
         case E_MASK_STATS: launch_smallm_t<AM, E_MASK_STATS>(A, B, M, Nout, Kd, E, grid, st); return PNPP_OK;
+        case E_BN_APPLY:
+            if constexpr (AM == A_PLAIN) {
+                PNPP_REQUIRE(grid.y == 1 && E.bn.mean && E.bn.istd && E.bn.scale && E.bn.shift && E.bn.y, PNPP_ERR_ARG,
+                             "gemm(small M): the BatchNorm epilogue needs all rows in one tile (M <= 32) and its outputs");
+                launch_smallm_t<AM, E_BN_APPLY>(A, B, M, Nout, Kd, E, grid, st);
+                return PNPP_OK;
+            }
+            break;
     }
     set_error("gemm(small M): bad epilogue mode %d", E.mode);
     return PNPP_ERR_ARG;
@@ -1162,9 +1229,8 @@ int launch_gemm(const AOperand &A, const BOperand &Bin, int M, int Nout, int Kd,
         int rc = PNPP_OK;
         if (try_launch_ws(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;
     }
-    const bool b_aligned = (B.ldb % 4 == 0) && (((uintptr_t)B.b & 15) == 0) && B.perm_D < 0;
     const bool a_aligned = (A.mode == A_CONCAT || A.mode == A_GATHER) || (A.lda % 4 == 0 && ((uintptr_t)A.a & 15) == 0);
-    if (M <= 4096 && cdiv(M, 32) <= kMaxStatBlocks && b_aligned && a_aligned && A.mode != A_GATHER) {
+    if (M <= 4096 && cdiv(M, 32) <= kMaxStatBlocks && a_aligned && A.mode != A_GATHER) {
         // split-K 32x32 tiles: the fully connected head (M = batch) and the group_all layers (M = B * 32)
         const dim3 grid(cdiv(Nout, 32), cdiv(M, 32));
         if (nslab) *nslab = grid.y;

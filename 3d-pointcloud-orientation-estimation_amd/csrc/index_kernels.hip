@@ -304,8 +304,7 @@ __global__ void __launch_bounds__(256) ball_query_kernel(const float *__restrict
 // ---------------------------------------------------------------------------------------------
 // device-side centre sampling: uniform random ordered subset (replaces B host randperm calls).
 // key(n) = Philox4x32-10(counter = (n, b, stream_lo, stream_hi), key = seed); rank by (key, n);
-// out[rank] = n for rank < npoint.  O(N^2) compares per cloud against an LDS-resident key table
-// (broadcast reads), fully deterministic.
+// out[rank] = n for rank < npoint.  Fully deterministic (a pure function of seed, stream id and cloud).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned philox_key(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
 #pragma unroll
@@ -323,43 +322,66 @@ __device__ __forceinline__ unsigned philox_key(unsigned c0, unsigned c1, unsigne
     return c0;
 }
 
+// One workgroup per cloud.  Only the npoint smallest keys matter, so the keys are first cut at a threshold that keeps
+// about 2 npoint + 64 of them (all of them when that is >= N); the survivors go to LDS as 64-bit (key, index) words --
+// the lexicographic order of the reference rank -- and each survivor counts the survivors below it.  A cloud whose
+// cut kept fewer than npoint keys (a > 8 sigma event) is redone without the cut, so the result never depends on it.
 __global__ void __launch_bounds__(256) sample_random_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_lo,
                                                             unsigned str_hi, unsigned long long *__restrict__ str_dev,
                                                             int N, int npoint, int32_t *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned keys[];
-    const int b = blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) unsigned long long cand[];
+    __shared__ int nc_s;
+    const int b = blockIdx.x;
     if (str_dev) {  // stream id lives in device memory (graph replays draw fresh centres): str_dev[0] + (str_hi:str_lo)
         const unsigned long long sid = str_dev[0] + (((unsigned long long)str_hi << 32) | str_lo);
         str_lo = (unsigned)sid, str_hi = (unsigned)(sid >> 32);
     }
-    const int Np = (N + 3) & ~3;  // padding keys are the maximum and sit behind every real index: they never count
-    for (int n = threadIdx.x; n < Np; n += 256)
-        keys[n] = n < N ? philox_key((unsigned)n, (unsigned)b, str_lo, str_hi, seed_lo, seed_hi) : 0xffffffffu;
-    __syncthreads();
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n < N) {
-        const unsigned mine = keys[n];
-        int rank = 0;
-        const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
-#pragma unroll 4
-        for (int m4 = 0; m4 < Np / 4; ++m4) {  // one 16-byte LDS broadcast per four candidates
-            const uint4 o = k4[m4];
-            const int m = 4 * m4;
-            rank += (o.x < mine) || (o.x == mine && m < n);
-            rank += (o.y < mine) || (o.y == mine && m + 1 < n);
-            rank += (o.z < mine) || (o.z == mine && m + 2 < n);
-            rank += (o.w < mine) || (o.w == mine && m + 3 < n);
+    const double keep = (2.0 * npoint + 64.0) / (double)N;
+    unsigned cut = keep >= 1.0 ? 0xffffffffu : (unsigned)(keep * 4294967296.0);
+    int nc;
+    for (;;) {
+        if (threadIdx.x == 0) nc_s = 0;
+        __syncthreads();
+        for (int n0 = 0; n0 < N; n0 += 256) {  // wave-level compaction: one LDS atomic per wave and pass
+            const int n = n0 + threadIdx.x;
+            const unsigned k = n < N ? philox_key((unsigned)n, (unsigned)b, str_lo, str_hi, seed_lo, seed_hi) : 0u;
+            const bool keepit = n < N && k <= cut;
+            const unsigned long long vote = __ballot(keepit);
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == 0 && vote) base = atomicAdd(&nc_s, __popcll(vote));
+            base = __shfl(base, 0, 64);
+            if (keepit) cand[base + __popcll(vote & ((1ull << lane) - 1ull))] = ((unsigned long long)k << 32) | (unsigned)n;
         }
-        if (rank < npoint) out[(size_t)b * npoint + rank] = n;
+        __syncthreads();
+        nc = nc_s;
+        if (nc >= npoint || cut == 0xffffffffu) break;  // uniform: nc_s is the same for every lane
+        cut = 0xffffffffu;
+        __syncthreads();
+    }
+    if (nc & 1) {  // pad to an even count with a word above every real one
+        if (threadIdx.x == 0) cand[nc] = ~0ull;
+        __syncthreads();
+    }
+    const int nc2 = (nc + 1) >> 1;
+    const ulonglong2 *c2 = reinterpret_cast<const ulonglong2 *>(cand);
+    for (int i = threadIdx.x; i < nc; i += 256) {
+        const unsigned long long mine = cand[i];
+        int rank = 0;
+#pragma unroll 4
+        for (int j = 0; j < nc2; ++j) {  // one 16-byte LDS broadcast per two candidates
+            const ulonglong2 o = c2[j];
+            rank += (o.x < mine) + (o.y < mine);
+        }
+        if (rank < npoint) out[(size_t)b * npoint + rank] = (int32_t)(unsigned)mine;
     }
     if (str_dev) {
         // post-increment of the device counter: every workgroup has read str_dev[0] before it takes a ticket, so
         // the workgroup that takes the last ticket can bump the counter (and clear the ticket word for the next launch)
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned total = gridDim.x * gridDim.y;
             const unsigned long long t = atomicAdd(&str_dev[1], 1ull);
-            if (t == total - 1) {
+            if (t == gridDim.x - 1) {
                 str_dev[1] = 0ull;
                 str_dev[0] += 1ull;
             }
@@ -547,13 +569,13 @@ static int sample_random_impl(uint64_t seed, uint64_t stream_id, uint64_t *strea
     PNPP_REQUIRE(out, PNPP_ERR_ARG, "sample_random: null pointer");
     PNPP_REQUIRE(B > 0 && N > 0 && npoint > 0, PNPP_ERR_ARG, "sample_random: non-positive size");
     PNPP_REQUIRE(npoint <= N, PNPP_ERR_RANGE, "sample_random: npoint=%d > N=%d", npoint, N);
-    PNPP_REQUIRE((size_t)N * 4 <= 128 * 1024, PNPP_ERR_ARG, "sample_random: N=%d too large", N);
+    PNPP_REQUIRE((size_t)(N + 1) * 8 <= 128 * 1024, PNPP_ERR_ARG, "sample_random: N=%d too large", N);
     PNPP_REQUIRE(B <= 65535, PNPP_ERR_ARG, "sample_random: batch exceeds grid limit");
-    const size_t lds = (size_t)((N + 3) & ~3) * sizeof(unsigned);
+    const size_t lds = (size_t)(N + 1) * sizeof(unsigned long long);
     if (lds > 48 * 1024)
         hipFuncSetAttribute((const void *)sample_random_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     ProfScope ps(as_stream(stream), "sample_random_kernel B=%d N=%d npoint=%d", B, N, npoint);
-    hipLaunchKernelGGL(sample_random_kernel, dim3(cdiv(N, 256), B), dim3(256), lds, as_stream(stream), (unsigned)seed,
+    hipLaunchKernelGGL(sample_random_kernel, dim3(B), dim3(256), lds, as_stream(stream), (unsigned)seed,
                        (unsigned)(seed >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32),
                        reinterpret_cast<unsigned long long *>(stream_id_dev), N, npoint, out);
     PNPP_CHECK_LAUNCH("sample_random");

@@ -39,7 +39,21 @@ struct AOperand {
 enum EMode {
     E_STORE = 0,        // C[row][col] = acc
     E_STORE_STATS = 1,  // + per-column sum / sum of squares (float64 partials -> slab)
-    E_MASK_STATS = 2    // v = acc * [scale*Zp+shift > 0]; C = v; stats: sum v, sum v * xhat(Zp)
+    E_MASK_STATS = 2,   // v = acc * [scale*Zp+shift > 0]; C = v; stats: sum v, sum v * xhat(Zp)
+    E_BN_APPLY = 3      // small-M kernel, all rows in one tile (M <= 32): train-mode BatchNorm1d statistics, running
+                        // update, affine, ReLU and dropout mask in the epilogue (C = pre-BN z, Epilogue::bn.y = output)
+};
+
+struct BnTail {  // E_BN_APPLY: the fully connected head's Linear -> BatchNorm1d -> ReLU -> Dropout in one launch
+    const float *bias = nullptr, *gamma = nullptr, *beta = nullptr;
+    float *rm = nullptr, *rv = nullptr;
+    long long *nbt = nullptr;
+    float momentum = 0.1f, eps = 1e-5f;
+    float *mean = nullptr, *istd = nullptr, *scale = nullptr, *shift = nullptr;  // outputs kept for backward
+    const uint8_t *mask = nullptr;
+    float drop_scale = 1.f;
+    int relu = 0;
+    float *y = nullptr;
 };
 
 struct Epilogue {
@@ -53,6 +67,7 @@ struct Epilogue {
     // partial sums go to dwslab[worker][Kd][dw_ld] and are combined by launch_slab_reduce
     float *dwslab = nullptr;
     int dw_ld = 0;
+    BnTail bn;
 };
 
 // The B operand (weights) is read in place from its state_dict layout -- no transposed copies are made.
