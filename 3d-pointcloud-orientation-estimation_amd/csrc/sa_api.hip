@@ -139,7 +139,10 @@ static SaScratch sa_scratch_layout(const pnpp_sa_desc *d, const SaGeom &g, void 
     for (int l = 0; l < d->L; ++l) {
         int nsplit, kp_pad;
         dw_plan(g.M, d->C[l], g.Cin[l], &nsplit, &kp_pad);
-        const size_t need = (size_t)nsplit * d->C[l] * kp_pad;
+        size_t need = (size_t)nsplit * d->C[l] * kp_pad;
+        // the fused dA+dW kernels (large M only) write one C_l x C_{l-1} partial per worker, at most kMaxStatBlocks of them
+        const size_t fused = (l > 0 && g.M >= 8192) ? (size_t)kMaxStatBlocks * d->C[l] * d->C[l - 1] : 0;
+        need = fused > need ? fused : need;
         dwmax = need > dwmax ? need : dwmax;
     }
     s.dwslab = cv.take<float>(dwmax);
