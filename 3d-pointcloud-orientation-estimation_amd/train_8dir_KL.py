@@ -13,7 +13,7 @@ from torch.utils.data import DataLoader
 
 from dataloader_8dir_sampled import PointCloudDataset
 from models.pointnet_pp_8dir import DIRS_8, PointNetPP8Dir
-from pnpp_hip import dist as pdist, ops, trainer
+from pnpp_hip import sampling, dist as pdist, ops, trainer
 
 ROOT = trainer.env_path("PNPP_ROOT", "/home/pablo/ForwardNet/data/2d_1to8_sampled")
 RES = trainer.env_path("PNPP_RES", "/home/pablo/ForwardNet/results/8dir_KLdiv")
@@ -69,6 +69,7 @@ def main(argv=None):
     args = ap.parse_args(argv)
     rank, _, world = pdist.init_from_env()
     torch.manual_seed(SEED), np.random.seed(SEED), random.seed(SEED)
+    sampling.reset(0)   # the device-side centre sampler restarts its stream too: a run is a function of SEED
     RES.mkdir(parents=True, exist_ok=True)
     from models.pointnet_pp_8dir import PointNetSetAbstraction
     PointNetSetAbstraction.sampler = args.sampler

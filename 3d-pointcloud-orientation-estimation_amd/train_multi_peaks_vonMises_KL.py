@@ -21,7 +21,7 @@ from torch.utils.data import DataLoader
 
 from dataloader_multi_peak_vonMises import PointCloudDatasetMvM
 from models.pointnet_pp_mvM import PointNetPPMvM
-from pnpp_hip import dist as pdist, ops, trainer
+from pnpp_hip import sampling, dist as pdist, ops, trainer
 
 ROOT = trainer.env_path("PNPP_ROOT", "/home/pablo/ForwardNet/data/MN40_multi_peak_vM_gt")
 PLY_ROOT = trainer.env_path("PNPP_PLY_ROOT", "/home/pablo/ForwardNet/data/full_mn40_normal_resampled_2d_rotated_ply")
@@ -129,6 +129,7 @@ def main(argv=None):
     args = ap.parse_args(argv)
     rank, _, world = pdist.init_from_env()
     torch.manual_seed(SEED), np.random.seed(SEED), random.seed(SEED)
+    sampling.reset(0)   # the device-side centre sampler restarts its stream too: a run is a function of SEED
     RES.mkdir(parents=True, exist_ok=True), FIGS.mkdir(parents=True, exist_ok=True)
     from models.pointnet_pp_8dir import PointNetSetAbstraction
     PointNetSetAbstraction.sampler = args.sampler

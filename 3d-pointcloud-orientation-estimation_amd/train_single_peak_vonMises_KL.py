@@ -22,7 +22,7 @@ from torch.utils.data import DataLoader
 
 from dataloader_single_peak_vonMises import PointCloudDatasetVonMises
 from models.pointnet_pp_vonMises import PointNetPPVonMises
-from pnpp_hip import dist as pdist, ops, trainer
+from pnpp_hip import sampling, dist as pdist, ops, trainer
 
 ROOT = trainer.env_path("PNPP_ROOT", "/home/pablo/ForwardNet/data/chair_toilet_sofa_plant_bowl_bottle")
 RES = trainer.env_path("PNPP_RES", "/home/pablo/ForwardNet/results/single_peak_vonMises_KL_1006_2")
@@ -98,6 +98,7 @@ def main(argv=None):
     args = ap.parse_args(argv)
     rank, _, world = pdist.init_from_env()
     torch.manual_seed(SEED), np.random.seed(SEED), random.seed(SEED)
+    sampling.reset(0)   # the device-side centre sampler restarts its stream too: a run is a function of SEED
     RES.mkdir(parents=True, exist_ok=True), FIGS.mkdir(parents=True, exist_ok=True)
     from models.pointnet_pp_8dir import PointNetSetAbstraction
     PointNetSetAbstraction.sampler = args.sampler
