@@ -323,9 +323,9 @@ __device__ __forceinline__ unsigned philox_key(unsigned c0, unsigned c1, unsigne
 }
 
 // One workgroup per cloud.  Only the npoint smallest keys matter, so the keys are first cut at a threshold that keeps
-// about 2 npoint + 64 of them (all of them when that is >= N); the survivors go to LDS as 64-bit (key, index) words --
+// about npoint + 4 sqrt(npoint) + 16 of them (all of them when that is >= N); the survivors go to LDS as 64-bit (key, index) words --
 // the lexicographic order of the reference rank -- and each survivor counts the survivors below it.  A cloud whose
-// cut kept fewer than npoint keys (a > 8 sigma event) is redone without the cut, so the result never depends on it.
+// cut kept fewer than npoint keys (a > 5 sigma event) is redone without the cut, so the result never depends on it.
 __global__ void __launch_bounds__(256) sample_random_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_lo,
                                                             unsigned str_hi, unsigned long long *__restrict__ str_dev,
                                                             int N, int npoint, int32_t *__restrict__ out) {
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) sample_random_kernel(unsigned seed_lo, un
         const unsigned long long sid = str_dev[0] + (((unsigned long long)str_hi << 32) | str_lo);
         str_lo = (unsigned)sid, str_hi = (unsigned)(sid >> 32);
     }
-    const double keep = (2.0 * npoint + 64.0) / (double)N;
+    const double keep = (npoint + 4.0 * sqrt((double)npoint) + 16.0) / (double)N;  // >= 5 sigma above npoint survivors
     unsigned cut = keep >= 1.0 ? 0xffffffffu : (unsigned)(keep * 4294967296.0);
     int nc;
     for (;;) {

@@ -385,6 +385,134 @@ __global__ void __launch_bounds__(64) sumsq_final_kernel(const double *__restric
     if (threadIdx.x == 0) out[0] = acc;
 }
 
+// ---- direction-vector heads and their MSE / orthogonality losses (the other set-abstraction models) ----------------
+// F.normalize(x, p=2, dim=1, eps): y = x / max(||x||, eps)            (pointnet_pp_Fwd.py:98, Pointnet_pp_xyz.py:84-85)
+constexpr int VEC_CMAX = 64;
+__global__ void __launch_bounds__(64) l2_normalize_kernel(const float *__restrict__ x, int M, int C, float eps,
+                                                          float *__restrict__ y) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= M) return;
+    const float *xr = x + (size_t)m * C;
+    double ss = 0.0;
+    for (int c = 0; c < C; ++c) ss += (double)xr[c] * (double)xr[c];
+    const double d = fmax(sqrt(ss), (double)eps);
+    for (int c = 0; c < C; ++c) y[(size_t)m * C + c] = (float)((double)xr[c] / d);
+}
+
+// dx = (dy - y (y . dy)) / ||x||  where ||x|| > eps, dy / eps otherwise (the clamp is then the constant denominator)
+__global__ void __launch_bounds__(64) l2_normalize_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                              int M, int C, float eps, float *__restrict__ dx) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= M) return;
+    const float *xr = x + (size_t)m * C, *gr = dy + (size_t)m * C;
+    double ss = 0.0, xg = 0.0;
+    for (int c = 0; c < C; ++c) ss += (double)xr[c] * (double)xr[c], xg += (double)xr[c] * (double)gr[c];
+    const double nrm = sqrt(ss);
+    if (nrm > (double)eps) {
+        for (int c = 0; c < C; ++c) dx[(size_t)m * C + c] = (float)(((double)gr[c] - (double)xr[c] * xg / ss) / nrm);
+    } else {
+        for (int c = 0; c < C; ++c) dx[(size_t)m * C + c] = (float)((double)gr[c] / (double)eps);
+    }
+}
+
+// nn.MSELoss(): mean over all n elements (train.py:168,183; train_multi_8dir.py:80,100); dp = 2 (p - t) / n.
+// One workgroup, fixed-order float64 tree: deterministic.
+__global__ void __launch_bounds__(256) mse_kernel(const float *__restrict__ p, const float *__restrict__ t, size_t n,
+                                                  float *__restrict__ loss, float *__restrict__ dp) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    const double inv = 1.0 / (double)n;
+    for (size_t i = threadIdx.x; i < n; i += 256) {
+        const double d = (double)p[i] - (double)t[i];
+        acc += d * d;
+        if (dp) dp[i] = (float)(2.0 * d * inv);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(red[0] * inv);
+}
+
+// orthogonality penalty of two predicted axes: mean_b (a_b . b_b)^2   (train.py:184-185)
+__global__ void __launch_bounds__(256) orth_loss_kernel(const float *__restrict__ a, const float *__restrict__ b, int B, int C,
+                                                        float *__restrict__ loss, float *__restrict__ da,
+                                                        float *__restrict__ db) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    const double inv = 1.0 / (double)B;
+    for (int m = threadIdx.x; m < B; m += 256) {
+        double dot = 0.0;
+        for (int c = 0; c < C; ++c) dot += (double)a[(size_t)m * C + c] * (double)b[(size_t)m * C + c];
+        acc += dot * dot;
+        if (da && db)
+            for (int c = 0; c < C; ++c) {
+                da[(size_t)m * C + c] = (float)(2.0 * dot * inv * (double)b[(size_t)m * C + c]);
+                db[(size_t)m * C + c] = (float)(2.0 * dot * inv * (double)a[(size_t)m * C + c]);
+            }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(red[0] * inv);
+}
+
+// proj_probs (train_multi_8dir.py:41-44): v = normalize(vec); sims = clamp(v D^T, min=0); p = sims / clamp(sum sims, 1e-8)
+constexpr int PROJ_DMAX = 16;
+__global__ void __launch_bounds__(64) proj_probs_kernel(const float *__restrict__ vec, const float *__restrict__ dirs, int B,
+                                                        int D, float *__restrict__ probs) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= B) return;
+    const double x0 = vec[3 * m], x1 = vec[3 * m + 1], x2 = vec[3 * m + 2];
+    const double d = fmax(sqrt(x0 * x0 + x1 * x1 + x2 * x2), 1e-12);
+    const float v0 = (float)(x0 / d), v1 = (float)(x1 / d), v2 = (float)(x2 / d);  // F.normalize's float32 result
+    double sims[PROJ_DMAX], sum = 0.0;
+    for (int j = 0; j < D; ++j) {
+        const double dot = (double)v0 * (double)dirs[3 * j] + (double)v1 * (double)dirs[3 * j + 1] + (double)v2 * (double)dirs[3 * j + 2];
+        sims[j] = fmax(dot, 0.0);
+        sum += sims[j];
+    }
+    const double s = fmax(sum, 1e-8);
+    for (int j = 0; j < D; ++j) probs[(size_t)m * D + j] = (float)(sims[j] / s);
+}
+
+__global__ void __launch_bounds__(64) proj_probs_bwd_kernel(const float *__restrict__ vec, const float *__restrict__ dirs,
+                                                            const float *__restrict__ dprobs, int B, int D,
+                                                            float *__restrict__ dvec) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= B) return;
+    const double x0 = vec[3 * m], x1 = vec[3 * m + 1], x2 = vec[3 * m + 2];
+    const double ss = x0 * x0 + x1 * x1 + x2 * x2, nrm = sqrt(ss), d = fmax(nrm, 1e-12);
+    const double v0 = x0 / d, v1 = x1 / d, v2 = x2 / d;
+    double dots[PROJ_DMAX], sum = 0.0, gs = 0.0;
+    for (int j = 0; j < D; ++j) {
+        dots[j] = v0 * (double)dirs[3 * j] + v1 * (double)dirs[3 * j + 1] + v2 * (double)dirs[3 * j + 2];
+        const double sj = fmax(dots[j], 0.0);
+        sum += sj;
+        gs += (double)dprobs[(size_t)m * D + j] * sj;
+    }
+    const double s = fmax(sum, 1e-8);
+    const double back = sum >= 1e-8 ? gs / (s * s) : 0.0;  // the clamped denominator is a constant below 1e-8
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0;                   // gradient w.r.t. the unit vector
+    for (int j = 0; j < D; ++j) {
+        if (!(dots[j] >= 0.0)) continue;                    // clamp(min=0) passes the gradient where its input >= 0
+        const double gj = (double)dprobs[(size_t)m * D + j] / s - back;
+        g0 += gj * (double)dirs[3 * j], g1 += gj * (double)dirs[3 * j + 1], g2 += gj * (double)dirs[3 * j + 2];
+    }
+    if (nrm > 1e-12) {
+        const double vg = v0 * g0 + v1 * g1 + v2 * g2;
+        dvec[3 * m] = (float)((g0 - v0 * vg) / nrm), dvec[3 * m + 1] = (float)((g1 - v1 * vg) / nrm);
+        dvec[3 * m + 2] = (float)((g2 - v2 * vg) / nrm);
+    } else {
+        dvec[3 * m] = (float)(g0 / 1e-12), dvec[3 * m + 1] = (float)(g1 / 1e-12), dvec[3 * m + 2] = (float)(g2 / 1e-12);
+    }
+}
+
 }  // namespace pnpp
 
 using namespace pnpp;
@@ -459,6 +587,56 @@ extern "C" int pnpp_mvm_head_bwd(const float *pi_raw, const float *mu_raw, const
     hipLaunchKernelGGL(mvm_head_bwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), pi_raw, mu_raw, kappa_raw, weight,
                        dmu, dkappa, dweight, B, K, temp, kappa_max, dpi_raw, dmu_raw, dkappa_raw);
     PNPP_CHECK_LAUNCH("mvm_head_bwd");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_l2_normalize(const float *x, int M, int C, float eps, float *y, void *stream) {
+    PNPP_REQUIRE(x && y, PNPP_ERR_ARG, "l2_normalize: null pointer");
+    PNPP_REQUIRE(M > 0 && C > 0 && C <= VEC_CMAX, PNPP_ERR_ARG, "l2_normalize: M=%d C=%d (C <= %d)", M, C, VEC_CMAX);
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3(cdiv(M, 64)), dim3(64), 0, as_stream(stream), x, M, C, eps, y);
+    PNPP_CHECK_LAUNCH("l2_normalize");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_l2_normalize_bwd(const float *x, const float *dy, int M, int C, float eps, float *dx, void *stream) {
+    PNPP_REQUIRE(x && dy && dx, PNPP_ERR_ARG, "l2_normalize_bwd: null pointer");
+    PNPP_REQUIRE(M > 0 && C > 0 && C <= VEC_CMAX, PNPP_ERR_ARG, "l2_normalize_bwd: M=%d C=%d (C <= %d)", M, C, VEC_CMAX);
+    hipLaunchKernelGGL(l2_normalize_bwd_kernel, dim3(cdiv(M, 64)), dim3(64), 0, as_stream(stream), x, dy, M, C, eps, dx);
+    PNPP_CHECK_LAUNCH("l2_normalize_bwd");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_mse(const float *p, const float *t, size_t n, float *loss, float *dp, void *stream) {
+    PNPP_REQUIRE(p && t && loss, PNPP_ERR_ARG, "mse: null pointer");
+    PNPP_REQUIRE(n > 0, PNPP_ERR_ARG, "mse: empty input");
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, as_stream(stream), p, t, n, loss, dp);
+    PNPP_CHECK_LAUNCH("mse");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_orth_loss(const float *a, const float *b, int B, int C, float *loss, float *da, float *db, void *stream) {
+    PNPP_REQUIRE(a && b && loss, PNPP_ERR_ARG, "orth_loss: null pointer");
+    PNPP_REQUIRE((da == nullptr) == (db == nullptr), PNPP_ERR_ARG, "orth_loss: pass both gradient outputs or neither");
+    PNPP_REQUIRE(B > 0 && C > 0, PNPP_ERR_ARG, "orth_loss: non-positive size");
+    hipLaunchKernelGGL(orth_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), a, b, B, C, loss, da, db);
+    PNPP_CHECK_LAUNCH("orth_loss");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_proj_probs(const float *vec, const float *dirs, int B, int D, float *probs, void *stream) {
+    PNPP_REQUIRE(vec && dirs && probs, PNPP_ERR_ARG, "proj_probs: null pointer");
+    PNPP_REQUIRE(B > 0 && D > 0 && D <= PROJ_DMAX, PNPP_ERR_ARG, "proj_probs: B=%d D=%d (D <= %d)", B, D, PROJ_DMAX);
+    hipLaunchKernelGGL(proj_probs_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), vec, dirs, B, D, probs);
+    PNPP_CHECK_LAUNCH("proj_probs");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_proj_probs_bwd(const float *vec, const float *dirs, const float *dprobs, int B, int D, float *dvec,
+                                   void *stream) {
+    PNPP_REQUIRE(vec && dirs && dprobs && dvec, PNPP_ERR_ARG, "proj_probs_bwd: null pointer");
+    PNPP_REQUIRE(B > 0 && D > 0 && D <= PROJ_DMAX, PNPP_ERR_ARG, "proj_probs_bwd: B=%d D=%d (D <= %d)", B, D, PROJ_DMAX);
+    hipLaunchKernelGGL(proj_probs_bwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), vec, dirs, dprobs, B, D, dvec);
+    PNPP_CHECK_LAUNCH("proj_probs_bwd");
     return PNPP_OK;
 }
 

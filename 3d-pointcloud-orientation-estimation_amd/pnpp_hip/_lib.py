@@ -86,6 +86,12 @@ SIGNATURES = {
     "pnpp_mvm_head": (_i, [_fp, _fp, _fp, _i, _i, _f, _f, _fp, _fp, _fp, _fp]),
     "pnpp_mvm_head_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _f, _f, _fp, _fp, _fp, _fp]),
     "pnpp_soft_ce": (_i, [_fp, _fp, _i, _i, _fp, _fp, _fp]),
+    "pnpp_l2_normalize": (_i, [_fp, _i, _i, _f, _fp, _fp]),
+    "pnpp_l2_normalize_bwd": (_i, [_fp, _fp, _i, _i, _f, _fp, _fp]),
+    "pnpp_mse": (_i, [_fp, _fp, _sz, _fp, _fp, _fp]),
+    "pnpp_orth_loss": (_i, [_fp, _fp, _i, _i, _fp, _fp, _fp, _fp]),
+    "pnpp_proj_probs": (_i, [_fp, _fp, _i, _i, _fp, _fp]),
+    "pnpp_proj_probs_bwd": (_i, [_fp, _fp, _fp, _i, _i, _fp, _fp]),
     "pnpp_adam_step": (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _f, _f, _f, _f, _fp]),
     "pnpp_sumsq": (_i, [_fp, _sz, _fp, _fp, _sz, _fp]),
 }

@@ -15,10 +15,15 @@ import torch
 
 
 class GraphedStep:
-    def __init__(self, opt, loss_fn: Callable[..., torch.Tensor], example_inputs: Sequence[torch.Tensor], warmup: int = 3):
-        """loss_fn(*inputs) -> scalar loss; `opt` is a pnpp_hip.optim.FlatAdam (its flat gradient buffer is static)."""
+    def __init__(self, opt, loss_fn: Callable[..., torch.Tensor], example_inputs: Sequence[torch.Tensor], warmup: int = 3,
+                 adopt_inputs: bool = False):
+        """loss_fn(*inputs) -> scalar loss; `opt` is a pnpp_hip.optim.FlatAdam (its flat gradient buffer is static).
+
+        adopt_inputs=True makes `example_inputs` themselves the static input buffers (`self.static_in`): a loader that
+        writes the next batch into them (H2D copy target) and then calls the step with the same tensors pays no
+        device-to-device copy; any other tensor passed later is copied in as usual."""
         self.opt = opt
-        self.static_in = [t.clone() for t in example_inputs]
+        self.static_in = list(example_inputs) if adopt_inputs else [t.clone() for t in example_inputs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -569,3 +569,108 @@ class _SoftCE(torch.autograd.Function):
 def soft_ce(logits, p_target):
     """train_8dir_KL.py:60-68."""
     return _SoftCE.apply(logits, p_target)
+
+
+# ------------------------------------------------------------------------------------------------
+# direction-vector heads and losses of the other set-abstraction models (SURVEY section 8 f-3)
+# ------------------------------------------------------------------------------------------------
+class _L2Normalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = _f32(x, "x")
+        if x.dim() != 2:
+            raise ValueError(f"l2_normalize: expected (M,C), got {tuple(x.shape)}")
+        M, Cc = x.shape
+        y = torch.empty_like(x)
+        L.check(L.lib().pnpp_l2_normalize(x.data_ptr(), M, Cc, float(eps), y.data_ptr(), _stream()))
+        ctx.save_for_backward(x)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _f32(dy, "dy")
+        dx = torch.empty_like(x)
+        L.check(L.lib().pnpp_l2_normalize_bwd(x.data_ptr(), dy.data_ptr(), x.shape[0], x.shape[1], ctx.eps, dx.data_ptr(),
+                                              _stream()))
+        return dx, None
+
+
+def l2_normalize(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """F.normalize(x, p=2, dim=1, eps) for (M,C) inputs (pointnet_pp_Fwd.py:98, Pointnet_pp_xyz.py:84-85)."""
+    return _L2Normalize.apply(x, eps)
+
+
+class _Mse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, t):
+        p, t = _f32(p, "input"), _f32(t, "target")
+        if p.shape != t.shape:
+            raise ValueError(f"mse_loss: input {tuple(p.shape)} and target {tuple(t.shape)} differ")
+        loss = torch.empty((), device=p.device, dtype=torch.float32)
+        dp = torch.empty_like(p)
+        L.check(L.lib().pnpp_mse(p.data_ptr(), t.data_ptr(), p.numel(), loss.data_ptr(), dp.data_ptr(), _stream()))
+        ctx.save_for_backward(dp)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        return g * dp, None
+
+
+def mse_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """nn.MSELoss()(pred, target): mean over all elements, value and gradient from one launch."""
+    return _Mse.apply(pred, target)
+
+
+class _Orth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32(a, "a"), _f32(b, "b")
+        if a.shape != b.shape or a.dim() != 2:
+            raise ValueError(f"orth_loss: expected two (B,C) tensors, got {tuple(a.shape)} and {tuple(b.shape)}")
+        loss = torch.empty((), device=a.device, dtype=torch.float32)
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        L.check(L.lib().pnpp_orth_loss(a.data_ptr(), b.data_ptr(), a.shape[0], a.shape[1], loss.data_ptr(), da.data_ptr(),
+                                       db.data_ptr(), _stream()))
+        ctx.save_for_backward(da, db)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        da, db = ctx.saved_tensors
+        return g * da, g * db
+
+
+def orth_loss(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """(a * b).sum(1).pow(2).mean()  (train.py:184-185)."""
+    return _Orth.apply(a, b)
+
+
+class _ProjProbs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vec, dirs):
+        vec, dirs = _f32(vec, "vec"), _f32(dirs, "dirs")
+        if vec.dim() != 2 or vec.shape[1] != 3 or dirs.dim() != 2 or dirs.shape[1] != 3:
+            raise ValueError(f"proj_probs: expected vec (B,3) and dirs (D,3), got {tuple(vec.shape)}, {tuple(dirs.shape)}")
+        B, D = vec.shape[0], dirs.shape[0]
+        probs = torch.empty(B, D, device=vec.device, dtype=torch.float32)
+        L.check(L.lib().pnpp_proj_probs(vec.data_ptr(), dirs.data_ptr(), B, D, probs.data_ptr(), _stream()))
+        ctx.save_for_backward(vec, dirs)
+        return probs
+
+    @staticmethod
+    def backward(ctx, dprobs):
+        vec, dirs = ctx.saved_tensors
+        dprobs = _f32(dprobs, "dprobs")
+        dvec = torch.empty_like(vec)
+        L.check(L.lib().pnpp_proj_probs_bwd(vec.data_ptr(), dirs.data_ptr(), dprobs.data_ptr(), vec.shape[0], dirs.shape[0],
+                                            dvec.data_ptr(), _stream()))
+        return dvec, None
+
+
+def proj_probs(vec: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
+    """train_multi_8dir.py:41-44: unit vector -> non-negative cosine to each of the D directions -> normalised to sum 1."""
+    return _ProjProbs.apply(vec, dirs)

@@ -47,7 +47,7 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph):
     if use_graph:
         try:
             from pnpp_hip.graph import GraphedStep
-            graphed = GraphedStep(opt, loss_fn, [xyz, mu_gt, kappa_gt])
+            graphed = GraphedStep(opt, loss_fn, [xyz, mu_gt, kappa_gt], adopt_inputs=True)   # the batch is resident: no staging copy
         except Exception as e:  # capture is an optimisation, never a requirement
             print(f"[bench] hipGraph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr)
             graphed = None

@@ -237,6 +237,21 @@ int pnpp_mvm_head_bwd(const float *pi_raw, const float *mu_raw, const float *kap
 /* train_8dir_KL.py:60-68: loss_vec[b] = -sum p * log_softmax(logits); dlogits = softmax*sum(p) - p. */
 int pnpp_soft_ce(const float *logits, const float *p, int B, int C, float *loss_vec, float *dlogits, void *stream);
 
+/* Heads and losses of the other set-abstraction models.
+ * models/pointnet_pp_Fwd.py:98, models/Pointnet_pp_xyz.py:84-85, models/Pointnet_pp_xyz_Schedmit.py:87-88:
+ * F.normalize(x, p=2, dim=1, eps): y[m,:] = x[m,:] / max(||x[m,:]||, eps); x, y (M,C), C <= 64. */
+int pnpp_l2_normalize(const float *x, int M, int C, float eps, float *y, void *stream);
+int pnpp_l2_normalize_bwd(const float *x, const float *dy, int M, int C, float eps, float *dx, void *stream);
+/* nn.MSELoss() (train.py:168,183; train_multi_8dir.py:80,100; train_8dir.py:53,67): loss[0] = mean_i (p_i - t_i)^2 over
+ * all n elements, dp (optional) = 2 (p - t) / n.  One workgroup, fixed-order float64 sum. */
+int pnpp_mse(const float *p, const float *t, size_t n, float *loss, float *dp, void *stream);
+/* train.py:184-185: loss[0] = mean_b (a_b . b_b)^2 for two (B,C) sets of axes; da, db optional (both or neither). */
+int pnpp_orth_loss(const float *a, const float *b, int B, int C, float *loss, float *da, float *db, void *stream);
+/* train_multi_8dir.py:41-44 proj_probs: v = normalize(vec (B,3)); sims = clamp(v dirs^T, min=0) with dirs (D,3), D <= 16;
+ * probs (B,D) = sims / clamp(sum_j sims, min=1e-8). */
+int pnpp_proj_probs(const float *vec, const float *dirs, int B, int D, float *probs, void *stream);
+int pnpp_proj_probs_bwd(const float *vec, const float *dirs, const float *dprobs, int B, int D, float *dvec, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Step glue on one flat parameter / gradient buffer
  * (train_single_peak_vonMises_KL.py:80,85; train_multi_peaks_vonMises_KL.py:221,235-236)

@@ -401,6 +401,74 @@ def golden_debug_log(max_blocks=200):
     save("debug_log_kat.npz", **out)
 
 
+def golden_f3():
+    """The other set-abstraction models: PointNetPP, PointNetPPFwd, PointNetPPXYZ,
+    PointNetPPXYZ_Schedmit run by the reference in float32 and float64, with the loss expressions of their training
+    scripts: nn.MSELoss on the raw vector (train_8dir.py:53,67), proj_probs + MSELoss (train_multi_8dir.py:41-44,80,100;
+    proj_probs is the reference's own function object), and the inline axis-pair loss of train.py:183-187."""
+    import importlib
+    from models.pointnet_pp_8dir import DIRS_8
+    proj = {dt: ref_functions("train_multi_8dir.py", ["proj_probs"], {"DIRS_8_T": DIRS_8.to(dt)})[0]
+            for dt in (torch.float32, torch.float64)}   # the script's global DIRS_8_T, in the run's dtype
+    crit = nn.MSELoss()
+    B, N = 8, 1024
+    xyz, _, _, fwd = R.synthetic_clouds(B, N, seed=1234)
+    up = torch.tensor([0.0, 1.0, 0.0]).expand(B, 3).contiguous()
+    side = torch.stack([-fwd[:, 2], torch.zeros(B), fwd[:, 0]], 1)
+    prob8 = torch.relu(fwd @ DIRS_8.t())
+    prob8 = prob8 / prob8.sum(1, keepdim=True)
+    gmask = torch.Generator().manual_seed(8)
+    mask = (torch.rand(B, 256, generator=gmask) < 0.5).float()
+    out = dict(xyz_ck=np.array([xyz.double().sum().item(), xyz.double().abs().sum().item()]), fwd=n(fwd), up=n(up),
+               side=n(side), prob8=n(prob8), drop_mask=n(mask).astype(np.uint8))
+    specs = [("pp", "models.pointnet_pp", "PointNetPP"), ("fwd", "models.pointnet_pp_Fwd", "PointNetPPFwd"),
+             ("xyz", "models.Pointnet_pp_xyz", "PointNetPPXYZ"), ("sch", "models.Pointnet_pp_xyz_Schedmit", "PointNetPPXYZ_Schedmit")]
+    for tag0, modname, cls in specs:
+        mod = importlib.import_module(modname)
+        orig_q = mod.query_ball_point
+
+        def q32(new_xyz, x, k, _o=orig_q):
+            return _o(new_xyz.float(), x.float(), k)
+
+        for dt_name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            mod.query_ball_point = q32 if dt == torch.float64 else orig_q
+            for variant in ("nodrop", "mask"):
+                torch.manual_seed(42)
+                model = getattr(mod, cls)()
+                if dt_name == "f32" and variant == "nodrop":
+                    out.update({f"{tag0}_{k}": v for k, v in _param_checksums(model).items()})
+                model = model.to(dt)
+                model.drop = nn.Identity() if variant == "nodrop" else _Mask(mask, 0.5)
+                model.train()
+                torch.manual_seed(4242)
+                res = model(xyz.to(dt))
+                tag = f"{tag0}_{dt_name}_{variant}"
+                if tag0 == "pp":
+                    loss = crit(res, fwd.to(dt))                                    # train_8dir.py:67
+                    out[f"{tag}.out"] = n(res)
+                elif tag0 == "fwd":
+                    pred = proj[dt](res)                                            # train_multi_8dir.py:99
+                    loss = crit(pred, prob8.to(dt))                                 # :100
+                    out[f"{tag}.out"], out[f"{tag}.probs"] = n(res), n(pred)
+                else:
+                    va, vb = res
+                    ga, gb = (side, up) if tag0 == "xyz" else (up, fwd)
+                    pred_loss = (crit(va, ga.to(dt)) + crit(vb, gb.to(dt))) / 2.0   # train.py:183
+                    dot_prod = (va * vb).sum(dim=1)                                 # :184
+                    orth_loss = dot_prod.pow(2).mean()                              # :185
+                    loss = pred_loss + 0.1 * orth_loss                              # :186-187
+                    out[f"{tag}.out_a"], out[f"{tag}.out_b"] = n(va), n(vb)
+                loss.backward()
+                out[f"{tag}.loss"] = np.array(loss.item())
+                for k, v in _grad_summary(model).items():
+                    out[f"{tag}.{k}"] = v
+        mod.query_ball_point = orig_q
+    torch.manual_seed(4242)
+    cs = R.replay_centres(B)
+    out["centres1"], out["centres2"] = n(cs[0]).astype(np.int16), n(cs[1]).astype(np.int16)
+    save("f3.npz", **out)
+
+
 def golden_vm_gt():
     """data_process/demo_vm_gt/*.txt + the mu values printed in 2d_single_peak_vM_test.ipynb."""
     d = os.path.join(REF, "data_process/demo_vm_gt")
@@ -422,6 +490,6 @@ def golden_vm_gt():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["index", "sa", "e2e", "kl", "debug_log", "vm_gt"]
+    which = sys.argv[1:] or ["index", "sa", "e2e", "kl", "debug_log", "vm_gt", "f3"]
     for w in which:
         globals()[f"golden_{w}"]()

@@ -226,14 +226,19 @@ def _lin(x, P, name):
     return x @ P[f"{name}.weight"].t() + P[f"{name}.bias"]
 
 
-def bn_head_forward(feat, P, drop_mask: Optional[torch.Tensor], training=True, bn_state=None, p_drop=0.5):
-    """fc1/bn1/relu, fc2/bn2/relu, dropout, fc3 (pointnet_pp_vonMises.py:32-35, pointnet_pp_8dir.py:81-85).
+def bn_head_features(feat, P, drop_mask: Optional[torch.Tensor], training=True, bn_state=None, p_drop=0.5):
+    """fc1/bn1/relu, fc2/bn2/relu, dropout (pointnet_pp_vonMises.py:32-34 and every other BN-head model).
     drop_mask (B,256) of {0,1} replaces nn.Dropout's draw; None = no dropout."""
     x = torch.relu(_bn1d(_lin(feat, P, "fc1"), P, "bn1", training, bn_state))
     x = torch.relu(_bn1d(_lin(x, P, "fc2"), P, "bn2", training, bn_state))
     if training and drop_mask is not None:
         x = x * drop_mask.to(x.dtype) / (1.0 - p_drop)
-    return _lin(x, P, "fc3")
+    return x
+
+
+def bn_head_forward(feat, P, drop_mask: Optional[torch.Tensor], training=True, bn_state=None, p_drop=0.5):
+    """... followed by fc3 (pointnet_pp_vonMises.py:35, pointnet_pp_8dir.py:85, pointnet_pp.py:68)."""
+    return _lin(bn_head_features(feat, P, drop_mask, training, bn_state, p_drop), P, "fc3")
 
 
 def vonmises_forward(xyz32, P, centres, drop_mask=None, training=True, bn_state=None, **bk):
@@ -245,6 +250,44 @@ def vonmises_forward(xyz32, P, centres, drop_mask=None, training=True, bn_state=
 def dir8_forward(xyz32, P, centres, drop_mask=None, training=True, bn_state=None, **bk):
     """PointNetPP8Dir.forward (pointnet_pp_8dir.py:76-85) -> logits (B,8)."""
     return bn_head_forward(backbone_forward(xyz32, P, centres, training, bn_state, **bk), P, drop_mask, training, bn_state)
+
+
+def l2_normalize(x, eps=1e-12):
+    """F.normalize(x, p=2, dim=1, eps) (pointnet_pp_Fwd.py:98)."""
+    return x / x.norm(dim=1, keepdim=True).clamp_min(eps)
+
+
+def pp_forward(xyz32, P, centres, drop_mask=None, training=True, bn_state=None, **bk):
+    """PointNetPP.forward (pointnet_pp.py:58-68) -> raw (B,3)."""
+    return bn_head_forward(backbone_forward(xyz32, P, centres, training, bn_state, **bk), P, drop_mask, training, bn_state)
+
+
+def fwd_forward(xyz32, P, centres, drop_mask=None, training=True, bn_state=None, **bk):
+    """PointNetPPFwd.forward (pointnet_pp_Fwd.py:89-98) -> unit (B,3)."""
+    return l2_normalize(pp_forward(xyz32, P, centres, drop_mask, training, bn_state, **bk))
+
+
+def axes_forward(xyz32, P, centres, heads, drop_mask=None, training=True, bn_state=None, **bk):
+    """PointNetPPXYZ.forward (heads=("head_x","head_y"), Pointnet_pp_xyz.py:66-90) and PointNetPPXYZ_Schedmit.forward
+    (heads=("head_y","head_z"), Pointnet_pp_xyz_Schedmit.py:68-90) -> two unit (B,3) vectors."""
+    feat = bn_head_features(backbone_forward(xyz32, P, centres, training, bn_state, **bk), P, drop_mask, training, bn_state)
+    return tuple(l2_normalize(_lin(feat, P, h)) for h in heads)
+
+
+def mse(pred, target):
+    """nn.MSELoss() (train.py:168)."""
+    return ((pred - target) ** 2).mean()
+
+
+def axis_pair_loss(vy, vz, gy, gz, lam=0.1):
+    """train.py:183-187."""
+    return (mse(vy, gy) + mse(vz, gz)) / 2.0 + lam * (vy * vz).sum(dim=1).pow(2).mean()
+
+
+def proj_probs(vec, dirs):
+    """train_multi_8dir.py:41-44."""
+    sims = (l2_normalize(vec) @ dirs.t()).clamp(min=0)
+    return sims / sims.sum(dim=1, keepdim=True).clamp(min=1e-8)
 
 
 def mvm_forward(xyz32, P, centres, drop_masks=(None, None), training=True, bn_state=None,
