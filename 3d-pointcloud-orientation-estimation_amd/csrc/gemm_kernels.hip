@@ -1386,6 +1386,72 @@ dw_kernel(const AOperand dz, const AOperand a2, int M, int Nc, int Kp, int tiles
             }
 }
 
+// ---------------------------------------------------------------------------------------------
+// dW of an xyz-only layer 0 (SA1: C x 3): dW[c][k] = sum_m dZ[m][c] * (xyz[nbr(m)][k] - centre(m)[k]).
+// The 64 x 64 MFMA tiles of dw_kernel would spend 61 of their 64 reduction columns on padding; this is a streaming
+// VALU kernel instead: a workgroup takes 256 consecutive rows, stages their three relative coordinates in LDS (one
+// row per thread: neighbour index, gather, float32 subtraction as in the forward) and then walks the rows with
+// lane = channel (64 channels x 4 row lanes), so dY and Z are read once, fully coalesced, and dZ is rebuilt on the
+// fly.  Output: one partial [C][4] per workgroup in the slab layout slab_reduce expects (pitch 4).
+// ---------------------------------------------------------------------------------------------
+template <int DZMODE>
+__global__ void __launch_bounds__(256)
+dw_xyz_kernel(const AOperand dz, const AOperand a2, int M, int C, float *__restrict__ slab) {
+    __shared__ float rel[256][4];
+    __shared__ float red[4][64][3];
+    const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
+    const int m0 = blockIdx.x * 256;
+    {  // this thread's row: relative coordinates, zero for rows beyond M
+        const float2 x = fetch_a1<A_GATHER>(a2, m0 + tid, 0, 3, M);
+        const float2 y = fetch_a1<A_GATHER>(a2, m0 + tid, 1, 3, M);
+        const float2 z = fetch_a1<A_GATHER>(a2, m0 + tid, 2, 3, M);
+        const float okf = (m0 + tid < M) ? 1.f : 0.f;
+        rel[tid][0] = __fsub_rn(x.x, x.y) * okf;
+        rel[tid][1] = __fsub_rn(y.x, y.y) * okf;
+        rel[tid][2] = __fsub_rn(z.x, z.y) * okf;
+        rel[tid][3] = 0.f;
+    }
+    __syncthreads();
+    for (int c0 = blockIdx.y * 64; c0 < C; c0 += gridDim.y * 64) {
+        const int c = c0 + cl;
+        const ChanConst cc = load_chan_const<DZMODE>(dz, min(c, C - 1), C);
+        float a0 = 0.f, a1 = 0.f, a2s = 0.f;
+#pragma unroll 8
+        for (int r = rl; r < 256; r += 4) {
+            const float2 f = fetch_a1<DZMODE>(dz, m0 + r, c, C, M);
+            const float g = xform_a1<DZMODE>(f, cc, c, C, true);  // rows >= M meet zero coordinates
+            const float4 q = *reinterpret_cast<const float4 *>(rel[r]);
+            a0 = fmaf(g, q.x, a0), a1 = fmaf(g, q.y, a1), a2s = fmaf(g, q.z, a2s);
+        }
+        red[rl][cl][0] = a0, red[rl][cl][1] = a1, red[rl][cl][2] = a2s;
+        __syncthreads();
+        if (tid < 192) {
+            const int ch = tid / 3, k = tid - 3 * ch;
+            if (c0 + ch < C)
+                slab[((size_t)blockIdx.x * C + c0 + ch) * 4 + k] = (red[0][ch][k] + red[1][ch][k]) + (red[2][ch][k] + red[3][ch][k]);
+        }
+        __syncthreads();
+    }
+}
+
+// number of partial slabs launch_dw_xyz writes (pitch 4), for sizing
+int dw_xyz_splits(int M) { return cdiv(M, 256); }
+
+int launch_dw_xyz(const AOperand &dz, int C, const AOperand &a2, int M, float *slab, hipStream_t st) {
+    PNPP_REQUIRE(a2.mode == A_GATHER && a2.D == 0, PNPP_ERR_ARG, "dw_xyz: the second operand must be an xyz-only gather");
+    PNPP_REQUIRE(M > 0 && C > 0, PNPP_ERR_ARG, "dw_xyz: non-positive size");
+    const dim3 grid(dw_xyz_splits(M), 1);
+    ProfScope ps(st, "dw_xyz_kernel<A%d> M=%d N=%d K=3 grid=%dx1", dz.mode, M, C, grid.x);
+    switch (dz.mode) {
+        case A_PLAIN: hipLaunchKernelGGL(dw_xyz_kernel<A_PLAIN>, grid, dim3(256), 0, st, dz, a2, M, C, slab); break;
+        case A_DZ: hipLaunchKernelGGL(dw_xyz_kernel<A_DZ>, grid, dim3(256), 0, st, dz, a2, M, C, slab); break;
+        case A_DZ_POOL: hipLaunchKernelGGL(dw_xyz_kernel<A_DZ_POOL>, grid, dim3(256), 0, st, dz, a2, M, C, slab); break;
+        default: set_error("dw_xyz: bad dZ mode %d", dz.mode); return PNPP_ERR_ARG;
+    }
+    PNPP_CHECK_LAUNCH("dw_xyz");
+    return PNPP_OK;
+}
+
 void dw_plan(int M, int Nc, int Kp, int *nsplit, int *kp_pad) {
     const int tilesC = cdiv(Nc, 64), tilesK = cdiv(Kp, 64);
     const int tiles = tilesC * tilesK;

@@ -94,6 +94,9 @@ int launch_dw(const AOperand &dz, int Nc, const AOperand &a2, int Kp, int M, flo
 int launch_dz_materialize(const AOperand &dz, int M, int C, float *out, hipStream_t st);
 // picks the split count / padded pitch launch_dw will use (so callers can size the slab)
 void dw_plan(int M, int Nc, int Kp, int *nsplit, int *kp_pad);
+// xyz-only layer 0 (second operand A_GATHER with D == 0): streaming kernel, one [Nc][4] partial per 256 rows
+int dw_xyz_splits(int M);
+int launch_dw_xyz(const AOperand &dz, int Nc, const AOperand &a2, int M, float *slab, hipStream_t st);
 // out[c][perm(k)] = sum_s slab[s][c][k]; perm_D < 0: identity; else feature-first -> xyz-first column order.
 int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kvalid, int perm_D, float *out, int ldo,
                        hipStream_t st);

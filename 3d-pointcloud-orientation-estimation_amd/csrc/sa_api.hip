@@ -309,8 +309,13 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             PNPP_TRY(launch_gemm(dz, W, g.M, d->C[l - 1], C, E, &nslab_next, st, &dw_slabs));
             fused_slabs = dw_slabs;
         }
-        if (fused_slabs == 0)  // dW_l = dZ_l^T * A_l as its own launch (layer 0, group_all layers, odd shapes)
+        const bool xyz_only = l == 0 && a2.mode == A_GATHER && d->D == 0 && dw_xyz_splits(g.M) <= nsplit * (kp_pad / 4);
+        if (xyz_only) {  // C x 3 gradient: streaming kernel (the MFMA tiles would be 95 % padding)
+            PNPP_TRY(launch_dw_xyz(dz, C, a2, g.M, sc.dwslab, st));
+            nsplit = dw_xyz_splits(g.M), kp_pad = 4;
+        } else if (fused_slabs == 0) {  // dW_l = dZ_l^T * A_l as its own launch (layer 0, group_all layers, odd shapes)
             PNPP_TRY(launch_dw(dz, C, a2, g.Cin[l], g.M, sc.dwslab, nsplit, kp_pad, st));
+        }
         if (l > 0) {  // reduce dW_l's partials and finalise layer l-1's BatchNorm-backward sums in one launch
             const int Cp = d->C[l - 1];
             PNPP_TRY(launch_post_gemm(sc.slab, nslab_next, Cp, (double)g.M, d->training, a->bn_w[l - 1], sv.mean[l - 1],
