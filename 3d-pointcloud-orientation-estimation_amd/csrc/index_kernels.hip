@@ -445,6 +445,80 @@ __global__ void __launch_bounds__(64) scatter_rows_bwd_kernel(const float *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// on-device point subsampling for the data path (dataloader_*: sample_pts / np.random.choice(len, num, replace=len<num)):
+// a bank of full clouds stays resident in HBM as (n_clouds, Lmax, 3) + lengths; one workgroup per batch slot draws
+// `num` rows of its cloud -- an ordered uniform subset without replacement when the cloud has at least `num` points
+// (same key + rank scheme as sample_random_kernel), uniform draws with replacement otherwise -- and writes the
+// coordinates straight into the batch tensor.  Pure function of (seed, stream id, slot); empty clouds give zeros.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+subsample_points_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_lo, unsigned str_hi,
+                        const float *__restrict__ bank, const int32_t *__restrict__ lengths,
+                        const int32_t *__restrict__ cloud_ids, int Lmax, int num, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long cand[];
+    __shared__ int nc_s;
+    const int b = blockIdx.x;
+    const int cloud = cloud_ids ? cloud_ids[b] : b;
+    const int L = min(lengths[cloud], Lmax);
+    const float *src = bank + (size_t)cloud * Lmax * 3;
+    float *dst = out + (size_t)b * num * 3;
+    if (L <= 0) {
+        for (int j = threadIdx.x; j < 3 * num; j += 256) dst[j] = 0.f;
+        return;
+    }
+    if (L < num) {  // with replacement: index = floor(u * L), u from the 32-bit Philox word
+        for (int j = threadIdx.x; j < num; j += 256) {
+            const unsigned u = philox_key((unsigned)j, (unsigned)b, str_lo, str_hi, seed_lo, seed_hi);
+            const int n = (int)(((unsigned long long)u * (unsigned long long)L) >> 32);
+            dst[3 * j] = src[3 * n], dst[3 * j + 1] = src[3 * n + 1], dst[3 * j + 2] = src[3 * n + 2];
+        }
+        return;
+    }
+    const double keep = (num + 4.0 * sqrt((double)num) + 16.0) / (double)L;
+    unsigned cut = keep >= 1.0 ? 0xffffffffu : (unsigned)(keep * 4294967296.0);
+    int nc;
+    for (;;) {
+        if (threadIdx.x == 0) nc_s = 0;
+        __syncthreads();
+        for (int n0 = 0; n0 < L; n0 += 256) {
+            const int n = n0 + threadIdx.x;
+            const unsigned k = n < L ? philox_key((unsigned)n, (unsigned)b, str_lo, str_hi, seed_lo, seed_hi) : 0u;
+            const bool keepit = n < L && k <= cut;
+            const unsigned long long vote = __ballot(keepit);
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == 0 && vote) base = atomicAdd(&nc_s, __popcll(vote));
+            base = __shfl(base, 0, 64);
+            if (keepit) cand[base + __popcll(vote & ((1ull << lane) - 1ull))] = ((unsigned long long)k << 32) | (unsigned)n;
+        }
+        __syncthreads();
+        nc = nc_s;
+        if (nc >= num || cut == 0xffffffffu) break;
+        cut = 0xffffffffu;
+        __syncthreads();
+    }
+    if (nc & 1) {
+        if (threadIdx.x == 0) cand[nc] = ~0ull;
+        __syncthreads();
+    }
+    const int nc2 = (nc + 1) >> 1;
+    const ulonglong2 *c2 = reinterpret_cast<const ulonglong2 *>(cand);
+    for (int i = threadIdx.x; i < nc; i += 256) {
+        const unsigned long long mine = cand[i];
+        int rank = 0;
+#pragma unroll 4
+        for (int j = 0; j < nc2; ++j) {
+            const ulonglong2 o = c2[j];
+            rank += (o.x < mine) + (o.y < mine);
+        }
+        if (rank < num) {
+            const int n = (int)(unsigned)mine;
+            dst[3 * rank] = src[3 * n], dst[3 * rank + 1] = src[3 * n + 1], dst[3 * rank + 2] = src[3 * n + 2];
+        }
+    }
+}
+
 // gather of centre coordinates new_xyz[b,s,:] = xyz[b, centre[b,s], :] into two destinations (the caller's output and
 // the copy kept for backward); centre == nullptr writes the origin (group_all, pointnet_pp_8dir.py:24)
 __global__ void __launch_bounds__(256) gather_centres_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ centre,
@@ -556,6 +630,25 @@ static int sample_random_impl(uint64_t seed, uint64_t stream_id, uint64_t *strea
 
 extern "C" int pnpp_sample_random(uint64_t seed, uint64_t stream_id, int B, int N, int npoint, int32_t *out, void *stream) {
     return sample_random_impl(seed, stream_id, nullptr, B, N, npoint, out, stream);
+}
+
+extern "C" int pnpp_subsample_points(uint64_t seed, uint64_t stream_id, const float *bank, const int32_t *lengths,
+                                     const int32_t *cloud_ids, int B, int Lmax, int num, float *out, void *stream) {
+    PNPP_REQUIRE(bank && lengths && out, PNPP_ERR_ARG, "subsample_points: null pointer");
+    PNPP_REQUIRE(B > 0 && Lmax > 0 && num > 0, PNPP_ERR_ARG, "subsample_points: non-positive size");
+    PNPP_REQUIRE((size_t)(Lmax + 1) * 8 <= 128 * 1024, PNPP_ERR_ARG, "subsample_points: Lmax=%d too large (<= 16383)", Lmax);
+    const size_t lds = (size_t)(Lmax + 1) * sizeof(unsigned long long);
+    static size_t granted = 0;
+    if (lds > 48 * 1024 && lds > granted) {
+        (void)hipFuncSetAttribute((const void *)subsample_points_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        granted = lds;
+    }
+    ProfScope ps(as_stream(stream), "subsample_points_kernel B=%d Lmax=%d num=%d", B, Lmax, num);
+    hipLaunchKernelGGL(subsample_points_kernel, dim3(B), dim3(256), lds, as_stream(stream), (unsigned)seed,
+                       (unsigned)(seed >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32), bank, lengths, cloud_ids, Lmax,
+                       num, out);
+    PNPP_CHECK_LAUNCH("subsample_points");
+    return PNPP_OK;
 }
 
 extern "C" int pnpp_sample_random_dev(uint64_t seed, uint64_t *stream_id_dev, uint64_t offset, int B, int N, int npoint,

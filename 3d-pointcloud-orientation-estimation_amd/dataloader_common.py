@@ -61,3 +61,70 @@ def sample_pts(arr, num=10_000):
         return np.asarray(arr)
     idx = np.random.choice(n, num, replace=n < num)
     return np.asarray(arr)[idx]
+
+
+class DeviceCloudBank:
+    """Full clouds resident in HBM with on-device `sample_pts` (throughput mode of the data path).
+
+    The reference draws `np.random.choice(len, num, replace=len<num)` per item on the host every epoch
+    (dataloader_single_peak_vonMises.py:12-14); at the rates the GPU path sustains that and the host-to-device copy of
+    every batch are the bottleneck.  Here every cloud is uploaded once (padded to the longest, 288 GB of HBM hold
+    millions of 10k-point clouds) and a batch is drawn by one kernel launch: `sample(cloud_ids, num_points)` returns
+    a fresh (B, num_points, 3) float32 device tensor with the same distribution as sample_pts -- without replacement
+    when the cloud has enough points, with replacement otherwise.  Draws are a pure function of (seed, draw counter).
+    """
+    MAX_POINTS = 16383  # LDS-resident key table of the kernel
+
+    def __init__(self, clouds, device, seed: int = 0):
+        import torch
+        clouds = [np.asarray(c, dtype=np.float32).reshape(-1, 3) for c in clouds]
+        if not clouds:
+            raise ValueError("DeviceCloudBank: no clouds")
+        longest = max(len(c) for c in clouds)
+        if longest > self.MAX_POINTS:
+            raise ValueError(f"DeviceCloudBank: a cloud has {longest} points, the on-device sampler takes at most "
+                             f"{self.MAX_POINTS}; thin it once on the host first")
+        lmax = max(longest, 1)
+        host = np.zeros((len(clouds), lmax, 3), np.float32)
+        for i, c in enumerate(clouds):
+            host[i, :len(c)] = c
+        self.bank = torch.from_numpy(host).to(device)
+        self.lengths = torch.tensor([len(c) for c in clouds], dtype=torch.int32, device=device)
+        self.seed, self.draws = int(seed), 0
+
+    def __len__(self):
+        return self.bank.shape[0]
+
+    def sample(self, cloud_ids, num_points: int):
+        import torch
+        from pnpp_hip import ops
+        ids = torch.as_tensor(cloud_ids, dtype=torch.int32, device=self.bank.device)
+        self.draws += 1
+        return ops.subsample_points(self.seed, self.draws, self.bank, self.lengths, num_points, ids)
+
+
+class BankLoader:
+    """Iterates (xyz (B,num_points,3), *targets[ids]) batches entirely on the device: the loaders' shuffle + the bank's
+    on-device subsampling; drop-in for a torch DataLoader in pnpp_hip.trainer.fit / evaluate."""
+
+    def __init__(self, bank: DeviceCloudBank, targets, num_points: int, batch: int, shuffle: bool, seed: int = 0,
+                 drop_last: bool = False):
+        import torch
+        self.bank, self.num_points, self.batch, self.shuffle, self.drop_last = bank, num_points, batch, shuffle, drop_last
+        self.targets = [t.to(bank.bank.device) for t in targets]
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def __len__(self):
+        n = len(self.bank)
+        return n // self.batch if self.drop_last else (n + self.batch - 1) // self.batch
+
+    def __iter__(self):
+        import torch
+        n = len(self.bank)
+        order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+        for i in range(0, n, self.batch):
+            ids = order[i:i + self.batch]
+            if self.drop_last and len(ids) < self.batch:
+                break
+            dev_ids = ids.to(self.bank.bank.device)
+            yield (self.bank.sample(dev_ids, self.num_points), *(t[dev_ids] for t in self.targets))

@@ -132,6 +132,28 @@ def sample_random_dev(seed: int, counter: torch.Tensor, offset: int, B: int, N: 
     return out
 
 
+def subsample_points(seed: int, stream_id: int, bank: torch.Tensor, lengths: torch.Tensor, num: int,
+                     cloud_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`num` points of each selected cloud of a device-resident bank (n_clouds,Lmax,3): without replacement where the
+    cloud has at least `num` points, with replacement otherwise (dataloader_*: sample_pts).  Returns (B,num,3)."""
+    bank = _f32(bank, "bank")
+    _need_gpu(lengths, "lengths")
+    if bank.dim() != 3 or bank.shape[2] != 3 or lengths.dtype != torch.int32 or lengths.numel() != bank.shape[0]:
+        raise ValueError("subsample_points: bank must be (n_clouds,Lmax,3) float32 and lengths (n_clouds,) int32")
+    lengths = lengths.contiguous()
+    if cloud_ids is not None:
+        _need_gpu(cloud_ids, "cloud_ids")
+        cloud_ids = cloud_ids.to(torch.int32).contiguous()
+        if cloud_ids.numel() and (int(cloud_ids.min()) < 0 or int(cloud_ids.max()) >= bank.shape[0]):
+            raise IndexError("subsample_points: cloud id out of range")
+    B = bank.shape[0] if cloud_ids is None else cloud_ids.numel()
+    out = torch.empty(B, int(num), 3, device=bank.device, dtype=torch.float32)
+    L.check(L.lib().pnpp_subsample_points(int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1), bank.data_ptr(),
+                                          lengths.data_ptr(), _p(cloud_ids), B, bank.shape[1], int(num), out.data_ptr(),
+                                          _stream()))
+    return out
+
+
 class _IndexPoints(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points, idx):

@@ -75,6 +75,13 @@ int pnpp_ball_query(const float *new_xyz, const float *xyz, int B, int S, int N,
  * calls (throughput mode; parity mode replays the CPU generator on the host and passes the indices in).
  * Counter-based: the result is a pure function of (seed, stream_id, b).  out (B,npoint) int32. */
 int pnpp_sample_random(uint64_t seed, uint64_t stream_id, int B, int N, int npoint, int32_t *out, void *stream);
+/* dataloader_single_peak_vonMises.py:12-14 (and the two other dataloaders): sample_pts = np.random.choice(len, num,
+ * replace=len<num) rows of a cloud -- on the device, for a bank of full clouds resident in HBM: bank (n_clouds,Lmax,3),
+ * lengths (n_clouds) valid rows per cloud, cloud_ids (B) bank row of every batch slot (NULL: slot b reads cloud b).
+ * out (B,num,3): an ordered uniform subset without replacement where lengths >= num, uniform draws with replacement
+ * where 0 < lengths < num, zeros for an empty cloud.  Pure function of (seed, stream_id, slot); Lmax <= 16383. */
+int pnpp_subsample_points(uint64_t seed, uint64_t stream_id, const float *bank, const int32_t *lengths,
+                          const int32_t *cloud_ids, int B, int Lmax, int num, float *out, void *stream);
 /* Same, with the stream id read from DEVICE memory at kernel time: stream_id = stream_id_dev[0] + offset, and the
  * kernel post-increments stream_id_dev[0] once every workgroup has read it -- the launch can be captured into a
  * hipGraph and still draws fresh centres on every replay.  stream_id_dev points at TWO uint64 words: the counter and

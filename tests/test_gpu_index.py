@@ -177,3 +177,54 @@ def test_models_base_surface(oracle, golden):
     assert np.array_equal(np.sort(idx.cpu().numpy(), -1), g["knn_idx1_sorted"])
     d = base.square_distance(new, xyz)
     assert d.shape == (2, 128, 1024)
+
+
+def test_subsample_points_on_device(ops):
+    """sample_pts on the device: without replacement when the cloud is large enough, with replacement otherwise."""
+    import dataloader_common as dc
+    rng = np.random.default_rng(0)
+    lens = [5000, 300, 1024, 0, 1, 16383]
+    clouds = [rng.standard_normal((n, 3)).astype(np.float32) + 10.0 * i for i, n in enumerate(lens)]
+    bank = dc.DeviceCloudBank(clouds, "cuda", seed=7)
+    num = 1024
+    ids = torch.tensor([0, 1, 2, 3, 4, 5, 0])
+    out = bank.sample(ids, num).cpu().numpy()
+    assert out.shape == (7, num, 3)
+    for slot, cid in enumerate(ids.tolist()):
+        rows, src = out[slot], clouds[cid]
+        if len(src) == 0:
+            assert np.all(rows == 0)
+            continue
+        src_set = {r.tobytes() for r in src}
+        assert all(r.tobytes() in src_set for r in rows)                       # every drawn row is a point of ITS cloud
+        distinct = len({r.tobytes() for r in rows})
+        if len(src) >= num:
+            assert distinct == num                                             # without replacement
+        else:
+            assert distinct <= len(src) and (len(src) == 1 or distinct > 0.8 * min(len(src), num) * 0.6)
+    assert not np.array_equal(out[0], out[6])                                  # slots draw independently
+    # len == num: a permutation of the cloud
+    assert {r.tobytes() for r in out[2]} == {r.tobytes() for r in clouds[2]}
+    # pure function of (seed, draw counter); a new draw differs
+    again = dc.DeviceCloudBank(clouds, "cuda", seed=7).sample(ids, num).cpu().numpy()
+    assert np.array_equal(out, again)
+    assert not np.array_equal(out, bank.sample(ids, num).cpu().numpy())
+    # uniform marginals: each of the 5000 points of cloud 0 is picked with probability num/5000 per draw
+    cnt = np.zeros(5000)
+    lut = {r.tobytes(): i for i, r in enumerate(clouds[0])}
+    big = dc.DeviceCloudBank([clouds[0]], "cuda", seed=3)
+    for _ in range(30):
+        rows = big.sample(torch.zeros(16, dtype=torch.int64), num).cpu().numpy().reshape(-1, 3)
+        np.add.at(cnt, [lut[r.tobytes()] for r in rows], 1)
+    exp = 30 * 16 * num / 5000
+    chi2 = ((cnt - exp) ** 2 / exp).sum()
+    assert 0.7 * 5000 < chi2 < 1.1 * 5000, chi2                                # ~ (1 - num/5000) * 4999 = 3975 +- 100
+    # loader on top of it
+    tgt = torch.arange(len(clouds), dtype=torch.float32)
+    seen = []
+    for xyz, t in dc.BankLoader(bank, [tgt], 256, batch=4, shuffle=True, seed=1):
+        assert xyz.is_cuda and xyz.shape[1:] == (256, 3) and t.is_cuda
+        seen += t.cpu().tolist()
+    assert sorted(seen) == list(range(len(clouds)))
+    with pytest.raises(ValueError):
+        dc.DeviceCloudBank([np.zeros((20000, 3), np.float32)], "cuda")
