@@ -1,0 +1,216 @@
+// transformer_kernels.hip -- forward kernels of the point-transformer configuration (SURVEY section 8 f-4,
+// reference models/point_transformer.py:4-20 = nn.TransformerEncoderLayer(d_model=64, nhead=4, batch_first=True) x 6).
+//
+//   linear_smallk_kernel   input_proj: y = x W^T + b for a reduction length of at most 8 (xyz -> 64 channels)
+//   attention_fwd_kernel   softmax(q k^T / sqrt(d_head)) v per (cloud, head), flash style: the N x N score matrix is
+//                          never written; float32 MFMA (v_mfma_f32_32x32x2_f32), online softmax, log-sum-exp kept
+//   add_layernorm_kernel   y = LayerNorm(x + r)  (post-norm residual blocks)
+//   mean_points_kernel     mean over the points of a cloud
+//
+// The dense projections (in_proj, out_proj, linear1 + ReLU, linear2, fc_out) go through pnpp_fc_forward.
+#include "common.h"
+
+namespace pnpp {
+
+constexpr int SMALLK_MAX = 8;
+
+__global__ void __launch_bounds__(256) linear_smallk_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ b, int M, int K, int N,
+                                                            float *__restrict__ y) {
+    // lane = output channel (coalesced stores), rows strided over the grid; K <= 8 inputs per row are broadcast loads
+    const int n = threadIdx.x % 64, rl = threadIdx.x / 64;
+    for (int n0 = 0; n0 < N; n0 += 64) {
+        const int c = n0 + n;
+        float wr[SMALLK_MAX];
+#pragma unroll
+        for (int k = 0; k < SMALLK_MAX; ++k) wr[k] = (c < N && k < K) ? w[(size_t)c * K + k] : 0.f;
+        const float bias = (c < N && b) ? b[c] : 0.f;
+        for (int m = blockIdx.x * 4 + rl; m < M; m += gridDim.x * 4) {
+            float acc = bias;
+#pragma unroll
+            for (int k = 0; k < SMALLK_MAX; ++k)
+                if (k < K) acc = fmaf(x[(size_t)m * K + k], wr[k], acc);
+            if (c < N) y[(size_t)m * N + c] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention forward, head dimension 16.  qkv (B, N, 3E) row-major with the in_proj bias already added, E = H * 16:
+// q = qkv[..., 0:E], k = qkv[..., E:2E], v = qkv[..., 2E:3E]; head h owns columns h*16 .. h*16+15 of each.
+// Workgroup = 128 queries of one (cloud, head): 4 waves x 32 queries.  Keys / values stream through LDS in blocks of 32.
+//
+// Layouts (v_mfma_f32_32x32x2_f32: A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31],
+// D[row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col = lane & 31] in register r):
+//   S^T = K Q^T : A = key block (i = key, k = dim), B = Q^T (k = dim, j = query)  ->  lane = query, register r = key
+//                 kappa(r, lh) = (r & 3) + 8 (r >> 2) + 4 lh: a query's row of scores sits in the 16 registers of two lanes,
+//                 so the row maximum and row sum are register reductions plus one cross-half shuffle;
+//   O^T = V^T P^T: A = V^T (i = dim, k = key), B = P^T (k = key, j = query): the k index of an MFMA step is free to name
+//                 any key as long as A and B agree, and step s with k = lh naming key kappa(s, lh) makes the B operand
+//                 exactly score register s -- the probabilities never move between lanes.
+// ---------------------------------------------------------------------------------------------
+constexpr int ATT_DH = 16;
+constexpr int ATT_KP = 17;  // LDS pitch of the key / value tiles
+
+__global__ void __launch_bounds__(256)
+attention_fwd_kernel(const float *__restrict__ qkv, int N, int H, float scale, float *__restrict__ out,
+                     float *__restrict__ lse) {
+    __shared__ float Ks[2][32][ATT_KP], Vs[2][32][ATT_KP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z, E = H * ATT_DH, ld = 3 * E;
+    const float *base = qkv + (size_t)b * N * ld;
+    const int q = blockIdx.x * 128 + wave * 32 + l31;  // this lane's query (N % 128 == 0: always valid)
+
+    float qreg[8];  // Q^T operand: dims 2s + lh of this lane's query, pre-scaled (1/sqrt(16) is exact)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qreg[s] = base[(size_t)q * ld + h * ATT_DH + 2 * s + lh] * scale;
+
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging map: threads 0..127 load the key tile, 128..255 the value tile, one float4 each
+    const int st_row = (tid & 127) >> 2, st_c4 = 4 * (tid & 3);
+    const float *st_src = base + (tid < 128 ? E : 2 * E) + h * ATT_DH + st_c4;
+    auto fetch = [&](int kb) { return *reinterpret_cast<const float4 *>(st_src + (size_t)(kb * 32 + st_row) * ld); };
+    auto put = [&](const float4 &v, int buf) {
+        float *d = (tid < 128 ? &Ks[buf][st_row][st_c4] : &Vs[buf][st_row][st_c4]);
+        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+    };
+    const int nkb = N / 32;
+    put(fetch(0), 0);
+    __syncthreads();
+    const float vmask = l31 < ATT_DH ? 1.f : 0.f;  // rows 16..31 of V^T do not exist
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        const float4 nxt = fetch(min(kb + 1, nkb - 1));  // in flight while this block is computed
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[buf][l31][2 * t + lh], qreg[t], s, 0, 0, 0);
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first block
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __expf(s[r] - m_new);
+            rs += s[r];
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[r] *= alpha;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int key = (t & 3) + 8 * (t >> 2) + 4 * lh;
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[buf][key][l31 & (ATT_DH - 1)] * vmask, s[t], o, 0, 0, 0);
+        }
+        if (kb + 1 < nkb) put(nxt, buf ^ 1);  // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+    const float inv = 1.f / l_run;
+    float *orow = out + ((size_t)b * N + q) * E + h * ATT_DH;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) orow[(r & 3) + 8 * (r >> 2) + 4 * lh] = o[r] * inv;
+    if (lse && lh == 0) lse[((size_t)b * H + h) * N + q] = m_run + logf(l_run);
+}
+
+// y = LayerNorm(x + r) over the last dimension E (64 or 128); one wave per row, two-pass statistics in float64
+__global__ void __launch_bounds__(256) add_layernorm_kernel(const float *__restrict__ x, const float *__restrict__ r,
+                                                            const float *__restrict__ w, const float *__restrict__ bias,
+                                                            int M, int E, float eps, float *__restrict__ y) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[2];
+    double sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = c < E ? x[(size_t)row * E + c] + (r ? r[(size_t)row * E + c] : 0.f) : 0.f;
+        sum += (double)v[j];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sum += shfl_xor_f64(sum, m);
+    const double mu = sum / (double)E;
+    double sq = 0.0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (lane + 64 * j < E) sq += ((double)v[j] - mu) * ((double)v[j] - mu);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sq += shfl_xor_f64(sq, m);
+    const double is = 1.0 / sqrt(sq / (double)E + (double)eps);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = lane + 64 * j;
+        if (c < E) y[(size_t)row * E + c] = (float)(((double)v[j] - mu) * is * (double)w[c] + (double)bias[c]);
+    }
+}
+
+// y[b][c] = mean_n x[b][n][c]; one workgroup per cloud, fixed-order float64 sums
+__global__ void __launch_bounds__(256) mean_points_kernel(const float *__restrict__ x, int N, int E, float *__restrict__ y) {
+    __shared__ double red[4][64];
+    const int b = blockIdx.x, c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < E; c0 += 64) {
+        double acc = 0.0;
+        if (c0 + c < E)
+            for (int n = rl; n < N; n += 4) acc += (double)x[((size_t)b * N + n) * E + c0 + c];
+        red[rl][c] = acc;
+        __syncthreads();
+        if (rl == 0 && c0 + c < E) y[(size_t)b * E + c0 + c] = (float)(((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) / (double)N);
+        __syncthreads();
+    }
+}
+
+}  // namespace pnpp
+
+using namespace pnpp;
+
+extern "C" int pnpp_linear_smallk(const float *x, const float *w, const float *b, int M, int K, int N, float *y, void *stream) {
+    PNPP_REQUIRE(x && w && y, PNPP_ERR_ARG, "linear_smallk: null pointer");
+    PNPP_REQUIRE(M > 0 && N > 0 && K > 0 && K <= SMALLK_MAX, PNPP_ERR_ARG, "linear_smallk: M=%d N=%d K=%d (K <= %d)", M, N, K,
+                 SMALLK_MAX);
+    const int grid = cdiv(M, 4) < 4096 ? cdiv(M, 4) : 4096;
+    ProfScope ps(as_stream(stream), "linear_smallk_kernel M=%d N=%d K=%d", M, N, K);
+    hipLaunchKernelGGL(linear_smallk_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, w, b, M, K, N, y);
+    PNPP_CHECK_LAUNCH("linear_smallk");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_attention_fwd(const float *qkv, int B, int N, int H, int head_dim, float *out, float *lse, void *stream) {
+    PNPP_REQUIRE(qkv && out, PNPP_ERR_ARG, "attention_fwd: null pointer");
+    PNPP_REQUIRE(B > 0 && N > 0 && H > 0, PNPP_ERR_ARG, "attention_fwd: non-positive size");
+    PNPP_REQUIRE(head_dim == ATT_DH, PNPP_ERR_ARG, "attention_fwd: head dimension %d is not supported (only %d)", head_dim, ATT_DH);
+    PNPP_REQUIRE(N % 128 == 0, PNPP_ERR_ARG, "attention_fwd: N=%d must be a multiple of 128", N);
+    PNPP_REQUIRE(B <= 65535 && H <= 65535, PNPP_ERR_ARG, "attention_fwd: B or H exceeds the grid limit");
+    ProfScope ps(as_stream(stream), "attention_fwd_kernel B=%d N=%d H=%d", B, N, H);
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(N / 128, H, B), dim3(256), 0, as_stream(stream), qkv, N, H,
+                       1.0f / sqrtf((float)head_dim), out, lse);
+    PNPP_CHECK_LAUNCH("attention_fwd");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_add_layernorm(const float *x, const float *r, const float *w, const float *b, int M, int E, float eps,
+                                  float *y, void *stream) {
+    PNPP_REQUIRE(x && w && b && y, PNPP_ERR_ARG, "add_layernorm: null pointer");
+    PNPP_REQUIRE(M > 0 && E > 0 && E <= 128, PNPP_ERR_ARG, "add_layernorm: M=%d E=%d (E <= 128)", M, E);
+    ProfScope ps(as_stream(stream), "add_layernorm_kernel M=%d E=%d", M, E);
+    hipLaunchKernelGGL(add_layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, as_stream(stream), x, r, w, b, M, E, eps, y);
+    PNPP_CHECK_LAUNCH("add_layernorm");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_mean_points(const float *x, int B, int N, int E, float *y, void *stream) {
+    PNPP_REQUIRE(x && y, PNPP_ERR_ARG, "mean_points: null pointer");
+    PNPP_REQUIRE(B > 0 && N > 0 && E > 0, PNPP_ERR_ARG, "mean_points: non-positive size");
+    ProfScope ps(as_stream(stream), "mean_points_kernel B=%d N=%d E=%d", B, N, E);
+    hipLaunchKernelGGL(mean_points_kernel, dim3(B), dim3(256), 0, as_stream(stream), x, N, E, y);
+    PNPP_CHECK_LAUNCH("mean_points");
+    return PNPP_OK;
+}

@@ -93,6 +93,10 @@ SIGNATURES = {
     "pnpp_orth_loss": (_i, [_fp, _fp, _i, _i, _fp, _fp, _fp, _fp]),
     "pnpp_proj_probs": (_i, [_fp, _fp, _i, _i, _fp, _fp]),
     "pnpp_proj_probs_bwd": (_i, [_fp, _fp, _fp, _i, _i, _fp, _fp]),
+    "pnpp_linear_smallk": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
+    "pnpp_attention_fwd": (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _fp]),
+    "pnpp_add_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp, _fp]),
+    "pnpp_mean_points": (_i, [_fp, _i, _i, _i, _fp, _fp]),
     "pnpp_adam_step": (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _f, _f, _f, _f, _fp]),
     "pnpp_sumsq": (_i, [_fp, _sz, _fp, _fp, _sz, _fp]),
 }

@@ -29,6 +29,7 @@ SOURCES = {
     "loss_kernels.hip": [],
     "sa_api.hip": [],
     "fc_api.hip": [],
+    "transformer_kernels.hip": [],
 }
 
 

@@ -259,6 +259,20 @@ int pnpp_orth_loss(const float *a, const float *b, int B, int C, float *loss, fl
 int pnpp_proj_probs(const float *vec, const float *dirs, int B, int D, float *probs, void *stream);
 int pnpp_proj_probs_bwd(const float *vec, const float *dirs, const float *dprobs, int B, int D, float *dvec, void *stream);
 
+/* Point-transformer configuration (models/point_transformer.py:4-20), forward pass.
+ * input_proj (nn.Linear with at most 8 inputs): y (M,N) = x (M,K) w^T (N,K) + b. */
+int pnpp_linear_smallk(const float *x, const float *w, const float *b, int M, int K, int N, float *y, void *stream);
+/* nn.MultiheadAttention core (torch.nn.functional.multi_head_attention_forward between in_proj and out_proj), eval mode:
+ * qkv (B,N,3E) with the in_proj bias added, E = H*head_dim, head h = columns h*head_dim.. of each third;
+ * out (B,N,E) = concat_h softmax(q_h k_h^T / sqrt(head_dim)) v_h; lse (B,H,N) optional log-sum-exp of the scaled scores.
+ * The N x N matrix is never materialised.  head_dim must be 16 and N a multiple of 128. */
+int pnpp_attention_fwd(const float *qkv, int B, int N, int H, int head_dim, float *out, float *lse, void *stream);
+/* Post-norm residual block: y (M,E) = LayerNorm(x + r) * w + b over the last dimension (r may be NULL), E <= 128. */
+int pnpp_add_layernorm(const float *x, const float *r, const float *w, const float *b, int M, int E, float eps, float *y,
+                       void *stream);
+/* x.mean(dim=1): y (B,E) = mean over the N points of x (B,N,E). */
+int pnpp_mean_points(const float *x, int B, int N, int E, float *y, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Step glue on one flat parameter / gradient buffer
  * (train_single_peak_vonMises_KL.py:80,85; train_multi_peaks_vonMises_KL.py:221,235-236)

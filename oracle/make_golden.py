@@ -469,6 +469,47 @@ def golden_f3():
     save("f3.npz", **out)
 
 
+def golden_pt():
+    """models/point_transformer.py: the reference model in eval mode (the constructor's
+    dropout 0.1 is then inactive) in float32 and float64, and in train mode with every dropout probability set to 0
+    with an MSE loss to a target direction (no reference script trains this model; the harness is ours)."""
+    from models.point_transformer import PointTransformer
+    B, N = 4, 256
+    xyz, _, _, fwd = R.synthetic_clouds(B, N, seed=99)
+    out = dict(xyz=n(xyz), target=n(fwd[:B]))
+    for dt_name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        torch.manual_seed(42)
+        model = PointTransformer()
+        torch.manual_seed(5)
+        with torch.no_grad():   # the clones of one encoder layer start identical; perturb them so that layers differ
+            for p in model.parameters():
+                p.add_(0.02 * torch.randn_like(p))
+        if dt_name == "f32":
+            out.update({f"pt_{k}": v for k, v in _param_checksums(model).items()})
+        model = model.to(dt).eval()
+        with torch.no_grad():
+            y = model(xyz.to(dt))
+        out[f"pt_{dt_name}.eval_out"] = n(y)
+        # per-layer activations through the reference's own encoder layers (slow path: no nested tensors in train mode)
+        model.train()
+        for m in model.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+            if isinstance(m, nn.MultiheadAttention):
+                m.dropout = 0.0
+        x = model.input_proj(xyz.to(dt))
+        for li, layer in enumerate(model.transformer.layers):
+            x = layer(x)
+            out[f"pt_{dt_name}.layer{li}_ck"] = np.array([x.double().sum().item(), x.double().abs().sum().item()])
+        y = model(xyz.to(dt))
+        loss = ((y - fwd[:B].to(dt)) ** 2).mean()
+        loss.backward()
+        out[f"pt_{dt_name}.train_out"], out[f"pt_{dt_name}.loss"] = n(y), np.array(loss.item())
+        for k, v in _grad_summary(model).items():
+            out[f"pt_{dt_name}.{k}"] = v
+    save("pt.npz", **out)
+
+
 def golden_vm_gt():
     """data_process/demo_vm_gt/*.txt + the mu values printed in 2d_single_peak_vM_test.ipynb."""
     d = os.path.join(REF, "data_process/demo_vm_gt")
@@ -490,6 +531,6 @@ def golden_vm_gt():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["index", "sa", "e2e", "kl", "debug_log", "vm_gt", "f3"]
+    which = sys.argv[1:] or ["index", "sa", "e2e", "kl", "debug_log", "vm_gt", "f3", "pt"]
     for w in which:
         globals()[f"golden_{w}"]()

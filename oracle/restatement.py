@@ -290,6 +290,38 @@ def proj_probs(vec, dirs):
     return sims / sims.sum(dim=1, keepdim=True).clamp(min=1e-8)
 
 
+def _layer_norm(x, w, b, eps=1e-5):
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def point_transformer_forward(xyz, P, num_heads=4, depth=6, return_layers=False):
+    """models/point_transformer.py:15-20 in eval mode (all dropouts are identities): input_proj, `depth` post-norm
+    nn.TransformerEncoderLayer(d_model=64, nhead=4, dim_feedforward=2048, relu) blocks, mean over the points, fc_out.
+    Restated from torch.nn.functional.multi_head_attention_forward / TransformerEncoderLayer.forward (norm_first=False):
+        q,k,v = split(x W_in^T + b_in); per head: softmax(q k^T / sqrt(d_head)) v; concat heads; out_proj
+        x = LN1(x + attn);  x = LN2(x + W2 relu(W1 x + b1) + b2)"""
+    x = xyz.to(P["input_proj.weight"].dtype) @ P["input_proj.weight"].t() + P["input_proj.bias"]
+    B, N, E = x.shape
+    dh = E // num_heads
+    layers = []
+    for l in range(depth):
+        pre = f"transformer.layers.{l}."
+        qkv = x @ P[pre + "self_attn.in_proj_weight"].t() + P[pre + "self_attn.in_proj_bias"]
+        q, k, v = (t.reshape(B, N, num_heads, dh).transpose(1, 2) for t in qkv.split(E, dim=-1))   # (B,H,N,dh)
+        att = torch.softmax((q * (1.0 / math.sqrt(dh))) @ k.transpose(-1, -2), dim=-1)
+        o = (att @ v).transpose(1, 2).reshape(B, N, E)
+        o = o @ P[pre + "self_attn.out_proj.weight"].t() + P[pre + "self_attn.out_proj.bias"]
+        x = _layer_norm(x + o, P[pre + "norm1.weight"], P[pre + "norm1.bias"])
+        h = torch.relu(x @ P[pre + "linear1.weight"].t() + P[pre + "linear1.bias"])
+        f = h @ P[pre + "linear2.weight"].t() + P[pre + "linear2.bias"]
+        x = _layer_norm(x + f, P[pre + "norm2.weight"], P[pre + "norm2.bias"])
+        layers.append(x)
+    out = x.mean(dim=1) @ P["fc_out.weight"].t() + P["fc_out.bias"]
+    return (out, layers) if return_layers else out
+
+
 def mvm_forward(xyz32, P, centres, drop_masks=(None, None), training=True, bn_state=None,
                 max_K=4, kappa_max=80.0, p_drop=0.4, temp=0.7, **bk):
     """PointNetPPMvM.forward (pointnet_pp_mvM.py:75-127) -> (mu, kappa, weight), each (B,K).

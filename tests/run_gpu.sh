@@ -3,7 +3,7 @@
 # usage: tests/run_gpu.sh <logfile> [pytest args...]
 log=$1; shift
 : > "$log"
-for f in tests/test_gpu_index.py tests/test_gpu_head_loss.py tests/test_gpu_sa.py tests/test_gpu_e2e.py tests/test_gpu_f3.py tests/test_gpu_train.py; do
+for f in tests/test_gpu_index.py tests/test_gpu_head_loss.py tests/test_gpu_sa.py tests/test_gpu_e2e.py tests/test_gpu_f3.py tests/test_gpu_pt.py tests/test_gpu_train.py; do
   echo "=== $f" >> "$log"
   timeout -k 10 300 python -m pytest "$f" -m gpu -q -p no:cacheprovider --maxfail=6 -s "$@" >> "$log" 2>&1
   rc=$?

@@ -1,0 +1,86 @@
+"""GPU parity of the point-transformer forward path: kernels vs float64 restatements, and the drop-in
+model vs the numbers the reference model itself produced (tests/golden/pt.npz, eval mode and train mode with p = 0)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _pt_model():
+    from models.point_transformer import PointTransformer
+    torch.manual_seed(42)
+    m = PointTransformer()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    return m
+
+
+def test_attention_forward_vs_float64():
+    from pnpp_hip import transformer as T
+    g = torch.Generator().manual_seed(0)
+    for B, N, H in ((2, 256, 4), (1, 128, 1), (3, 384, 2)):
+        E = 16 * H
+        qkv = torch.randn(B, N, 3 * E, generator=g) * 1.5
+        qkv[0, :, :E] *= 3.0                                   # a cloud with peaked softmax rows
+        out, lse = T.attention(qkv.cuda(), H, want_lse=True)
+        q, k, v = (t.double().reshape(B, N, H, 16).transpose(1, 2) for t in qkv.split(E, dim=-1))
+        s = (q * 0.25) @ k.transpose(-1, -2)
+        ref = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, N, E)
+        assert float((out.cpu().double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (B, N, H)
+        assert float((lse.cpu().double() - torch.logsumexp(s, dim=-1)).abs().max()) <= 2e-5
+    with pytest.raises(ValueError):
+        T.attention(torch.zeros(1, 100, 192, device="cuda"), 4)          # N not a multiple of 128
+    with pytest.raises(ValueError):
+        T.attention(torch.zeros(1, 128, 96, device="cuda"), 4)           # head dimension 8
+
+
+def test_layernorm_mean_and_small_linear_vs_float64():
+    from pnpp_hip import transformer as T
+    g = torch.Generator().manual_seed(1)
+    x, r = torch.randn(1000, 64, generator=g) * 3 + 1, torch.randn(1000, 64, generator=g)
+    ln = torch.nn.LayerNorm(64)
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.2, generator=g), ln.bias.normal_(0.0, 0.2, generator=g)
+    ref = torch.nn.functional.layer_norm((x + r).double(), (64,), ln.weight.double(), ln.bias.double(), 1e-5)
+    got = T.add_layernorm(x.cuda(), r.cuda(), ln.cuda())
+    assert float((got.cpu().double() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    xs = torch.randn(3, 777, 64, generator=g)
+    assert float((T.mean_points(xs.cuda()).cpu().double() - xs.double().mean(1)).abs().max()) <= 1e-6
+    lin = torch.nn.Linear(3, 64)
+    pts = torch.randn(5000, 3, generator=g)
+    ref = pts.double() @ lin.weight.double().t() + lin.bias.double()
+    assert float((T.linear_smallk(pts.cuda(), lin.cuda()).cpu().double() - ref).abs().max()) <= 1e-6
+
+
+def test_point_transformer_forward_matches_reference_capture(golden):
+    g = golden("pt.npz")
+    model = _pt_model().cuda().eval()
+    out = model(_t(g["xyz"]).cuda()).cpu().double().numpy()
+    ref64, ref32 = g["pt_f64.eval_out"], g["pt_f32.eval_out"]
+    d64 = np.abs(out - ref64).max()
+    print(f"\nHIP vs reference fp64: {d64:.2e}; reference fp32 vs its own fp64: {np.abs(ref32 - ref64).max():.2e}")
+    assert d64 <= 2e-5 * max(1.0, np.abs(ref64).max())
+    assert np.abs(out - g["pt_f64.train_out"]).max() <= 2e-5 * max(1.0, np.abs(ref64).max())   # train mode, p = 0
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model(_t(g["xyz"]).cuda())                          # no backward yet, and no silent fallback
+    with torch.no_grad():                                   # no_grad is still the forward path
+        assert np.abs(model(_t(g["xyz"]).cuda()).cpu().double().numpy() - ref64).max() <= 2e-5
+
+
+def test_point_transformer_forward_larger_cloud_vs_oracle(oracle):
+    model = _pt_model()
+    P64 = {k: v.double() for k, v in model.state_dict().items()}
+    xyz, _, _, _ = oracle.synthetic_clouds(2, 1024, seed=3)
+    ref = oracle.point_transformer_forward(xyz.double(), P64)
+    out = model.cuda().eval()(xyz.cuda()).cpu().double()
+    assert float((out - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
