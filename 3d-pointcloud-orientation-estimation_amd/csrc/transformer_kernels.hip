@@ -9,6 +9,7 @@
 //
 // The dense projections (in_proj, out_proj, linear1 + ReLU, linear2, fc_out) go through pnpp_fc_forward.
 #include "common.h"
+#include "kernels.h"
 
 namespace pnpp {
 
@@ -168,6 +169,259 @@ __global__ void __launch_bounds__(256) mean_points_kernel(const float *__restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward kernels (same MFMA layout algebra as the forward: an accumulator tile with lane = X and register = Y is,
+// unchanged, the B operand of a product that contracts over Y and whose output columns are X)
+// ---------------------------------------------------------------------------------------------
+
+// input_proj backward: dW (N,K) = dy^T x and db (N) = column sums of dy; one [N][16] partial per 256 rows
+// (columns 0..K-1: dW, column K: db), combined by slab_reduce.  x is data: no dx.
+__global__ void __launch_bounds__(256) linear_smallk_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                                int M, int K, int N, float *__restrict__ slab) {
+    __shared__ float red[4][64][SMALLK_MAX + 1];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, m0 = blockIdx.x * 256;
+    for (int c0 = 0; c0 < N; c0 += 64) {
+        const int c = c0 + cl;
+        float acc[SMALLK_MAX + 1];
+#pragma unroll
+        for (int k = 0; k <= SMALLK_MAX; ++k) acc[k] = 0.f;
+        for (int r = rl; r < 256; r += 4) {
+            const int m = m0 + r;
+            if (m >= M) break;
+            const float g = c < N ? dy[(size_t)m * N + c] : 0.f;
+#pragma unroll
+            for (int k = 0; k < SMALLK_MAX; ++k)
+                if (k < K) acc[k] = fmaf(g, x[(size_t)m * K + k], acc[k]);
+            acc[SMALLK_MAX] += g;
+        }
+#pragma unroll
+        for (int k = 0; k <= SMALLK_MAX; ++k) red[rl][cl][k] = acc[k];
+        __syncthreads();
+        for (int f = threadIdx.x; f < 64 * (SMALLK_MAX + 1); f += 256) {
+            const int ch = f / (SMALLK_MAX + 1), k = f % (SMALLK_MAX + 1);
+            if (c0 + ch < N && (k < K || k == SMALLK_MAX)) {
+                const float t = (red[0][ch][k] + red[1][ch][k]) + (red[2][ch][k] + red[3][ch][k]);
+                slab[((size_t)blockIdx.x * N + c0 + ch) * 16 + (k == SMALLK_MAX ? K : k)] = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dQ: a wave owns 32 queries and walks the key blocks.  S^T and dP^T tiles are lane = query, register = key, so the
+// per-query log-sum-exp and D = rowsum(dO * O) are per-lane scalars and dS^T is directly the B operand of dQ^T = K^T dS^T.
+// Also writes D (B,H,N) for the dK/dV kernel.
+__global__ void __launch_bounds__(256)
+attention_bwd_dq_kernel(const float *__restrict__ qkv, const float *__restrict__ o, const float *__restrict__ d_o,
+                        const float *__restrict__ lse, int N, int H, float scale, float *__restrict__ dqkv,
+                        float *__restrict__ dsum) {
+    __shared__ float Ks[2][32][ATT_KP], Vs[2][32][ATT_KP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z, E = H * ATT_DH, ld = 3 * E;
+    const float *base = qkv + (size_t)b * N * ld;
+    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    float qreg[8], doreg[8], dpart = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int d = h * ATT_DH + 2 * s + lh;
+        qreg[s] = base[(size_t)q * ld + d] * scale;
+        doreg[s] = d_o[((size_t)b * N + q) * E + d];
+        dpart = fmaf(doreg[s], o[((size_t)b * N + q) * E + d], dpart);
+    }
+    const float D = dpart + __shfl_xor(dpart, 32, 64);
+    const float L = lse[((size_t)b * H + h) * N + q];
+    if (lh == 0) dsum[((size_t)b * H + h) * N + q] = D;
+
+    f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+    const int st_row = (tid & 127) >> 2, st_c4 = 4 * (tid & 3);
+    const float *st_src = base + (tid < 128 ? E : 2 * E) + h * ATT_DH + st_c4;
+    auto fetch = [&](int kb) { return *reinterpret_cast<const float4 *>(st_src + (size_t)(kb * 32 + st_row) * ld); };
+    auto put = [&](const float4 &v, int buf) {
+        float *d = (tid < 128 ? &Ks[buf][st_row][st_c4] : &Vs[buf][st_row][st_c4]);
+        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+    };
+    const int nkb = N / 32;
+    put(fetch(0), 0);
+    __syncthreads();
+    const float vmask = l31 < ATT_DH ? 1.f : 0.f;
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        const float4 nxt = fetch(min(kb + 1, nkb - 1));
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[buf][l31][2 * t + lh], qreg[t], s, 0, 0, 0);     // S^T  = K Q^T
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[buf][l31][2 * t + lh], doreg[t], dp, 0, 0, 0);  // dP^T = V dO^T
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = __expf(s[r] - L) * (dp[r] - D);  // dS^T = P^T * (dP^T - D)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int key = (t & 3) + 8 * (t >> 2) + 4 * lh;
+            dq = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[buf][key][l31 & (ATT_DH - 1)] * vmask, s[t], dq, 0, 0, 0);
+        }
+        if (kb + 1 < nkb) put(nxt, buf ^ 1);
+        __syncthreads();
+    }
+    float *drow = dqkv + ((size_t)b * N + q) * ld + h * ATT_DH;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) drow[(r & 3) + 8 * (r >> 2) + 4 * lh] = dq[r] * scale;
+}
+
+// dK, dV: a wave owns 32 keys and walks the query blocks.  S and dP tiles are lane = key, register = query; P and dS are
+// directly the B operands of dV^T = dO^T P and dK^T = (scale Q)^T dS.  Per-query L and D come from LDS (one per register).
+__global__ void __launch_bounds__(256)
+attention_bwd_dkv_kernel(const float *__restrict__ qkv, const float *__restrict__ d_o, const float *__restrict__ lse,
+                         const float *__restrict__ dsum, int N, int H, float scale, float *__restrict__ dqkv) {
+    __shared__ float Qs[2][32][ATT_KP], Gs[2][32][ATT_KP], Ls[2][32], Ds[2][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z, E = H * ATT_DH, ld = 3 * E;
+    const float *base = qkv + (size_t)b * N * ld;
+    const int key = blockIdx.x * 128 + wave * 32 + l31;
+    float kreg[8], vreg[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        kreg[s] = base[(size_t)key * ld + E + h * ATT_DH + 2 * s + lh];
+        vreg[s] = base[(size_t)key * ld + 2 * E + h * ATT_DH + 2 * s + lh];
+    }
+    f32x16 dk, dv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[r] = 0.f, dv[r] = 0.f;
+    // staging: threads 0..127 the (scaled) query tile, 128..255 the dO tile; threads 0..31 / 32..63 also L / D
+    const int st_row = (tid & 127) >> 2, st_c4 = 4 * (tid & 3);
+    const float *q_src = base + h * ATT_DH + st_c4;
+    const float *g_src = d_o + (size_t)b * N * E + h * ATT_DH + st_c4;
+    const float *l_src = lse + ((size_t)b * H + h) * N, *d_src = dsum + ((size_t)b * H + h) * N;
+    auto fetch = [&](int qb) {
+        const int row = qb * 32 + st_row;
+        return tid < 128 ? *reinterpret_cast<const float4 *>(q_src + (size_t)row * ld) : *reinterpret_cast<const float4 *>(g_src + (size_t)row * E);
+    };
+    auto fetch_ld = [&](int qb) { return tid < 32 ? l_src[qb * 32 + tid] : (tid < 64 ? d_src[qb * 32 + tid - 32] : 0.f); };
+    auto put = [&](const float4 &v, float x, int buf) {
+        if (tid < 128) {
+            float *d = &Qs[buf][st_row][st_c4];
+            d[0] = v.x * scale, d[1] = v.y * scale, d[2] = v.z * scale, d[3] = v.w * scale;
+        } else {
+            float *d = &Gs[buf][st_row][st_c4];
+            d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+        }
+        if (tid < 32) Ls[buf][tid] = x;
+        else if (tid < 64) Ds[buf][tid - 32] = x;
+    };
+    const int nqb = N / 32;
+    put(fetch(0), fetch_ld(0), 0);
+    __syncthreads();
+    const float vmask = l31 < ATT_DH ? 1.f : 0.f;
+    for (int qb = 0; qb < nqb; ++qb) {
+        const int buf = qb & 1;
+        const float4 nxt = fetch(min(qb + 1, nqb - 1));
+        const float nxt_ld = fetch_ld(min(qb + 1, nqb - 1));
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[buf][l31][2 * t + lh], kreg[t], s, 0, 0, 0);   // S  = (scale Q) K^T
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[buf][l31][2 * t + lh], vreg[t], dp, 0, 0, 0);  // dP = dO V^T
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = (r & 3) + 8 * (r >> 2) + 4 * lh;       // the query this register belongs to
+            s[r] = __expf(s[r] - Ls[buf][qi]);                    // P
+            dp[r] = s[r] * (dp[r] - Ds[buf][qi]);                 // dS
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int qi = (t & 3) + 8 * (t >> 2) + 4 * lh;
+            dv = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[buf][qi][l31 & (ATT_DH - 1)] * vmask, s[t], dv, 0, 0, 0);   // dV^T += dO^T P
+            dk = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[buf][qi][l31 & (ATT_DH - 1)] * vmask, dp[t], dk, 0, 0, 0);  // dK^T += (scale Q)^T dS
+        }
+        if (qb + 1 < nqb) put(nxt, nxt_ld, buf ^ 1);
+        __syncthreads();
+    }
+    float *drow = dqkv + ((size_t)b * N + key) * ld + h * ATT_DH;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        drow[E + d] = dk[r];
+        drow[2 * E + d] = dv[r];
+    }
+}
+
+// LayerNorm(x + r) backward: u = x + r, xh = (u - mu) rstd (recomputed), g = dy * w:
+//   du = rstd * (g - mean(g) - xh * mean(g * xh))  (= dx = dr);  dw = sum_rows dy * xh;  db = sum_rows dy
+// One wave per row; the column sums go to one [2][E] partial per workgroup of 64 rows (slab_reduce combines them).
+__global__ void __launch_bounds__(256) add_layernorm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ r,
+                                                                const float *__restrict__ w, const float *__restrict__ dy,
+                                                                int M, int E, float eps, float *__restrict__ du,
+                                                                float *__restrict__ slab) {
+    __shared__ float red[4][2][128];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float aw[2] = {0.f, 0.f}, ab[2] = {0.f, 0.f};
+    for (int it = 0; it < 16; ++it) {
+        const int row = blockIdx.x * 64 + it * 4 + wv;
+        if (row >= M) break;
+        float v[2], g[2];
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = lane + 64 * j;
+            v[j] = c < E ? x[(size_t)row * E + c] + (r ? r[(size_t)row * E + c] : 0.f) : 0.f;
+            g[j] = c < E ? dy[(size_t)row * E + c] : 0.f;
+            sum += (double)v[j];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sum += shfl_xor_f64(sum, m);
+        const double mu = sum / (double)E;
+        double sq = 0.0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (lane + 64 * j < E) sq += ((double)v[j] - mu) * ((double)v[j] - mu);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sq += shfl_xor_f64(sq, m);
+        const double rstd = 1.0 / sqrt(sq / (double)E + (double)eps);
+        double xh[2], gw[2], s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = lane + 64 * j;
+            xh[j] = c < E ? ((double)v[j] - mu) * rstd : 0.0;
+            gw[j] = c < E ? (double)g[j] * (double)w[c] : 0.0;
+            s1 += gw[j], s2 += gw[j] * xh[j];
+            aw[j] += (float)((double)g[j] * xh[j]);
+            ab[j] += g[j];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s1 += shfl_xor_f64(s1, m), s2 += shfl_xor_f64(s2, m);
+        s1 /= (double)E, s2 /= (double)E;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = lane + 64 * j;
+            if (c < E) du[(size_t)row * E + c] = (float)(rstd * (gw[j] - s1 - xh[j] * s2));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) red[wv][0][lane + 64 * j] = aw[j], red[wv][1][lane + 64 * j] = ab[j];
+    __syncthreads();
+    for (int f = threadIdx.x; f < 2 * E; f += 256) {
+        const int which = f / E, c = f % E;
+        slab[((size_t)blockIdx.x * 2 + which) * E + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
+// x.mean(dim=1) backward: dx[b][n][c] = dy[b][c] / N
+__global__ void __launch_bounds__(256) mean_points_bwd_kernel(const float *__restrict__ dy, int N, int E, size_t total,
+                                                              float *__restrict__ dx) {
+    const float inv = 1.f / (float)N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t bn = i / E;
+        dx[i] = dy[(bn / N) * E + (i - bn * E)] * inv;
+    }
+}
+
 }  // namespace pnpp
 
 using namespace pnpp;
@@ -212,5 +466,77 @@ extern "C" int pnpp_mean_points(const float *x, int B, int N, int E, float *y, v
     ProfScope ps(as_stream(stream), "mean_points_kernel B=%d N=%d E=%d", B, N, E);
     hipLaunchKernelGGL(mean_points_kernel, dim3(B), dim3(256), 0, as_stream(stream), x, N, E, y);
     PNPP_CHECK_LAUNCH("mean_points");
+    return PNPP_OK;
+}
+
+extern "C" size_t pnpp_linear_smallk_bwd_scratch_bytes(int M, int N) { return (size_t)cdiv(M, 256) * N * 16 * sizeof(float); }
+
+extern "C" int pnpp_linear_smallk_bwd(const float *x, const float *dy, int M, int K, int N, float *dw, float *db, void *scratch,
+                                      void *stream) {
+    PNPP_REQUIRE(x && dy && dw && scratch, PNPP_ERR_ARG, "linear_smallk_bwd: null pointer");
+    PNPP_REQUIRE(M > 0 && N > 0 && K > 0 && K <= SMALLK_MAX, PNPP_ERR_ARG, "linear_smallk_bwd: M=%d N=%d K=%d (K <= %d)", M, N, K,
+                 SMALLK_MAX);
+    hipStream_t st = as_stream(stream);
+    float *slab = static_cast<float *>(scratch);
+    const int nsplit = cdiv(M, 256);
+    {
+        ProfScope ps(st, "linear_smallk_bwd_kernel M=%d N=%d K=%d", M, N, K);
+        hipLaunchKernelGGL(linear_smallk_bwd_kernel, dim3(nsplit), dim3(256), 0, st, x, dy, M, K, N, slab);
+        PNPP_CHECK_LAUNCH("linear_smallk_bwd");
+    }
+    int rc = launch_slab_reduce(slab, nsplit, N, 16, K, -1, dw, K, st);
+    if (rc != PNPP_OK) return rc;
+    if (db) rc = launch_slab_reduce(slab + K, nsplit, N, 16, 1, -1, db, 1, st);
+    return rc;
+}
+
+extern "C" int pnpp_attention_bwd(const float *qkv, const float *out, const float *d_out, const float *lse, int B, int N, int H,
+                                  int head_dim, float *dqkv, float *dsum, void *stream) {
+    PNPP_REQUIRE(qkv && out && d_out && lse && dqkv && dsum, PNPP_ERR_ARG, "attention_bwd: null pointer");
+    PNPP_REQUIRE(B > 0 && N > 0 && H > 0, PNPP_ERR_ARG, "attention_bwd: non-positive size");
+    PNPP_REQUIRE(head_dim == ATT_DH, PNPP_ERR_ARG, "attention_bwd: head dimension %d is not supported (only %d)", head_dim, ATT_DH);
+    PNPP_REQUIRE(N % 128 == 0, PNPP_ERR_ARG, "attention_bwd: N=%d must be a multiple of 128", N);
+    PNPP_REQUIRE(B <= 65535 && H <= 65535, PNPP_ERR_ARG, "attention_bwd: B or H exceeds the grid limit");
+    hipStream_t st = as_stream(stream);
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    {
+        ProfScope ps(st, "attention_bwd_dq_kernel B=%d N=%d H=%d", B, N, H);
+        hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3(N / 128, H, B), dim3(256), 0, st, qkv, out, d_out, lse, N, H, scale, dqkv,
+                           dsum);
+        PNPP_CHECK_LAUNCH("attention_bwd_dq");
+    }
+    {
+        ProfScope ps(st, "attention_bwd_dkv_kernel B=%d N=%d H=%d", B, N, H);
+        hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3(N / 128, H, B), dim3(256), 0, st, qkv, d_out, lse, dsum, N, H, scale, dqkv);
+        PNPP_CHECK_LAUNCH("attention_bwd_dkv");
+    }
+    return PNPP_OK;
+}
+
+extern "C" size_t pnpp_add_layernorm_bwd_scratch_bytes(int M, int E) { return (size_t)cdiv(M, 64) * 2 * E * sizeof(float); }
+
+extern "C" int pnpp_add_layernorm_bwd(const float *x, const float *r, const float *w, const float *dy, int M, int E, float eps,
+                                      float *du, float *dwb, void *scratch, void *stream) {
+    PNPP_REQUIRE(x && w && dy && du && dwb && scratch, PNPP_ERR_ARG, "add_layernorm_bwd: null pointer");
+    PNPP_REQUIRE(M > 0 && E > 0 && E <= 128, PNPP_ERR_ARG, "add_layernorm_bwd: M=%d E=%d (E <= 128)", M, E);
+    hipStream_t st = as_stream(stream);
+    float *slab = static_cast<float *>(scratch);
+    const int nsplit = cdiv(M, 64);
+    {
+        ProfScope ps(st, "add_layernorm_bwd_kernel M=%d E=%d", M, E);
+        hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(nsplit), dim3(256), 0, st, x, r, w, dy, M, E, eps, du, slab);
+        PNPP_CHECK_LAUNCH("add_layernorm_bwd");
+    }
+    return launch_slab_reduce(slab, nsplit, 2, E, E, -1, dwb, E, st);  // dwb (2,E): row 0 = d weight, row 1 = d bias
+}
+
+extern "C" int pnpp_mean_points_bwd(const float *dy, int B, int N, int E, float *dx, void *stream) {
+    PNPP_REQUIRE(dy && dx, PNPP_ERR_ARG, "mean_points_bwd: null pointer");
+    PNPP_REQUIRE(B > 0 && N > 0 && E > 0, PNPP_ERR_ARG, "mean_points_bwd: non-positive size");
+    const size_t total = (size_t)B * N * E;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    ProfScope ps(as_stream(stream), "mean_points_bwd_kernel B=%d N=%d E=%d", B, N, E);
+    hipLaunchKernelGGL(mean_points_bwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), dy, N, E, total, dx);
+    PNPP_CHECK_LAUNCH("mean_points_bwd");
     return PNPP_OK;
 }

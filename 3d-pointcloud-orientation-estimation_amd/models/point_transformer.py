@@ -4,8 +4,9 @@ The parameter containers are the reference's own modules in the same constructio
 nn.TransformerEncoderLayer cloned by nn.TransformerEncoder, nn.Linear), so state_dict keys, shapes and the seeded
 default initialisation are identical; forward() runs on the HIP kernels (pnpp_hip/transformer.py).
 
-Status: the forward pass is built (eval-mode parity with the reference); the backward pass and
-the train-mode dropouts of nn.TransformerEncoderLayer are not, so train-mode calls raise instead of falling back.
+Status: forward and backward are built (parity with the reference in eval mode and in train mode
+with the dropout probabilities at 0); nn.TransformerEncoderLayer's train-mode dropouts with p > 0 (the constructor's
+default 0.1) are not, and such calls raise instead of falling back to PyTorch.
 """
 import torch
 import torch.nn as nn
@@ -23,7 +24,12 @@ class PointTransformer(nn.Module):
     def forward(self, x: torch.Tensor):
         """x (B,N,3) -> (B,3)."""
         from pnpp_hip import transformer as T
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("PointTransformer on the HIP path: only the forward pass is built so far "
-                                      "(call .eval() / torch.no_grad()); there is no PyTorch fallback")
         return T.point_transformer_forward(self, x)
+
+    def set_dropout(self, p: float) -> "PointTransformer":
+        """Sets the four dropout probabilities of every encoder layer (the reference's constructor leaves them at
+        nn.TransformerEncoderLayer's default 0.1)."""
+        for layer in self.transformer.layers:
+            layer.dropout.p = layer.dropout1.p = layer.dropout2.p = float(p)
+            layer.self_attn.dropout = float(p)
+        return self

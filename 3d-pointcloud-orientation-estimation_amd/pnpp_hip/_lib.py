@@ -97,6 +97,12 @@ SIGNATURES = {
     "pnpp_attention_fwd": (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _fp]),
     "pnpp_add_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp, _fp]),
     "pnpp_mean_points": (_i, [_fp, _i, _i, _i, _fp, _fp]),
+    "pnpp_linear_smallk_bwd_scratch_bytes": (_sz, [_i, _i]),
+    "pnpp_linear_smallk_bwd": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp]),
+    "pnpp_attention_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp]),
+    "pnpp_add_layernorm_bwd_scratch_bytes": (_sz, [_i, _i]),
+    "pnpp_add_layernorm_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp, _fp, _fp, _fp]),
+    "pnpp_mean_points_bwd": (_i, [_fp, _i, _i, _i, _fp, _fp]),
     "pnpp_adam_step": (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _f, _f, _f, _f, _fp]),
     "pnpp_sumsq": (_i, [_fp, _sz, _fp, _fp, _sz, _fp]),
 }

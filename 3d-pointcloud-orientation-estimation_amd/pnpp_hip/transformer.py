@@ -1,83 +1,150 @@
 """Host side of the point-transformer configuration: models/point_transformer.py:15-20 on the
-HIP kernels.  Forward only (see models/point_transformer.py for the status): the dense projections go through the
-same pnpp_fc_forward path as the heads of the other models, attention / residual LayerNorm / pooling have their own
-kernels (csrc/transformer_kernels.hip).  Everything runs under torch.no_grad(); no PyTorch operator computes anything.
+HIP kernels, forward and backward.  The dense projections go through the same pnpp_fc_forward / pnpp_fc_backward path
+as the heads of the other models; attention, residual LayerNorm, pooling and the input projection have their own
+kernels (csrc/transformer_kernels.hip) wrapped in torch.autograd.Functions here.  No PyTorch operator computes anything.
+
+Dropout: nn.TransformerEncoderLayer's four dropouts (attention weights, after out_proj, after the ReLU, after linear2)
+are identities in eval mode and for p = 0; train mode with p > 0 is not built yet and raises.
 """
 from __future__ import annotations
-
-import ctypes as C  # noqa: F401
 
 import torch
 
 from . import _lib as L
 from . import ops
-from .ops import _f32, _stream
+from .ops import _f32, _scratch, _stream
 
 
-def linear_smallk(x2d: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
-    x2d = _f32(x2d, "x")
-    w, b = _f32(lin.weight, "weight"), (_f32(lin.bias, "bias") if lin.bias is not None else None)
-    M, K = x2d.shape
-    N = w.shape[0]
-    y = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
-    L.check(L.lib().pnpp_linear_smallk(x2d.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), M, K, N, y.data_ptr(),
-                                       _stream()))
-    return y
+class _LinearSmallK(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2d, w, b):
+        x2d, w = _f32(x2d, "x"), _f32(w, "weight")
+        b = _f32(b, "bias") if b is not None else None
+        M, K = x2d.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+        L.check(L.lib().pnpp_linear_smallk(x2d.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), M, K, N,
+                                           y.data_ptr(), _stream()))
+        ctx.save_for_backward(x2d)
+        ctx.dims, ctx.has_bias = (M, K, N), b is not None
+        ctx.sinks = (getattr(w, "_pnpp_grad_sink", None), getattr(b, "_pnpp_grad_sink", None) if b is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2d,) = ctx.saved_tensors
+        M, K, N = ctx.dims
+        dy = _f32(dy, "dy")
+        lib = L.lib()
+        sw, sb = ctx.sinks
+        dw = sw if sw is not None else torch.empty(N, K, device=dy.device, dtype=torch.float32)
+        db = (sb if sb is not None else torch.empty(N, device=dy.device, dtype=torch.float32)) if ctx.has_bias else None
+        scratch = _scratch(lib.pnpp_linear_smallk_bwd_scratch_bytes(M, N), dy.device)
+        L.check(lib.pnpp_linear_smallk_bwd(x2d.data_ptr(), dy.data_ptr(), M, K, N, dw.data_ptr(),
+                                           None if db is None else db.data_ptr(), scratch.data_ptr(), _stream()))
+        return None, (None if sw is not None else dw), (None if (sb is not None or db is None) else db)
+
+
+def linear_smallk(x2d: torch.Tensor, lin) -> torch.Tensor:
+    """nn.Linear with at most 8 inputs (input_proj): y = x W^T + b.  The input is data: it gets no gradient."""
+    return _LinearSmallK.apply(x2d, lin.weight, lin.bias)
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, num_heads):
+        qkv = _f32(qkv, "qkv")
+        B, N, E3 = qkv.shape
+        if E3 % (3 * num_heads) != 0:
+            raise ValueError(f"attention: last dimension {E3} is not 3 * heads * head_dim")
+        E = E3 // 3
+        out = torch.empty(B, N, E, device=qkv.device, dtype=torch.float32)
+        lse = torch.empty(B, num_heads, N, device=qkv.device, dtype=torch.float32)
+        L.check(L.lib().pnpp_attention_fwd(qkv.data_ptr(), B, N, num_heads, E // num_heads, out.data_ptr(), lse.data_ptr(),
+                                           _stream()))
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.heads = num_heads
+        ctx.mark_non_differentiable(lse)
+        return out, lse
+
+    @staticmethod
+    def backward(ctx, d_out, _d_lse):
+        qkv, out, lse = ctx.saved_tensors
+        B, N, E3 = qkv.shape
+        d_out = _f32(d_out, "d_out")
+        dqkv = torch.empty_like(qkv)
+        dsum = torch.empty_like(lse)
+        L.check(L.lib().pnpp_attention_bwd(qkv.data_ptr(), out.data_ptr(), d_out.data_ptr(), lse.data_ptr(), B, N, ctx.heads,
+                                           E3 // 3 // ctx.heads, dqkv.data_ptr(), dsum.data_ptr(), _stream()))
+        return dqkv, None
 
 
 def attention(qkv: torch.Tensor, num_heads: int, want_lse: bool = False):
-    """qkv (B,N,3E) -> (B,N,E) [, lse (B,H,N)]."""
-    qkv = _f32(qkv, "qkv")
-    B, N, E3 = qkv.shape
-    if E3 % (3 * num_heads) != 0:
-        raise ValueError(f"attention: last dimension {E3} is not 3 * heads * head_dim")
-    E = E3 // 3
-    out = torch.empty(B, N, E, device=qkv.device, dtype=torch.float32)
-    lse = torch.empty(B, num_heads, N, device=qkv.device, dtype=torch.float32) if want_lse else None
-    L.check(L.lib().pnpp_attention_fwd(qkv.data_ptr(), B, N, num_heads, E // num_heads, out.data_ptr(),
-                                       None if lse is None else lse.data_ptr(), _stream()))
+    """qkv (B,N,3E), in_proj bias included -> (B,N,E) [, log-sum-exp of the scaled scores (B,H,N)]."""
+    out, lse = _Attention.apply(qkv, num_heads)
     return (out, lse) if want_lse else out
 
 
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2d, r2d, w, b, eps):
+        x2d, w, b = _f32(x2d, "x"), _f32(w, "weight"), _f32(b, "bias")
+        r2d = _f32(r2d, "r") if r2d is not None else None
+        M, E = x2d.shape
+        y = torch.empty_like(x2d)
+        L.check(L.lib().pnpp_add_layernorm(x2d.data_ptr(), None if r2d is None else r2d.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                           M, E, float(eps), y.data_ptr(), _stream()))
+        ctx.save_for_backward(x2d, r2d if r2d is not None else x2d.new_empty(0), w)
+        ctx.has_r, ctx.eps = r2d is not None, float(eps)
+        ctx.sinks = (getattr(w, "_pnpp_grad_sink", None), getattr(b, "_pnpp_grad_sink", None))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, r2d, w = ctx.saved_tensors
+        r2d = r2d if ctx.has_r else None
+        M, E = x2d.shape
+        dy = _f32(dy, "dy")
+        lib = L.lib()
+        du = torch.empty_like(x2d)
+        dwb = torch.empty(2, E, device=dy.device, dtype=torch.float32)
+        scratch = _scratch(lib.pnpp_add_layernorm_bwd_scratch_bytes(M, E), dy.device)
+        L.check(lib.pnpp_add_layernorm_bwd(x2d.data_ptr(), None if r2d is None else r2d.data_ptr(), w.data_ptr(), dy.data_ptr(),
+                                           M, E, ctx.eps, du.data_ptr(), dwb.data_ptr(), scratch.data_ptr(), _stream()))
+        sw, sb = ctx.sinks
+        if sw is not None:
+            sw.copy_(dwb[0])
+        if sb is not None:
+            sb.copy_(dwb[1])
+        return du, (du if ctx.has_r else None), (None if sw is not None else dwb[0]), (None if sb is not None else dwb[1]), None
+
+
 def add_layernorm(x2d: torch.Tensor, r2d, norm: torch.nn.LayerNorm) -> torch.Tensor:
-    x2d = _f32(x2d, "x")
-    r2d = _f32(r2d, "r") if r2d is not None else None
-    M, E = x2d.shape
-    y = torch.empty_like(x2d)
-    L.check(L.lib().pnpp_add_layernorm(x2d.data_ptr(), None if r2d is None else r2d.data_ptr(), _f32(norm.weight, "w").data_ptr(),
-                                       _f32(norm.bias, "b").data_ptr(), M, E, float(norm.eps), y.data_ptr(), _stream()))
-    return y
+    """LayerNorm(x + r) over the last dimension (the post-norm residual blocks of nn.TransformerEncoderLayer)."""
+    return _AddLayerNorm.apply(x2d, r2d, norm.weight, norm.bias, norm.eps)
+
+
+class _MeanPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x, "x")
+        B, N, E = x.shape
+        y = torch.empty(B, E, device=x.device, dtype=torch.float32)
+        L.check(L.lib().pnpp_mean_points(x.data_ptr(), B, N, E, y.data_ptr(), _stream()))
+        ctx.dims = (B, N, E)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, E = ctx.dims
+        dy = _f32(dy, "dy")
+        dx = torch.empty(B, N, E, device=dy.device, dtype=torch.float32)
+        L.check(L.lib().pnpp_mean_points_bwd(dy.data_ptr(), B, N, E, dx.data_ptr(), _stream()))
+        return dx
 
 
 def mean_points(x: torch.Tensor) -> torch.Tensor:
-    x = _f32(x, "x")
-    B, N, E = x.shape
-    y = torch.empty(B, E, device=x.device, dtype=torch.float32)
-    L.check(L.lib().pnpp_mean_points(x.data_ptr(), B, N, E, y.data_ptr(), _stream()))
-    return y
-
-
-@torch.no_grad()
-def point_transformer_forward(model, xyz: torch.Tensor) -> torch.Tensor:
-    """models/point_transformer.py:15-20 with the dropouts inactive (eval)."""
-    xyz = _f32(xyz, "xyz")
-    B, N, K = xyz.shape
-    x = linear_smallk(xyz.reshape(B * N, K), model.input_proj)                        # (B*N, E)
-    E = x.shape[1]
-    for layer in model.transformer.layers:
-        att = layer.self_attn
-        if layer.norm_first or att.in_proj_weight is None or not att.batch_first:
-            raise NotImplementedError("only the post-norm, packed in_proj, batch_first encoder layer of the reference")
-        in_proj = _Affine(att.in_proj_weight, att.in_proj_bias)
-        qkv = ops.fc_block(x, in_proj, training=False)                                  # (B*N, 3E), bias added
-        o = attention(qkv.view(B, N, 3 * E), att.num_heads).view(B * N, E)
-        o = ops.fc_block(o, att.out_proj, training=False)
-        x = add_layernorm(x, o, layer.norm1)
-        hid = ops.fc_block(x, layer.linear1, relu=True, training=False)                 # relu(W1 x + b1)
-        f = ops.fc_block(hid, layer.linear2, training=False)
-        x = add_layernorm(x, f, layer.norm2)
-    pooled = mean_points(x.view(B, N, E))
-    return ops.fc_block(pooled, model.fc_out, training=False)
+    return _MeanPoints.apply(x)
 
 
 class _Affine:
@@ -85,3 +152,37 @@ class _Affine:
 
     def __init__(self, weight, bias):
         self.weight, self.bias = weight, bias
+
+
+def _check_dropouts(model) -> None:
+    if not model.training:
+        return
+    for layer in model.transformer.layers:
+        ps = (layer.dropout.p, layer.dropout1.p, layer.dropout2.p, layer.self_attn.dropout)
+        if any(p > 0 for p in ps):
+            raise NotImplementedError(
+                "PointTransformer on the HIP path: train-mode dropout (p > 0) is not built; set the four dropout "
+                "probabilities of every encoder layer to 0 or call .eval() -- there is no PyTorch fallback")
+
+
+def point_transformer_forward(model, xyz: torch.Tensor) -> torch.Tensor:
+    """models/point_transformer.py:15-20 (dropouts inactive: eval mode or p = 0), differentiable."""
+    _check_dropouts(model)
+    xyz = _f32(xyz, "xyz")
+    B, N, K = xyz.shape
+    x = linear_smallk(xyz.reshape(B * N, K), model.input_proj)                        # (B*N, E)
+    E = x.shape[1]
+    tr = model.training
+    for layer in model.transformer.layers:
+        att = layer.self_attn
+        if layer.norm_first or att.in_proj_weight is None or not att.batch_first:
+            raise NotImplementedError("only the post-norm, packed in_proj, batch_first encoder layer of the reference")
+        qkv = ops.fc_block(x, _Affine(att.in_proj_weight, att.in_proj_bias), training=tr)   # (B*N, 3E), bias added
+        o = attention(qkv.view(B, N, 3 * E), att.num_heads).view(B * N, E)
+        o = ops.fc_block(o, att.out_proj, training=tr)
+        x = add_layernorm(x, o, layer.norm1)
+        hid = ops.fc_block(x, layer.linear1, relu=True, training=tr)                    # relu(W1 x + b1)
+        f = ops.fc_block(hid, layer.linear2, training=tr)
+        x = add_layernorm(x, f, layer.norm2)
+    pooled = mean_points(x.view(B, N, E))
+    return ops.fc_block(pooled, model.fc_out, training=tr)

@@ -272,6 +272,20 @@ int pnpp_add_layernorm(const float *x, const float *r, const float *w, const flo
                        void *stream);
 /* x.mean(dim=1): y (B,E) = mean over the N points of x (B,N,E). */
 int pnpp_mean_points(const float *x, int B, int N, int E, float *y, void *stream);
+/* Backward passes of the four entries above (what torch.autograd derives for the reference model).
+ * linear_smallk: dw (N,K) = dy^T x, db (N) = column sums of dy (db may be NULL); x is data, no dx. */
+size_t pnpp_linear_smallk_bwd_scratch_bytes(int M, int N);
+int pnpp_linear_smallk_bwd(const float *x, const float *dy, int M, int K, int N, float *dw, float *db, void *scratch,
+                           void *stream);
+/* attention: dqkv (B,N,3E) from qkv, the forward's out and lse, and d_out (B,N,E); dsum (B,H,N) is scratch
+ * (rowsum(d_out * out) per head).  Scores are recomputed, never stored. */
+int pnpp_attention_bwd(const float *qkv, const float *out, const float *d_out, const float *lse, int B, int N, int H,
+                       int head_dim, float *dqkv, float *dsum, void *stream);
+/* add_layernorm: du (M,E) = gradient w.r.t. both x and r; dwb (2,E) = (d weight, d bias). */
+size_t pnpp_add_layernorm_bwd_scratch_bytes(int M, int E);
+int pnpp_add_layernorm_bwd(const float *x, const float *r, const float *w, const float *dy, int M, int E, float eps,
+                           float *du, float *dwb, void *scratch, void *stream);
+int pnpp_mean_points_bwd(const float *dy, int B, int N, int E, float *dx, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Step glue on one flat parameter / gradient buffer

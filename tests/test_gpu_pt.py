@@ -37,6 +37,15 @@ def test_attention_forward_vs_float64():
         ref = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, N, E)
         assert float((out.cpu().double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (B, N, H)
         assert float((lse.cpu().double() - torch.logsumexp(s, dim=-1)).abs().max()) <= 2e-5
+        # backward (scores recomputed in two kernels: dQ, then dK / dV) vs float64 autograd
+        up = torch.randn(B, N, E, generator=g)
+        qd = qkv.double().requires_grad_(True)
+        q2, k2, v2 = (t.reshape(B, N, H, 16).transpose(1, 2) for t in qd.split(E, dim=-1))
+        ((torch.softmax((q2 * 0.25) @ k2.transpose(-1, -2), dim=-1) @ v2).transpose(1, 2).reshape(B, N, E) * up.double()).sum().backward()
+        qg = qkv.clone().cuda().requires_grad_(True)
+        (T.attention(qg, H) * up.cuda()).sum().backward()
+        err = float((qg.grad.cpu().double() - qd.grad).abs().max()) / max(1.0, float(qd.grad.abs().max()))
+        assert err <= 2e-5, (B, N, H, err)
     with pytest.raises(ValueError):
         T.attention(torch.zeros(1, 100, 192, device="cuda"), 4)          # N not a multiple of 128
     with pytest.raises(ValueError):
@@ -52,19 +61,39 @@ def test_layernorm_mean_and_small_linear_vs_float64():
         ln.weight.normal_(1.0, 0.2, generator=g), ln.bias.normal_(0.0, 0.2, generator=g)
     ref = torch.nn.functional.layer_norm((x + r).double(), (64,), ln.weight.double(), ln.bias.double(), 1e-5)
     got = T.add_layernorm(x.cuda(), r.cuda(), ln.cuda())
-    assert float((got.cpu().double() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    assert float((got.detach().cpu().double() - ref.detach()).abs().max()) <= 2e-6 * max(1.0, float(ref.detach().abs().max()))
+    # backward: du for both addends, d weight, d bias
+    up = torch.randn(1000, 64, generator=g)
+    xd, rd = x.double().requires_grad_(True), r.double().requires_grad_(True)
+    wd, bd = ln.weight.detach().cpu().double().requires_grad_(True), ln.bias.detach().cpu().double().requires_grad_(True)
+    (torch.nn.functional.layer_norm(xd + rd, (64,), wd, bd, 1e-5) * up.double()).sum().backward()
+    xg, rg = x.clone().cuda().requires_grad_(True), r.clone().cuda().requires_grad_(True)
+    ln.zero_grad()
+    (T.add_layernorm(xg, rg, ln) * up.cuda()).sum().backward()
+    for got_g, ref_g in ((xg.grad, xd.grad), (rg.grad, rd.grad), (ln.weight.grad, wd.grad), (ln.bias.grad, bd.grad)):
+        assert float((got_g.cpu().double() - ref_g).abs().max()) <= 1e-5 * max(1.0, float(ref_g.abs().max()))
     xs = torch.randn(3, 777, 64, generator=g)
     assert float((T.mean_points(xs.cuda()).cpu().double() - xs.double().mean(1)).abs().max()) <= 1e-6
     lin = torch.nn.Linear(3, 64)
     pts = torch.randn(5000, 3, generator=g)
     ref = pts.double() @ lin.weight.double().t() + lin.bias.double()
-    assert float((T.linear_smallk(pts.cuda(), lin.cuda()).cpu().double() - ref).abs().max()) <= 1e-6
+    lin = lin.cuda()
+    y = T.linear_smallk(pts.cuda(), lin)
+    assert float((y.detach().cpu().double() - ref.detach()).abs().max()) <= 1e-6
+    upl = torch.randn(5000, 64, generator=g)
+    (y * upl.cuda()).sum().backward()
+    assert float((lin.weight.grad.cpu().double() - upl.double().t() @ pts.double()).abs().max()) <= 1e-5 * 5000 ** 0.5
+    assert float((lin.bias.grad.cpu().double() - upl.double().sum(0)).abs().max()) <= 1e-5 * 5000 ** 0.5
+    xm = xs.clone().cuda().requires_grad_(True)
+    upm = torch.randn(3, 64, generator=g)
+    (T.mean_points(xm) * upm.cuda()).sum().backward()
+    assert float((xm.grad.cpu().double() - (upm.double() / 777)[:, None, :].expand(3, 777, 64)).abs().max()) <= 1e-9
 
 
 def test_point_transformer_forward_matches_reference_capture(golden):
     g = golden("pt.npz")
     model = _pt_model().cuda().eval()
-    out = model(_t(g["xyz"]).cuda()).cpu().double().numpy()
+    out = model(_t(g["xyz"]).cuda()).detach().cpu().double().numpy()
     ref64, ref32 = g["pt_f64.eval_out"], g["pt_f32.eval_out"]
     d64 = np.abs(out - ref64).max()
     print(f"\nHIP vs reference fp64: {d64:.2e}; reference fp32 vs its own fp64: {np.abs(ref32 - ref64).max():.2e}")
@@ -72,9 +101,30 @@ def test_point_transformer_forward_matches_reference_capture(golden):
     assert np.abs(out - g["pt_f64.train_out"]).max() <= 2e-5 * max(1.0, np.abs(ref64).max())   # train mode, p = 0
     model.train()
     with pytest.raises(NotImplementedError):
-        model(_t(g["xyz"]).cuda())                          # no backward yet, and no silent fallback
-    with torch.no_grad():                                   # no_grad is still the forward path
-        assert np.abs(model(_t(g["xyz"]).cuda()).cpu().double().numpy() - ref64).max() <= 2e-5
+        model(_t(g["xyz"]).cuda())                          # default dropout 0.1 in train mode: not built, no silent fallback
+
+
+def test_point_transformer_training_step_matches_reference_capture(golden):
+    """Train mode with the dropout probabilities at 0 and the MSE harness loss: loss and every parameter gradient against
+    the reference's own float64 autograd run."""
+    from pnpp_hip import ops
+    g = golden("pt.npz")
+    model = _pt_model().cuda().train().set_dropout(0.0)
+    out = model(_t(g["xyz"]).cuda())
+    loss = ops.mse_loss(out, _t(g["target"]).cuda())
+    loss.backward()
+    assert np.abs(out.detach().cpu().double().numpy() - g["pt_f64.train_out"]).max() <= 2e-5
+    assert abs(loss.item() - float(g["pt_f64.loss"])) <= 1e-5 * max(1.0, float(g["pt_f64.loss"]))
+    worst = 0.0
+    for n, p in model.named_parameters():
+        pos, ref, norm = g[f"pt_f64.gp.{n}"], g[f"pt_f64.gs.{n}"], g[f"pt_f64.gn.{n}"][0]
+        got = p.grad.detach().cpu().double().flatten()[pos].numpy()
+        scale = max(norm / math.sqrt(p.numel()), 1e-12)
+        worst = max(worst, float(np.abs(got - ref).max() / scale))
+        gn = float(p.grad.detach().double().norm())
+        assert abs(gn - norm) <= 1e-4 * max(norm, 1e-12), (n, gn, norm)
+    print(f"\nloss {loss.item():.8f} ref {float(g['pt_f64.loss']):.8f}; worst sampled gradient error / rms {worst:.2e}")
+    assert worst <= 1e-3
 
 
 def test_point_transformer_forward_larger_cloud_vs_oracle(oracle):
@@ -82,5 +132,5 @@ def test_point_transformer_forward_larger_cloud_vs_oracle(oracle):
     P64 = {k: v.double() for k, v in model.state_dict().items()}
     xyz, _, _, _ = oracle.synthetic_clouds(2, 1024, seed=3)
     ref = oracle.point_transformer_forward(xyz.double(), P64)
-    out = model.cuda().eval()(xyz.cuda()).cpu().double()
+    out = model.cuda().eval()(xyz.cuda()).detach().cpu().double()
     assert float((out - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
