@@ -65,6 +65,33 @@ __global__ void __launch_bounds__(256) fc_apply_ln_kernel(const float *__restric
 
 // ---- backward, BatchNorm1d / none: block = 32 columns x 8 row lanes --------------------------------
 // g = dy * dropout * relu'; BN: dz = gamma*istd*(g - mean(g) - xhat*mean(g*xhat)); none: dz = g
+// Row-parallel form of the plain (no normalisation) case for many rows (the per-point linear layers of the transformer,
+// M = B * N): dz = dy with the dropout mask and the ReLU gate applied, and one [N] partial of the bias gradient per
+// 256-row chunk (slab_reduce adds them).  grid = (N / 64 column blocks, M / 256 row chunks).
+__global__ void __launch_bounds__(256)
+fc_bwd_rows_kernel(const float *__restrict__ dy, const float *__restrict__ z, const uint8_t *__restrict__ mask, float drop_scale,
+                   int relu, const float *__restrict__ bias, int M, int N, float *__restrict__ dz, float *__restrict__ slab) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + cl, m0 = blockIdx.y * 256;
+    const float sh = n < N ? bias[n] : 0.f;
+    float acc = 0.f;
+    if (n < N)
+        for (int r = rl; r < 256; r += 4) {
+            const int m = m0 + r;
+            if (m >= M) break;
+            const size_t i = (size_t)m * N + n;
+            float g = dy[i];
+            if (mask) g = mask[i] ? g * drop_scale : 0.f;
+            if (relu && !(z[i] + sh > 0.f)) g = 0.f;
+            dz[i] = g;
+            acc += g;
+        }
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && n < N) slab[(size_t)blockIdx.y * N + n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
 __global__ void __launch_bounds__(256)
 fc_bwd_cols_kernel(const float *__restrict__ dy, const float *__restrict__ z, const uint8_t *__restrict__ mask,
                    float drop_scale, int relu, int bn, const float *__restrict__ scale, const float *__restrict__ shift,
@@ -370,6 +397,7 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
             hipLaunchKernelGGL(fc_apply_ln_kernel, dim3(d->M), dim3(256), 0, st, sv.z, a->b, a->nw, a->nb, a->mask, d->drop_scale,
                                d->relu, d->N, d->eps, a->y, sv.mean, sv.istd);
         } else {
+            ProfScope ps(st, "fc_apply_cols_kernel M=%d N=%d", d->M, d->N);
             hipLaunchKernelGGL(fc_apply_cols_kernel, dim3(grid), dim3(256), 0, st, sv.z, (const float *)nullptr, a->b, a->mask,
                                d->drop_scale, d->relu, d->M, d->N, a->y);
         }
@@ -401,6 +429,15 @@ static int fc_backward_impl(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, hi
                            d->drop_scale, d->relu, sv.mean, sv.istd, d->N, sc.dz, sc.gbuf);
         hipLaunchKernelGGL(fc_bwd_ln_cols_kernel, dim3(cdiv(d->N, 32)), dim3(256), 0, st, sc.gbuf, sc.dz, sv.z, a->b, sv.mean,
                            sv.istd, d->M, d->N, a->dnw, a->dnb, a->db);
+    } else if (d->norm == PNPP_NORM_NONE && d->M > 4096) {
+        const int chunks = cdiv(d->M, 256);  // sc.gbuf (M x N floats) holds the [chunks][N] partials
+        {
+            ProfScope ps(st, "fc_bwd_rows_kernel M=%d N=%d", d->M, d->N);
+            hipLaunchKernelGGL(fc_bwd_rows_kernel, dim3(cdiv(d->N, 64), chunks), dim3(256), 0, st, a->dy, sv.z, a->mask,
+                               d->drop_scale, d->relu, a->b, d->M, d->N, sc.dz, sc.gbuf);
+            PNPP_CHECK_LAUNCH("fc_backward(rows)");
+        }
+        PNPP_TRY(launch_slab_reduce(sc.gbuf, chunks, 1, d->N, d->N, -1, a->db, d->N, st));
     } else {
         const int bn = d->norm == PNPP_NORM_BATCH;
         hipLaunchKernelGGL(fc_bwd_cols_kernel, dim3(cdiv(d->N, 32)), dim3(256), 0, st, a->dy, sv.z, a->mask, d->drop_scale,

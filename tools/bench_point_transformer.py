@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Timing of one training step of BASELINE config 5 (models/point_transformer.py, N=4096, 8 clouds per GPU = batch 64
+over 8 GPUs) on one MI355X: forward + MSE harness loss + backward + fused Adam, dropout probabilities at 0 (the only
+train-mode form the HIP path has).  Not the driver's bench line (that is bench.py / configs[1]); prints one JSON line
+with clouds/s, the per-kernel time table from the library's HIP-event profiler and the attention kernels' TFLOP/s."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "3d-pointcloud-orientation-estimation_amd"))
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--points", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    a = ap.parse_args()
+    from models.point_transformer import PointTransformer
+    from pnpp_hip import _lib, ops, optim
+    import synthetic
+    torch.manual_seed(42)
+    model = PointTransformer().cuda().train().set_dropout(0.0)
+    opt = optim.FlatAdam(model.parameters(), lr=1e-3)
+    xyz, _, _, fwd = synthetic.rotated_clouds(a.batch, a.points, seed=1234)
+    xyz, tgt = xyz.cuda(), fwd.cuda()
+
+    def step():
+        opt.zero_grad()
+        loss = ops.mse_loss(model(xyz), tgt)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    lib = _lib.lib()
+    lib.pnpp_profile_enable(1)
+    step()
+    torch.cuda.synchronize()
+    buf = ctypes.create_string_buffer(1 << 16)
+    rc = lib.pnpp_profile_report(buf, len(buf))
+    if rc < 0:
+        print("profile_report failed:", _lib.last_error(), file=sys.stderr)
+    lib.pnpp_profile_enable(0)
+    rows = []
+    for line in buf.value.decode().splitlines():
+        tag, cnt, ms = line.split("\t")
+        rows.append((tag, int(cnt), float(ms)))
+    rows.sort(key=lambda r: -r[2])
+    H, dh, L = 4, 16, len(model.transformer.layers)
+    att_flops_fwd = 4.0 * a.batch * H * a.points * a.points * dh          # QK^T and PV, 2 flops per MAC
+    table = []
+    for tag, cnt, ms in rows[:12]:
+        e = {"kernel": tag, "launches": cnt, "ms": round(ms, 3)}
+        if tag.startswith("attention_fwd"):
+            e["tflops"] = round(att_flops_fwd * cnt / (ms * 1e-3) / 1e12, 1)
+        if tag.startswith("attention_bwd_dq"):
+            e["tflops"] = round(1.5 * att_flops_fwd * cnt / (ms * 1e-3) / 1e12, 1)   # S, dP, dQ
+        if tag.startswith("attention_bwd_dkv"):
+            e["tflops"] = round(2.0 * att_flops_fwd * cnt / (ms * 1e-3) / 1e12, 1)   # S, dP, dV, dK
+        table.append(e)
+    print(json.dumps({"workload": f"configs[4]: point_transformer N={a.points} batch={a.batch}/GPU, fwd+MSE+bwd+Adam, dropout p=0, f32",
+                      "clouds_per_s": a.batch / dt, "ms_per_step": 1e3 * dt, "layers": L, "final_loss": float(loss.detach()),
+                      "kernel_ms_total": round(sum(r[2] for r in rows), 3), "top_kernels": table}))
+
+
+if __name__ == "__main__":
+    main()
