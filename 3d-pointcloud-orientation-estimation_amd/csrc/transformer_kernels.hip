@@ -50,12 +50,62 @@ __global__ void __launch_bounds__(256) linear_smallk_kernel(const float *__restr
 //                 any key as long as A and B agree, and step s with k = lh naming key kappa(s, lh) makes the B operand
 //                 exactly score register s -- the probabilities never move between lanes.
 // ---------------------------------------------------------------------------------------------
+// Dropout on the attention weights (nn.MultiheadAttention(dropout=p) in train mode): one keep bit per (cloud, head, query,
+// key), Bernoulli(1 - p), generated ONCE per layer call by a counter-based generator (Philox4x32-10, a pure function of
+// seed, stream id and the element index -- the backward pass regenerates the identical bits) and stored bit-packed in
+// both orientations: mask[bh][query][key / 32] (bit = key % 32) for the kernels whose lane is a query, and
+// maskT[bh][key][query / 32] (bit = query % 32) for the dK / dV kernel whose lane is a key.  1/8 byte per score in each
+// orientation; the float scores themselves are still never stored.
+__device__ __forceinline__ void philox4(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                        unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
+// one wave per pair of 32 x 32 tiles: lane = (tile half, row); 8 Philox calls give the row's 32 uniform words
+__global__ void __launch_bounds__(256)
+attention_dropout_mask_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_lo, unsigned str_hi, int N, unsigned thresh,
+                              unsigned *__restrict__ mask, unsigned *__restrict__ maskT) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+    const int nw = N / 32;                                  // words per row
+    const size_t wave_id = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t tile = wave_id * 2 + lh;                   // (bh, query block, key block) flattened
+    const size_t tiles_per_bh = (size_t)nw * nw;
+    const size_t bh = tile / tiles_per_bh;
+    const int qb = (int)((tile % tiles_per_bh) / nw), kb = (int)(tile % nw);
+    const int q = qb * 32 + l31;
+    unsigned w = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        unsigned r[4];
+        philox4((unsigned)(q * nw + kb), (unsigned)bh, str_lo + (unsigned)c, str_hi, seed_lo, seed_hi, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w |= (r[e] >= thresh ? 1u : 0u) << (4 * c + e);   // keep with probability 1 - p
+    }
+    mask[(bh * N + q) * nw + kb] = w;
+    // transpose the 32 x 32 bit tile of this half-wave: word j of the transposed tile = bit j of every row
+    unsigned wt = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const unsigned long long bal = __ballot((w >> j) & 1u);
+        const unsigned half = lh ? (unsigned)(bal >> 32) : (unsigned)bal;
+        if (l31 == j) wt = half;
+    }
+    maskT[(bh * N + kb * 32 + l31) * nw + qb] = wt;
+}
+
 constexpr int ATT_DH = 16;
 constexpr int ATT_KP = 17;  // LDS pitch of the key / value tiles
 
 __global__ void __launch_bounds__(256)
-attention_fwd_kernel(const float *__restrict__ qkv, int N, int H, float scale, float *__restrict__ out,
-                     float *__restrict__ lse) {
+attention_fwd_kernel(const float *__restrict__ qkv, int N, int H, float scale, const unsigned *__restrict__ mask,
+                     float keep_scale, float *__restrict__ out, float *__restrict__ lse) {
     __shared__ float Ks[2][32][ATT_KP], Vs[2][32][ATT_KP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z, E = H * ATT_DH, ld = 3 * E;
@@ -104,8 +154,13 @@ attention_fwd_kernel(const float *__restrict__ qkv, int N, int H, float scale, f
             rs += s[r];
         }
         rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
+        l_run = l_run * alpha + rs;   // the softmax normalisation is over the undropped weights
         m_run = m_new;
+        if (mask) {                   // dropout on the weights: keep bit of (query, key kappa(r, lh)), scaled by 1 / (1 - p)
+            const unsigned mw = mask[(((size_t)b * H + h) * N + q) * nkb + kb];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = ((mw >> ((r & 3) + 8 * (r >> 2) + 4 * lh)) & 1u) ? s[r] * keep_scale : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) o[r] *= alpha;
 #pragma unroll
@@ -213,8 +268,8 @@ __global__ void __launch_bounds__(256) linear_smallk_bwd_kernel(const float *__r
 // Also writes D (B,H,N) for the dK/dV kernel.
 __global__ void __launch_bounds__(256)
 attention_bwd_dq_kernel(const float *__restrict__ qkv, const float *__restrict__ o, const float *__restrict__ d_o,
-                        const float *__restrict__ lse, int N, int H, float scale, float *__restrict__ dqkv,
-                        float *__restrict__ dsum) {
+                        const float *__restrict__ lse, int N, int H, float scale, const unsigned *__restrict__ mask,
+                        float keep_scale, float *__restrict__ dqkv, float *__restrict__ dsum) {
     __shared__ float Ks[2][32][ATT_KP], Vs[2][32][ATT_KP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z, E = H * ATT_DH, ld = 3 * E;
@@ -257,6 +312,11 @@ attention_bwd_dq_kernel(const float *__restrict__ qkv, const float *__restrict__
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[buf][l31][2 * t + lh], qreg[t], s, 0, 0, 0);     // S^T  = K Q^T
             dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[buf][l31][2 * t + lh], doreg[t], dp, 0, 0, 0);  // dP^T = V dO^T
         }
+        if (mask) {  // d(dropped weights) -> d(weights): the same keep bits and scale as the forward
+            const unsigned mw = mask[(((size_t)b * H + h) * N + q) * nkb + kb];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] = ((mw >> ((r & 3) + 8 * (r >> 2) + 4 * lh)) & 1u) ? dp[r] * keep_scale : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = __expf(s[r] - L) * (dp[r] - D);  // dS^T = P^T * (dP^T - D)
 #pragma unroll
@@ -276,7 +336,8 @@ attention_bwd_dq_kernel(const float *__restrict__ qkv, const float *__restrict__
 // directly the B operands of dV^T = dO^T P and dK^T = (scale Q)^T dS.  Per-query L and D come from LDS (one per register).
 __global__ void __launch_bounds__(256)
 attention_bwd_dkv_kernel(const float *__restrict__ qkv, const float *__restrict__ d_o, const float *__restrict__ lse,
-                         const float *__restrict__ dsum, int N, int H, float scale, float *__restrict__ dqkv) {
+                         const float *__restrict__ dsum, int N, int H, float scale, const unsigned *__restrict__ maskT,
+                         float keep_scale, float *__restrict__ dqkv) {
     __shared__ float Qs[2][32][ATT_KP], Gs[2][32][ATT_KP], Ls[2][32], Ds[2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z, E = H * ATT_DH, ld = 3 * E;
@@ -328,11 +389,14 @@ attention_bwd_dkv_kernel(const float *__restrict__ qkv, const float *__restrict_
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[buf][l31][2 * t + lh], kreg[t], s, 0, 0, 0);   // S  = (scale Q) K^T
             dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[buf][l31][2 * t + lh], vreg[t], dp, 0, 0, 0);  // dP = dO V^T
         }
+        const unsigned mw = maskT ? maskT[(((size_t)b * H + h) * N + key) * nqb + qb] : 0xffffffffu;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qi = (r & 3) + 8 * (r >> 2) + 4 * lh;       // the query this register belongs to
-            s[r] = __expf(s[r] - Ls[buf][qi]);                    // P
-            dp[r] = s[r] * (dp[r] - Ds[buf][qi]);                 // dS
+            const float keep = ((mw >> qi) & 1u) ? keep_scale : 0.f;
+            const float pr = __expf(s[r] - Ls[buf][qi]);          // P
+            dp[r] = pr * (dp[r] * keep - Ds[buf][qi]);            // dS = P * (d(dropped P) * keep / (1 - p) - D)
+            s[r] = pr * keep;                                     // dropped P, the operand of dV
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -437,15 +501,34 @@ extern "C" int pnpp_linear_smallk(const float *x, const float *w, const float *b
     return PNPP_OK;
 }
 
-extern "C" int pnpp_attention_fwd(const float *qkv, int B, int N, int H, int head_dim, float *out, float *lse, void *stream) {
+extern "C" int pnpp_attention_dropout_mask(uint64_t seed, uint64_t stream_id, int B, int N, int H, float p, uint32_t *mask,
+                                           uint32_t *maskT, void *stream) {
+    PNPP_REQUIRE(mask && maskT, PNPP_ERR_ARG, "attention_dropout_mask: null pointer");
+    PNPP_REQUIRE(B > 0 && N > 0 && H > 0 && N % 128 == 0, PNPP_ERR_ARG, "attention_dropout_mask: bad size (N %% 128 == 0)");
+    PNPP_REQUIRE(p >= 0.f && p < 1.f, PNPP_ERR_ARG, "attention_dropout_mask: p=%g outside [0, 1)", (double)p);
+    const double t = (double)p * 4294967296.0;
+    const unsigned thresh = t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;   // keep iff word >= thresh
+    const size_t tiles = (size_t)B * H * (N / 32) * (N / 32);               // even: N / 32 is a multiple of 4
+    const size_t blocks = tiles / 8;
+    PNPP_REQUIRE(blocks <= 0x7fffffff, PNPP_ERR_ARG, "attention_dropout_mask: too many tiles");
+    ProfScope ps(as_stream(stream), "attention_dropout_mask_kernel B=%d N=%d H=%d", B, N, H);
+    hipLaunchKernelGGL(attention_dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (unsigned)seed,
+                       (unsigned)(seed >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32), N, thresh, mask, maskT);
+    PNPP_CHECK_LAUNCH("attention_dropout_mask");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_attention_fwd(const float *qkv, int B, int N, int H, int head_dim, const uint32_t *mask, float p, float *out,
+                                  float *lse, void *stream) {
     PNPP_REQUIRE(qkv && out, PNPP_ERR_ARG, "attention_fwd: null pointer");
     PNPP_REQUIRE(B > 0 && N > 0 && H > 0, PNPP_ERR_ARG, "attention_fwd: non-positive size");
     PNPP_REQUIRE(head_dim == ATT_DH, PNPP_ERR_ARG, "attention_fwd: head dimension %d is not supported (only %d)", head_dim, ATT_DH);
     PNPP_REQUIRE(N % 128 == 0, PNPP_ERR_ARG, "attention_fwd: N=%d must be a multiple of 128", N);
     PNPP_REQUIRE(B <= 65535 && H <= 65535, PNPP_ERR_ARG, "attention_fwd: B or H exceeds the grid limit");
     ProfScope ps(as_stream(stream), "attention_fwd_kernel B=%d N=%d H=%d", B, N, H);
+    PNPP_REQUIRE(p >= 0.f && p < 1.f, PNPP_ERR_ARG, "attention_fwd: dropout p=%g outside [0, 1)", (double)p);
     hipLaunchKernelGGL(attention_fwd_kernel, dim3(N / 128, H, B), dim3(256), 0, as_stream(stream), qkv, N, H,
-                       1.0f / sqrtf((float)head_dim), out, lse);
+                       1.0f / sqrtf((float)head_dim), mask, 1.0f / (1.0f - p), out, lse);
     PNPP_CHECK_LAUNCH("attention_fwd");
     return PNPP_OK;
 }
@@ -491,7 +574,11 @@ extern "C" int pnpp_linear_smallk_bwd(const float *x, const float *dy, int M, in
 }
 
 extern "C" int pnpp_attention_bwd(const float *qkv, const float *out, const float *d_out, const float *lse, int B, int N, int H,
-                                  int head_dim, float *dqkv, float *dsum, void *stream) {
+                                  int head_dim, const uint32_t *mask, const uint32_t *maskT, float p, float *dqkv, float *dsum,
+                                  void *stream) {
+    PNPP_REQUIRE((mask == nullptr) == (maskT == nullptr), PNPP_ERR_ARG, "attention_bwd: pass both mask orientations or neither");
+    PNPP_REQUIRE(p >= 0.f && p < 1.f, PNPP_ERR_ARG, "attention_bwd: dropout p=%g outside [0, 1)", (double)p);
+    const float keep_scale = 1.0f / (1.0f - p);
     PNPP_REQUIRE(qkv && out && d_out && lse && dqkv && dsum, PNPP_ERR_ARG, "attention_bwd: null pointer");
     PNPP_REQUIRE(B > 0 && N > 0 && H > 0, PNPP_ERR_ARG, "attention_bwd: non-positive size");
     PNPP_REQUIRE(head_dim == ATT_DH, PNPP_ERR_ARG, "attention_bwd: head dimension %d is not supported (only %d)", head_dim, ATT_DH);
@@ -501,13 +588,14 @@ extern "C" int pnpp_attention_bwd(const float *qkv, const float *out, const floa
     const float scale = 1.0f / sqrtf((float)head_dim);
     {
         ProfScope ps(st, "attention_bwd_dq_kernel B=%d N=%d H=%d", B, N, H);
-        hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3(N / 128, H, B), dim3(256), 0, st, qkv, out, d_out, lse, N, H, scale, dqkv,
-                           dsum);
+        hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3(N / 128, H, B), dim3(256), 0, st, qkv, out, d_out, lse, N, H, scale, mask,
+                           keep_scale, dqkv, dsum);
         PNPP_CHECK_LAUNCH("attention_bwd_dq");
     }
     {
         ProfScope ps(st, "attention_bwd_dkv_kernel B=%d N=%d H=%d", B, N, H);
-        hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3(N / 128, H, B), dim3(256), 0, st, qkv, d_out, lse, dsum, N, H, scale, dqkv);
+        hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3(N / 128, H, B), dim3(256), 0, st, qkv, d_out, lse, dsum, N, H, scale, maskT,
+                           keep_scale, dqkv);
         PNPP_CHECK_LAUNCH("attention_bwd_dkv");
     }
     return PNPP_OK;

@@ -4,9 +4,10 @@ The parameter containers are the reference's own modules in the same constructio
 nn.TransformerEncoderLayer cloned by nn.TransformerEncoder, nn.Linear), so state_dict keys, shapes and the seeded
 default initialisation are identical; forward() runs on the HIP kernels (pnpp_hip/transformer.py).
 
-Status: forward and backward are built (parity with the reference in eval mode and in train mode
-with the dropout probabilities at 0); nn.TransformerEncoderLayer's train-mode dropouts with p > 0 (the constructor's
-default 0.1) are not, and such calls raise instead of falling back to PyTorch.
+Status: forward and backward are built, including the train-mode dropouts of
+nn.TransformerEncoderLayer (own random streams: same distribution as the reference, not the same bits; parity with the
+reference is checked in eval mode and in train mode with the dropout probabilities at 0, the dropout paths against a
+float64 evaluation with the same masks).
 """
 import torch
 import torch.nn as nn

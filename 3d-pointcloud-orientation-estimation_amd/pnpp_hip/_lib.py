@@ -94,12 +94,13 @@ SIGNATURES = {
     "pnpp_proj_probs": (_i, [_fp, _fp, _i, _i, _fp, _fp]),
     "pnpp_proj_probs_bwd": (_i, [_fp, _fp, _fp, _i, _i, _fp, _fp]),
     "pnpp_linear_smallk": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
-    "pnpp_attention_fwd": (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _fp]),
+    "pnpp_attention_fwd": (_i, [_fp, _i, _i, _i, _i, _fp, _f, _fp, _fp, _fp]),
+    "pnpp_attention_dropout_mask": (_i, [_u64, _u64, _i, _i, _i, _f, _fp, _fp, _fp]),
     "pnpp_add_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp, _fp]),
     "pnpp_mean_points": (_i, [_fp, _i, _i, _i, _fp, _fp]),
     "pnpp_linear_smallk_bwd_scratch_bytes": (_sz, [_i, _i]),
     "pnpp_linear_smallk_bwd": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp]),
-    "pnpp_attention_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp]),
+    "pnpp_attention_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _f, _fp, _fp, _fp]),
     "pnpp_add_layernorm_bwd_scratch_bytes": (_sz, [_i, _i]),
     "pnpp_add_layernorm_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp, _fp, _fp, _fp]),
     "pnpp_mean_points_bwd": (_i, [_fp, _i, _i, _i, _fp, _fp]),

@@ -3,8 +3,10 @@ HIP kernels, forward and backward.  The dense projections go through the same pn
 as the heads of the other models; attention, residual LayerNorm, pooling and the input projection have their own
 kernels (csrc/transformer_kernels.hip) wrapped in torch.autograd.Functions here.  No PyTorch operator computes anything.
 
-Dropout: nn.TransformerEncoderLayer's four dropouts (attention weights, after out_proj, after the ReLU, after linear2)
-are identities in eval mode and for p = 0; train mode with p > 0 is not built yet and raises.
+Dropout (train mode): nn.TransformerEncoderLayer's four dropouts -- on the attention weights (bit-packed keep masks from
+a counter-based generator, applied inside the attention kernels, regenerable for the backward pass), after out_proj,
+after the ReLU and after linear2 (keep-masks of the projection kernels).  The random streams are this library's own:
+same distribution as the reference, not the same bits.
 """
 from __future__ import annotations
 
@@ -50,20 +52,40 @@ def linear_smallk(x2d: torch.Tensor, lin) -> torch.Tensor:
     return _LinearSmallK.apply(x2d, lin.weight, lin.bias)
 
 
+_drop_state = {"calls": 0}
+
+
+def attention_dropout_mask(B: int, N: int, H: int, p: float, device, seed=None, stream_id=None):
+    """Bit-packed keep masks (mask, maskT), each (B,H,N,N/32) int32, for dropout p on the attention weights.  The bits are
+    a pure function of (seed, stream_id); by default seed = torch.initial_seed() and stream_id counts the calls."""
+    if seed is None:
+        seed = torch.initial_seed()
+    if stream_id is None:
+        _drop_state["calls"] += 1
+        stream_id = _drop_state["calls"]
+    mask = torch.empty(B, H, N, N // 32, device=device, dtype=torch.int32)
+    maskT = torch.empty_like(mask)
+    L.check(L.lib().pnpp_attention_dropout_mask(int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1), B, N, H, float(p),
+                                                mask.data_ptr(), maskT.data_ptr(), _stream()))
+    return mask, maskT
+
+
 class _Attention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, num_heads):
+    def forward(ctx, qkv, num_heads, p, masks):
         qkv = _f32(qkv, "qkv")
         B, N, E3 = qkv.shape
         if E3 % (3 * num_heads) != 0:
             raise ValueError(f"attention: last dimension {E3} is not 3 * heads * head_dim")
         E = E3 // 3
+        mask, maskT = masks if masks is not None else (None, None)
         out = torch.empty(B, N, E, device=qkv.device, dtype=torch.float32)
         lse = torch.empty(B, num_heads, N, device=qkv.device, dtype=torch.float32)
-        L.check(L.lib().pnpp_attention_fwd(qkv.data_ptr(), B, N, num_heads, E // num_heads, out.data_ptr(), lse.data_ptr(),
+        L.check(L.lib().pnpp_attention_fwd(qkv.data_ptr(), B, N, num_heads, E // num_heads,
+                                           None if mask is None else mask.data_ptr(), float(p), out.data_ptr(), lse.data_ptr(),
                                            _stream()))
         ctx.save_for_backward(qkv, out, lse)
-        ctx.heads = num_heads
+        ctx.heads, ctx.p, ctx.masks = num_heads, float(p), (mask, maskT)
         ctx.mark_non_differentiable(lse)
         return out, lse
 
@@ -74,14 +96,21 @@ class _Attention(torch.autograd.Function):
         d_out = _f32(d_out, "d_out")
         dqkv = torch.empty_like(qkv)
         dsum = torch.empty_like(lse)
+        mask, maskT = ctx.masks
         L.check(L.lib().pnpp_attention_bwd(qkv.data_ptr(), out.data_ptr(), d_out.data_ptr(), lse.data_ptr(), B, N, ctx.heads,
-                                           E3 // 3 // ctx.heads, dqkv.data_ptr(), dsum.data_ptr(), _stream()))
-        return dqkv, None
+                                           E3 // 3 // ctx.heads, None if mask is None else mask.data_ptr(),
+                                           None if maskT is None else maskT.data_ptr(), ctx.p, dqkv.data_ptr(), dsum.data_ptr(),
+                                           _stream()))
+        return dqkv, None, None, None
 
 
-def attention(qkv: torch.Tensor, num_heads: int, want_lse: bool = False):
-    """qkv (B,N,3E), in_proj bias included -> (B,N,E) [, log-sum-exp of the scaled scores (B,H,N)]."""
-    out, lse = _Attention.apply(qkv, num_heads)
+def attention(qkv: torch.Tensor, num_heads: int, want_lse: bool = False, p: float = 0.0, masks=None):
+    """qkv (B,N,3E), in_proj bias included -> (B,N,E) [, log-sum-exp of the scaled scores (B,H,N)].
+    p > 0 applies dropout to the attention weights with the keep bits `masks` = attention_dropout_mask(...)
+    (drawn here when not given)."""
+    if p > 0.0 and masks is None:
+        masks = attention_dropout_mask(qkv.shape[0], qkv.shape[1], num_heads, p, qkv.device)
+    out, lse = _Attention.apply(qkv, num_heads, p if masks is not None else 0.0, masks)
     return (out, lse) if want_lse else out
 
 
@@ -154,20 +183,11 @@ class _Affine:
         self.weight, self.bias = weight, bias
 
 
-def _check_dropouts(model) -> None:
-    if not model.training:
-        return
-    for layer in model.transformer.layers:
-        ps = (layer.dropout.p, layer.dropout1.p, layer.dropout2.p, layer.self_attn.dropout)
-        if any(p > 0 for p in ps):
-            raise NotImplementedError(
-                "PointTransformer on the HIP path: train-mode dropout (p > 0) is not built; set the four dropout "
-                "probabilities of every encoder layer to 0 or call .eval() -- there is no PyTorch fallback")
-
-
 def point_transformer_forward(model, xyz: torch.Tensor) -> torch.Tensor:
-    """models/point_transformer.py:15-20 (dropouts inactive: eval mode or p = 0), differentiable."""
-    _check_dropouts(model)
+    """models/point_transformer.py:15-20, differentiable.  In train mode the four dropouts of every
+    nn.TransformerEncoderLayer are applied: on the attention weights inside the attention kernels (counter-based keep
+    bits), after out_proj (dropout1), after the ReLU (dropout) and after linear2 (dropout2) as keep-masks of the
+    projection kernels."""
     xyz = _f32(xyz, "xyz")
     B, N, K = xyz.shape
     x = linear_smallk(xyz.reshape(B * N, K), model.input_proj)                        # (B*N, E)
@@ -178,11 +198,11 @@ def point_transformer_forward(model, xyz: torch.Tensor) -> torch.Tensor:
         if layer.norm_first or att.in_proj_weight is None or not att.batch_first:
             raise NotImplementedError("only the post-norm, packed in_proj, batch_first encoder layer of the reference")
         qkv = ops.fc_block(x, _Affine(att.in_proj_weight, att.in_proj_bias), training=tr)   # (B*N, 3E), bias added
-        o = attention(qkv.view(B, N, 3 * E), att.num_heads).view(B * N, E)
-        o = ops.fc_block(o, att.out_proj, training=tr)
+        o = attention(qkv.view(B, N, 3 * E), att.num_heads, p=att.dropout if tr else 0.0).view(B * N, E)
+        o = ops.fc_block(o, att.out_proj, dropout=layer.dropout1, training=tr)
         x = add_layernorm(x, o, layer.norm1)
-        hid = ops.fc_block(x, layer.linear1, relu=True, training=tr)                    # relu(W1 x + b1)
-        f = ops.fc_block(hid, layer.linear2, training=tr)
+        hid = ops.fc_block(x, layer.linear1, relu=True, dropout=layer.dropout, training=tr)   # dropout(relu(W1 x + b1))
+        f = ops.fc_block(hid, layer.linear2, dropout=layer.dropout2, training=tr)
         x = add_layernorm(x, f, layer.norm2)
     pooled = mean_points(x.view(B, N, E))
     return ops.fc_block(pooled, model.fc_out, training=tr)

@@ -262,11 +262,19 @@ int pnpp_proj_probs_bwd(const float *vec, const float *dirs, const float *dprobs
 /* Point-transformer configuration (models/point_transformer.py:4-20), forward pass.
  * input_proj (nn.Linear with at most 8 inputs): y (M,N) = x (M,K) w^T (N,K) + b. */
 int pnpp_linear_smallk(const float *x, const float *w, const float *b, int M, int K, int N, float *y, void *stream);
-/* nn.MultiheadAttention core (torch.nn.functional.multi_head_attention_forward between in_proj and out_proj), eval mode:
+/* nn.MultiheadAttention core (torch.nn.functional.multi_head_attention_forward between in_proj and out_proj):
  * qkv (B,N,3E) with the in_proj bias added, E = H*head_dim, head h = columns h*head_dim.. of each third;
- * out (B,N,E) = concat_h softmax(q_h k_h^T / sqrt(head_dim)) v_h; lse (B,H,N) optional log-sum-exp of the scaled scores.
- * The N x N matrix is never materialised.  head_dim must be 16 and N a multiple of 128. */
-int pnpp_attention_fwd(const float *qkv, int B, int N, int H, int head_dim, float *out, float *lse, void *stream);
+ * out (B,N,E) = concat_h dropout(softmax(q_h k_h^T / sqrt(head_dim))) v_h; lse (B,H,N) optional log-sum-exp of the
+ * scaled scores.  The N x N matrix is never materialised.  head_dim must be 16 and N a multiple of 128.
+ * Dropout on the attention weights (train mode, nn.MultiheadAttention(dropout=p)): mask = bit-packed keep bits from
+ * pnpp_attention_dropout_mask (kept weights are scaled by 1/(1-p)); mask == NULL means no dropout (p is then ignored). */
+int pnpp_attention_fwd(const float *qkv, int B, int N, int H, int head_dim, const uint32_t *mask, float p, float *out,
+                       float *lse, void *stream);
+/* Keep bits, Bernoulli(1-p), a pure function of (seed, stream_id, element): mask (B,H,N,N/32) holds for every query the
+ * bits of its keys (bit = key % 32 of word key / 32); maskT (B,H,N,N/32) is the transpose (for every key the bits of the
+ * queries), read by the dK/dV kernel. */
+int pnpp_attention_dropout_mask(uint64_t seed, uint64_t stream_id, int B, int N, int H, float p, uint32_t *mask,
+                                uint32_t *maskT, void *stream);
 /* Post-norm residual block: y (M,E) = LayerNorm(x + r) * w + b over the last dimension (r may be NULL), E <= 128. */
 int pnpp_add_layernorm(const float *x, const float *r, const float *w, const float *b, int M, int E, float eps, float *y,
                        void *stream);
@@ -278,9 +286,11 @@ size_t pnpp_linear_smallk_bwd_scratch_bytes(int M, int N);
 int pnpp_linear_smallk_bwd(const float *x, const float *dy, int M, int K, int N, float *dw, float *db, void *scratch,
                            void *stream);
 /* attention: dqkv (B,N,3E) from qkv, the forward's out and lse, and d_out (B,N,E); dsum (B,H,N) is scratch
- * (rowsum(d_out * out) per head).  Scores are recomputed, never stored. */
+ * (rowsum(d_out * out) per head).  Scores are recomputed, never stored.  mask / maskT / p as in the forward (both NULL:
+ * no dropout). */
 int pnpp_attention_bwd(const float *qkv, const float *out, const float *d_out, const float *lse, int B, int N, int H,
-                       int head_dim, float *dqkv, float *dsum, void *stream);
+                       int head_dim, const uint32_t *mask, const uint32_t *maskT, float p, float *dqkv, float *dsum,
+                       void *stream);
 /* add_layernorm: du (M,E) = gradient w.r.t. both x and r; dwb (2,E) = (d weight, d bias). */
 size_t pnpp_add_layernorm_bwd_scratch_bytes(int M, int E);
 int pnpp_add_layernorm_bwd(const float *x, const float *r, const float *w, const float *dy, int M, int E, float eps,

@@ -99,9 +99,6 @@ def test_point_transformer_forward_matches_reference_capture(golden):
     print(f"\nHIP vs reference fp64: {d64:.2e}; reference fp32 vs its own fp64: {np.abs(ref32 - ref64).max():.2e}")
     assert d64 <= 2e-5 * max(1.0, np.abs(ref64).max())
     assert np.abs(out - g["pt_f64.train_out"]).max() <= 2e-5 * max(1.0, np.abs(ref64).max())   # train mode, p = 0
-    model.train()
-    with pytest.raises(NotImplementedError):
-        model(_t(g["xyz"]).cuda())                          # default dropout 0.1 in train mode: not built, no silent fallback
 
 
 def test_point_transformer_training_step_matches_reference_capture(golden):
@@ -134,3 +131,74 @@ def test_point_transformer_forward_larger_cloud_vs_oracle(oracle):
     ref = oracle.point_transformer_forward(xyz.double(), P64)
     out = model.cuda().eval()(xyz.cuda()).detach().cpu().double()
     assert float((out - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def _unpack(mask, N):
+    """(B,H,N,N/32) int32 bit-packed -> dense (B,H,N,N) float64 of {0,1} (bit j of word w = column 32 w + j)."""
+    m = mask.cpu().numpy().view(np.uint32)
+    bits = ((m[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(*m.shape[:3], N)
+    return torch.from_numpy(bits.astype(np.float64))
+
+
+def test_attention_dropout_masks_and_same_mask_parity():
+    """Keep bits: Bernoulli(1-p) with independent rows / columns, both orientations consistent, a pure function of the
+    seed; and the dropped attention (forward and backward) against float64 autograd evaluated with the SAME mask."""
+    from pnpp_hip import transformer as T
+    B, N, H, p = 2, 256, 4, 0.1
+    mask, maskT = T.attention_dropout_mask(B, N, H, p, "cuda", seed=11, stream_id=3)
+    keep = _unpack(mask, N)
+    assert torch.equal(keep, _unpack(maskT, N).transpose(-1, -2))                  # maskT is the transpose of mask
+    again, _ = T.attention_dropout_mask(B, N, H, p, "cuda", seed=11, stream_id=3)
+    other, _ = T.attention_dropout_mask(B, N, H, p, "cuda", seed=11, stream_id=4)
+    assert torch.equal(mask, again) and not torch.equal(mask, other)
+    n = keep.numel()
+    assert abs(float(keep.mean()) - (1 - p)) < 4 * math.sqrt(p * (1 - p) / n)
+    rows, cols = keep.mean(-1), keep.mean(-2)                                     # per-row / per-column keep rates
+    assert float((rows - (1 - p)).abs().max()) < 6 * math.sqrt(p * (1 - p) / N)
+    assert float((cols - (1 - p)).abs().max()) < 6 * math.sqrt(p * (1 - p) / N)
+    k = keep - keep.mean()
+    for shift in ((0, 1), (1, 0), (1, 1)):                                         # neighbouring bits are uncorrelated
+        c = float((k[..., :N - shift[0], :N - shift[1]] * k[..., shift[0]:, shift[1]:]).mean() / k.var())
+        assert abs(c) < 5 / math.sqrt(n), (shift, c)
+    g = torch.Generator().manual_seed(4)
+    E = 16 * H
+    qkv = torch.randn(B, N, 3 * E, generator=g)
+    up = torch.randn(B, N, E, generator=g)
+    qd = qkv.double().requires_grad_(True)
+    q, kk, v = (t.reshape(B, N, H, 16).transpose(1, 2) for t in qd.split(E, dim=-1))
+    w = torch.softmax((q * 0.25) @ kk.transpose(-1, -2), dim=-1) * keep / (1 - p)  # F.dropout semantics with this mask
+    ref = (w @ v).transpose(1, 2).reshape(B, N, E)
+    (ref * up.double()).sum().backward()
+    qg = qkv.clone().cuda().requires_grad_(True)
+    out = T.attention(qg, H, p=p, masks=(mask, maskT))
+    (out * up.cuda()).sum().backward()
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) <= 2e-5 * max(1.0, float(ref.detach().abs().max()))
+    err = float((qg.grad.cpu().double() - qd.grad).abs().max()) / max(1.0, float(qd.grad.abs().max()))
+    assert err <= 2e-5, err
+
+
+def test_point_transformer_trains_with_default_dropout():
+    """Train mode with the constructor's dropout 0.1 everywhere: finite loss and gradients for every parameter, different
+    draws on consecutive calls, eval unaffected; and the loss of a fixed batch goes down under FlatAdam."""
+    from pnpp_hip import ops, optim
+    import synthetic
+    torch.manual_seed(0)
+    model = _pt_model().cuda().train()
+    xyz, _, _, fwd = synthetic.rotated_clouds(4, 256, seed=2)
+    xyz, tgt = xyz.cuda(), fwd.cuda()
+    a, b = model(xyz).detach(), model(xyz).detach()
+    assert torch.isfinite(a).all() and not torch.equal(a, b)                        # fresh masks every call
+    model.eval()
+    assert torch.equal(model(xyz).detach(), model(xyz).detach())
+    model.train()
+    opt = optim.FlatAdam(model.parameters(), lr=1e-3)
+    hist = []
+    for _ in range(40):
+        opt.zero_grad()
+        loss = ops.mse_loss(model(xyz), tgt)
+        loss.backward()
+        opt.step()
+        hist.append(loss.item())
+    assert all(v == v for v in hist) and sum(hist[-5:]) / 5 < 0.7 * sum(hist[:5]) / 5, (hist[:5], hist[-5:])
+    for n, prm in model.named_parameters():
+        assert prm.grad is None or torch.isfinite(prm.grad).all(), n

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Timing of one training step of BASELINE config 5 (models/point_transformer.py, N=4096, 8 clouds per GPU = batch 64
-over 8 GPUs) on one MI355X: forward + MSE harness loss + backward + fused Adam, dropout probabilities at 0 (the only
-train-mode form the HIP path has).  Not the driver's bench line (that is bench.py / configs[1]); prints one JSON line
+over 8 GPUs) on one MI355X: forward + MSE harness loss + backward + fused Adam (--dropout sets the encoder layers' dropout probability).  Not the driver's bench line (that is bench.py / configs[1]); prints one JSON line
 with clouds/s, the per-kernel time table from the library's HIP-event profiler and the attention kernels' TFLOP/s."""
 import argparse
 import ctypes
@@ -21,12 +20,13 @@ def main():
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dropout", type=float, default=0.0, help="dropout probability of the encoder layers (reference default 0.1)")
     a = ap.parse_args()
     from models.point_transformer import PointTransformer
     from pnpp_hip import _lib, ops, optim
     import synthetic
     torch.manual_seed(42)
-    model = PointTransformer().cuda().train().set_dropout(0.0)
+    model = PointTransformer().cuda().train().set_dropout(a.dropout)
     opt = optim.FlatAdam(model.parameters(), lr=1e-3)
     xyz, _, _, fwd = synthetic.rotated_clouds(a.batch, a.points, seed=1234)
     xyz, tgt = xyz.cuda(), fwd.cuda()
@@ -72,7 +72,7 @@ def main():
         if tag.startswith("attention_bwd_dkv"):
             e["tflops"] = round(2.0 * att_flops_fwd * cnt / (ms * 1e-3) / 1e12, 1)   # S, dP, dV, dK
         table.append(e)
-    print(json.dumps({"workload": f"configs[4]: point_transformer N={a.points} batch={a.batch}/GPU, fwd+MSE+bwd+Adam, dropout p=0, f32",
+    print(json.dumps({"workload": f"configs[4]: point_transformer N={a.points} batch={a.batch}/GPU, fwd+MSE+bwd+Adam, dropout p={a.dropout}, f32",
                       "clouds_per_s": a.batch / dt, "ms_per_step": 1e3 * dt, "layers": L, "final_loss": float(loss.detach()),
                       "kernel_ms_total": round(sum(r[2] for r in rows), 3), "top_kernels": table}))
 
