@@ -28,7 +28,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # PNPP_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsals on a single-GPU box; RCCL refuses that)
+        backend = backend or os.environ.get("PNPP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     try:
         from . import sampling

@@ -31,8 +31,11 @@ class GraphedStep:
                 opt.zero_grad()
                 loss_fn(*self.static_in).backward()
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: with torch.distributed initialised, the process group's watchdog thread polls its events with
+        # HIP calls of its own; under the default (global) mode such a call during the capture would invalidate it
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             opt.zero_grad()
             self.static_loss = loss_fn(*self.static_in)
             self.static_loss.backward()

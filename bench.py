@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32x32x2_f32)
 
 
-def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph):
+def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=True):
     """Returns (step, launch_mode).  zero_grad + forward + loss + backward are replayed from one hipGraph when
     capture succeeds (falls back to eager launches otherwise); the all-reduce and the fused Adam follow eagerly."""
     from pnpp_hip import ops, dist as pdist
@@ -59,7 +59,8 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph):
             opt.zero_grad()
             loss = loss_fn(xyz, mu_gt, kappa_gt)
             loss.backward()
-        pdist.all_reduce_flat_grad(opt.flat_g)
+        if collective:   # the instrumented roofline pass runs on rank 0 alone: it must not enter a collective
+            pdist.all_reduce_flat_grad(opt.flat_g)
         opt.step(grad_scale=1.0 / world)
         return loss
 
@@ -226,7 +227,7 @@ def main():
     xyz, mu_gt, kappa_gt, _ = synthetic.rotated_clouds(B, N_POINTS, seed=1234 + rank)
     xyz, mu_gt, kappa_gt = xyz.to(dev), mu_gt.to(dev), kappa_gt.to(dev)
     step, launch_mode = build_step(model, opt, xyz, mu_gt, kappa_gt, world, not args.no_graph)
-    eager_step, _ = build_step(model, opt, xyz, mu_gt, kappa_gt, world, False) if launch_mode != "eager" else (step, None)
+    eager_step, _ = build_step(model, opt, xyz, mu_gt, kappa_gt, world, False, collective=False)   # rank-local, for the roofline pass
 
     for _ in range(args.warmup):
         step()
