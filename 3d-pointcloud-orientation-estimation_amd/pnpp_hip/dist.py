@@ -60,3 +60,7 @@ def all_reduce_flat_grad(flat_g: torch.Tensor, async_op: bool = False):
 
 def world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_initialized() else 0

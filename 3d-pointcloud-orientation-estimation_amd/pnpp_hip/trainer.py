@@ -58,7 +58,10 @@ def fit(model: torch.nn.Module, loss_fn: Callable, loaders: Dict[str, Iterable],
             model.train() if phase == "train" else model.eval()
             total = torch.zeros((), device=device, dtype=torch.float64)
             cnt = 0
-            for batch in loaders[phase]:
+            limit = _common_steps(loaders[phase], device) if phase == "train" else None
+            for step_i, batch in enumerate(loaders[phase]):
+                if limit is not None and step_i >= limit:
+                    break   # every rank takes the same number of optimiser steps (one all-reduce each)
                 batch = tuple(b.to(device, non_blocking=True) if torch.is_tensor(b) else b for b in batch)
                 if phase == "train":
                     opt.zero_grad()
@@ -73,13 +76,14 @@ def fit(model: torch.nn.Module, loss_fn: Callable, loaders: Dict[str, Iterable],
                         lv = loss_fn(model, batch)
                 total += lv.detach().double().sum()
                 cnt += lv.shape[0]
-            avg = float(total) / max(cnt, 1)
+            avg = _global_mean(total, cnt, device)
             hist[phase].append(avg)
             if phase == "val" and avg < best_val:
                 best_val, best_ep = avg, ep
                 best_state = copy.deepcopy(model.state_dict())
         va = hist["val"][-1] if hist["val"] else float("nan")
-        log(f"Ep {ep:03}/{epochs} Train {hist['train'][-1]:.4f} Val {va:.4f} | {label} | elapsed {time.time() - t0:.1f}s")
+        if pdist.rank() == 0:
+            log(f"Ep {ep:03}/{epochs} Train {hist['train'][-1]:.4f} Val {va:.4f} | {label} | elapsed {time.time() - t0:.1f}s")
     if best_state is None:
         best_state = copy.deepcopy(model.state_dict())
     return hist, best_state, best_ep
@@ -95,7 +99,28 @@ def evaluate(model, loss_fn, loader, device) -> float:
             lv = loss_fn(model, batch)
             total += lv.double().sum()
             cnt += lv.shape[0]
-    return float(total) / max(cnt, 1)
+    return _global_mean(total, cnt, device)
+
+
+def _common_steps(loader, device):
+    """With more than one rank: the smallest number of batches any rank's shard yields (shards differ by at most one
+    sample, so at most one batch); None for a single process."""
+    if pdist.world_size() <= 1:
+        return None
+    import torch.distributed as tdist
+    n = torch.tensor([len(loader)], dtype=torch.int64, device=device)
+    tdist.all_reduce(n, op=tdist.ReduceOp.MIN)
+    return int(n.item())
+
+
+def _global_mean(total: torch.Tensor, cnt: int, device) -> float:
+    """Mean over every rank's samples (one tiny all-reduce per epoch and phase): all ranks then agree on the history,
+    and with it on the best-validation epoch whose weights they keep."""
+    pair = torch.stack([total.double().reshape(()), torch.tensor(float(cnt), dtype=torch.float64, device=total.device)])
+    if pdist.world_size() > 1:
+        import torch.distributed as tdist
+        tdist.all_reduce(pair)
+    return float(pair[0]) / max(float(pair[1]), 1.0)
 
 
 def env_path(name: str, default: str):
