@@ -1455,9 +1455,10 @@ int launch_dw_xyz(const AOperand &dz, int C, const AOperand &a2, int M, float *s
 void dw_plan(int M, int Nc, int Kp, int *nsplit, int *kp_pad) {
     const int tilesC = cdiv(Nc, 64), tilesK = cdiv(Kp, 64);
     const int tiles = tilesC * tilesK;
-    // aim for ~2048 waves (2 per SIMD), at least 64 rows per wave, at most 1024 partial slabs
+    // aim for ~2048 waves (2 per SIMD), at least 64 rows per wave (32 for the small-M layers, whose waves are latency
+    // bound: twice the waves in flight beats the doubled slab count), at most 1024 partial slabs
     int split = cdiv(2048, tiles);
-    const int max_split = cdiv(M, 64);
+    const int max_split = cdiv(M, M <= 4096 ? 32 : 64);
     if (split > max_split) split = max_split;
     if (split > 1024) split = 1024;
     if (split < 1) split = 1;
