@@ -342,6 +342,8 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
     if (d->norm == PNPP_NORM_BATCH) PNPP_REQUIRE(a->rm && a->rv, PNPP_ERR_ARG, "fc_forward: running statistics are null");
     const FcSaved sv = fc_saved_layout(d, a->saved);
     const FcScratch sc = fc_scratch_layout(d, a->scratch);
+    PNPP_REQUIRE(!a->mask_out || (d->norm == PNPP_NORM_BATCH && d->training && d->M <= 32), PNPP_ERR_ARG,
+                 "fc_forward: the in-kernel dropout draw exists for the BatchNorm epilogue (training, M <= 32) only");
 
     if (fc_is_small(d)) {
         ProfScope ps(st, "fc_small_fwd_kernel M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -376,6 +378,12 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
             T.momentum = d->momentum, T.eps = d->eps;
             T.mean = sv.mean, T.istd = sv.istd, T.scale = sv.scale, T.shift = sv.shift;
             T.mask = a->mask, T.drop_scale = d->drop_scale, T.relu = d->relu, T.y = a->y;
+            if (a->mask_out) {
+                PNPP_REQUIRE(!a->mask && a->rng_counter && a->drop_p > 0.f && a->drop_p < 1.f, PNPP_ERR_ARG,
+                             "fc_forward: a drawn dropout mask needs rng_counter, 0 < drop_p < 1 and no given mask");
+                T.mask_out = a->mask_out, T.drop_p = a->drop_p, T.rng_seed = a->rng_seed;
+                T.rng_counter = reinterpret_cast<unsigned long long *>(a->rng_counter);
+            }
             return launch_gemm(A, W, d->M, d->N, d->K, E, nullptr, st);
         }
         if (d->training) {

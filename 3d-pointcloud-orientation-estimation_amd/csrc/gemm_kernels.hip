@@ -1137,7 +1137,33 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
                 float y = fmaf(part[e], cs[e % 32], cs[32 + e % 32]);
                 if (T.relu) y = fmaxf(y, 0.f);
                 if (T.mask) y = T.mask[(size_t)row * E.ldc + col] ? y * T.drop_scale : 0.f;
+                if (T.mask_out) {  // draw the keep bit of this element: one Philox word per element (a few hundred per workgroup)
+                    const unsigned long long sid = T.rng_counter[0];
+                    const unsigned idx = (unsigned)(row * E.ldc + col);
+                    unsigned c0 = idx, c1 = 0x44524f50u /* "DROP" */, c2 = (unsigned)sid, c3 = (unsigned)(sid >> 32);
+                    unsigned k0 = (unsigned)T.rng_seed, k1 = (unsigned)(T.rng_seed >> 32);
+#pragma unroll
+                    for (int rd = 0; rd < 10; ++rd) {
+                        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+                        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+                        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+                        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+                    }
+                    const bool keep = (double)c0 >= (double)T.drop_p * 4294967296.0;
+                    T.mask_out[(size_t)row * E.ldc + col] = keep ? 1 : 0;
+                    y = keep ? y * T.drop_scale : 0.f;
+                }
                 T.y[(size_t)row * E.ldc + col] = y;
+            }
+        }
+        if (T.mask_out) {  // every workgroup has read the counter above before it takes a ticket; the last one bumps it
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned long long t = atomicAdd(&T.rng_counter[1], 1ull);
+                if (t == (unsigned long long)gridDim.x * gridDim.y - 1) {
+                    T.rng_counter[1] = 0ull;
+                    T.rng_counter[0] += 1ull;
+                }
             }
         }
     } else if constexpr (EMODE != E_STORE) {

@@ -50,8 +50,15 @@ struct BnTail {  // E_BN_APPLY: the fully connected head's Linear -> BatchNorm1d
     long long *nbt = nullptr;
     float momentum = 0.1f, eps = 1e-5f;
     float *mean = nullptr, *istd = nullptr, *scale = nullptr, *shift = nullptr;  // outputs kept for backward
-    const uint8_t *mask = nullptr;
+    const uint8_t *mask = nullptr;   // given keep-mask (parity runs, injected masks)
     float drop_scale = 1.f;
+    // or: draw the keep-mask here (training with nn.Dropout): Bernoulli(1 - drop_p) bits from Philox4x32-10 keyed by
+    // rng_seed with stream id rng_counter[0] (device memory, post-incremented by the kernel through the ticket word
+    // rng_counter[1]: graph replays draw fresh masks); the drawn mask is written to mask_out for the backward pass
+    uint8_t *mask_out = nullptr;
+    float drop_p = 0.f;
+    unsigned long long rng_seed = 0;
+    unsigned long long *rng_counter = nullptr;
     int relu = 0;
     float *y = nullptr;
 };

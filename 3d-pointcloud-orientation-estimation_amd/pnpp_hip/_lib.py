@@ -46,7 +46,8 @@ class FcDesc(C.Structure):
 
 class FcFwdArgs(C.Structure):
     _fields_ = [("x", _fp), ("w", _fp), ("b", _fp), ("nw", _fp), ("nb", _fp), ("rm", _fp), ("rv", _fp), ("nbt", _fp),
-                ("mask", _fp), ("y", _fp), ("saved", _fp), ("scratch", _fp)]
+                ("mask", _fp), ("mask_out", _fp), ("drop_p", C.c_float), ("rng_seed", C.c_uint64), ("rng_counter", _fp),
+                ("y", _fp), ("saved", _fp), ("scratch", _fp)]
 
 
 class FcBwdArgs(C.Structure):

@@ -57,6 +57,19 @@ def _nbt(bn) -> Optional[torch.Tensor]:
     return t
 
 
+_dropout_counters = {}
+
+
+def _dropout_counter(device: torch.device) -> torch.Tensor:
+    """Device-side stream id of the in-kernel dropout draws: [counter, ticket word], bumped by the kernels themselves."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    c = _dropout_counters.get(key)
+    if c is None:
+        c = torch.zeros(2, dtype=torch.int64, device=device)
+        _dropout_counters[key] = c
+    return c
+
+
 _scratch_cache = {}
 
 
@@ -324,7 +337,7 @@ def set_abstraction(xyz, points, centre_idx, nsample, group_all, training, convs
 class _FcBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, nw, nb, rm, rv, mask, cfg):
-        norm, relu, training, eps, momentum, drop_scale, sinks, nbt = cfg
+        norm, relu, training, eps, momentum, drop_scale, sinks, nbt, draw = cfg
         x, w, b = _f32(x, "x"), _f32(w, "weight"), _f32(b, "bias")
         M, K = x.shape
         N = w.shape[0]
@@ -345,6 +358,10 @@ class _FcBlock(torch.autograd.Function):
         a = L.FcFwdArgs()
         a.x, a.w, a.b, a.nw, a.nb = x.data_ptr(), w.data_ptr(), b.data_ptr(), _p(nw), _p(nb)
         a.rm, a.rv, a.nbt, a.mask = _p(rm), _p(rv), _p(nbt), _p(mask)
+        if draw is not None:   # the kernel draws the keep-mask itself (no RNG launch, graph-replayable) and hands it back
+            p_drop, seed, counter = draw
+            mask = torch.empty(M, N, device=x.device, dtype=torch.uint8)
+            a.mask_out, a.drop_p, a.rng_seed, a.rng_counter = mask.data_ptr(), float(p_drop), int(seed) & (2**64 - 1), counter.data_ptr()
         a.y, a.saved, a.scratch = y.data_ptr(), saved.data_ptr(), scratch.data_ptr()
         L.check(lib.pnpp_fc_forward(C.byref(d), C.byref(a), _stream()))
         ctx.desc = d
@@ -398,8 +415,13 @@ def fc_block(x, linear, norm=None, relu=False, dropout=None, training=True, mask
     elif norm is not None:
         raise TypeError(f"unsupported norm module {type(norm).__name__}")
     drop_scale = 1.0
+    draw = None
     if training and mask is None and dropout is not None and dropout.p > 0:
-        mask = torch.empty(x.shape[0], linear.weight.shape[0], device=x.device, dtype=torch.uint8).bernoulli_(1.0 - dropout.p)
+        if kind == L.NORM_BATCH and x.shape[0] <= 32 and x.is_cuda:   # the BatchNorm epilogue draws it in the kernel
+            draw = (dropout.p, torch.initial_seed(), _dropout_counter(x.device))
+            drop_scale = 1.0 / (1.0 - dropout.p)
+        else:
+            mask = torch.empty(x.shape[0], linear.weight.shape[0], device=x.device, dtype=torch.uint8).bernoulli_(1.0 - dropout.p)
     if mask is not None:
         if not training:
             mask = None
@@ -409,7 +431,7 @@ def fc_block(x, linear, norm=None, relu=False, dropout=None, training=True, mask
             mask = mask.to(device=x.device, dtype=torch.uint8)
     sinks = tuple(getattr(p, "_pnpp_grad_sink", None) if p is not None else None for p in (linear.weight, linear.bias, nw, nb))
     nbt = _nbt(norm) if (training and kind == L.NORM_BATCH) else None   # bumped by the statistics kernel itself
-    cfg = (kind, relu, training, eps, momentum, drop_scale, sinks if any(s is not None for s in sinks) else None, nbt)
+    cfg = (kind, relu, training, eps, momentum, drop_scale, sinks if any(s is not None for s in sinks) else None, nbt, draw)
     return _FcBlock.apply(x, linear.weight, linear.bias, nw, nb, rm, rv, mask, cfg)
 
 

@@ -170,7 +170,7 @@ typedef struct {
     int relu;           /* apply ReLU after norm                                                  */
     int training;
     float eps, momentum;
-    float drop_scale;   /* 1/(1-p) applied with `mask`; ignored when mask == NULL                 */
+    float drop_scale;   /* 1/(1-p) applied with `mask` / the drawn mask; ignored without dropout   */
 } pnpp_fc_desc;
 
 typedef struct {
@@ -181,6 +181,13 @@ typedef struct {
     float *rm, *rv;      /* BatchNorm running stats or NULL                                        */
     int64_t *nbt;        /* BatchNorm num_batches_tracked (+1 in training) or NULL                 */
     const uint8_t *mask; /* (M,N) dropout keep-mask or NULL                                        */
+    uint8_t *mask_out;   /* or: (M,N) keep-mask DRAWN by the kernel (training, BatchNorm, M <= 32):
+                            Bernoulli(1 - drop_p) from Philox keyed by rng_seed, stream id rng_counter[0];
+                            the kernel post-increments rng_counter[0] (rng_counter[1] is its ticket word,
+                            zero on entry and exit); pass it as `mask` to pnpp_fc_backward.  NULL: unused */
+    float drop_p;
+    uint64_t rng_seed;
+    uint64_t *rng_counter;
     float *y;            /* out (M,N)                                                              */
     void *saved;         /* pnpp_fc_saved_bytes()                                                  */
     void *scratch;       /* pnpp_fc_scratch_bytes()                                                */

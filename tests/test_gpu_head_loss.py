@@ -239,3 +239,34 @@ def test_fc_block_eval_and_plain(ops):
     assert _rel(y.detach().cpu(), ref.detach()) < 1e-5
     y2 = ops.fc_block(x, lin, training=False)
     assert _rel(y2.detach().cpu(), lin(x).detach().double().cpu()) < 1e-5
+
+
+def test_fc_block_draws_its_dropout_mask_in_the_kernel(ops):
+    """Training, BatchNorm1d, batch <= 32: the keep-mask comes from the GEMM epilogue's own counter-based generator
+    (no RNG launch); it is Bernoulli(1-p), changes from call to call, and the backward pass uses exactly that mask."""
+    torch.manual_seed(3)
+    M, K, N, p = 32, 256, 512, 0.5
+    lin, bn, drop = nn.Linear(K, N).cuda(), nn.BatchNorm1d(N).cuda(), nn.Dropout(p)
+    x = torch.randn(M, K, device="cuda", requires_grad=True)
+    y = ops.fc_block(x, lin, bn, relu=False, dropout=drop, training=True)
+    y2 = ops.fc_block(x.detach(), lin, bn, relu=False, dropout=drop, training=True)
+    keep, keep2 = (y != 0), (y2 != 0)                          # bn(z) is never exactly 0, so zeros are dropped elements
+    rate = float(keep.float().mean())
+    assert abs(rate - (1 - p)) < 5 * math.sqrt(p * (1 - p) / (M * N)), rate
+    assert float((keep != keep2).float().mean()) > 0.3          # an independent draw on the second call
+    assert float(keep.float().mean(0).min()) > 0.1 and float(keep.float().mean(1).min()) > 0.35
+    # same function as BatchNorm1d (train) followed by this mask / (1 - p), forward and backward, in float64
+    up = torch.randn(M, N, device="cuda")
+    lin.zero_grad(), bn.zero_grad()
+    (y * up).sum().backward()
+    xd = x.detach().cpu().double().requires_grad_(True)
+    wd, bd = lin.weight.detach().cpu().double().requires_grad_(True), lin.bias.detach().cpu().double().requires_grad_(True)
+    gd, hd = bn.weight.detach().cpu().double().requires_grad_(True), bn.bias.detach().cpu().double().requires_grad_(True)
+    z = xd @ wd.t() + bd
+    zn = (z - z.mean(0)) / torch.sqrt(z.var(0, unbiased=False) + bn.eps) * gd + hd
+    ref = zn * keep.cpu().double() / (1 - p)
+    (ref * up.cpu().double()).sum().backward()
+    assert _rel(y.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+    assert _rel(x.grad.cpu().numpy(), xd.grad.numpy()) < 1e-4
+    assert _rel(lin.weight.grad.cpu().numpy(), wd.grad.numpy()) < 1e-4
+    assert _rel(bn.weight.grad.cpu().numpy(), gd.grad.numpy()) < 1e-4 and _rel(bn.bias.grad.cpu().numpy(), hd.grad.numpy()) < 1e-4
