@@ -414,6 +414,46 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
     return PNPP_OK;
 }
 
+// dW (N,K) = dz^T x for a batch of at most 32 rows (the head layers): an outer-product accumulation with no reduction
+// worth an MFMA tile.  Workgroup = 32 output rows (n) x 128 output columns (k): dz tile and x tile in LDS, each thread
+// owns one k and sixteen n.  Stores are 512-byte rows.
+__global__ void __launch_bounds__(256) dw_fewrows_kernel(const float *__restrict__ dz, const float *__restrict__ x, int M, int N,
+                                                         int K, float *__restrict__ dw) {
+    __shared__ __attribute__((aligned(16))) float dzs[32][32];
+    __shared__ float xs[32][128];
+    const int kl = threadIdx.x & 127, nh = threadIdx.x >> 7;
+    const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 32;
+    for (int f = threadIdx.x; f < 32 * 32; f += 256) {
+        const int m = f >> 5, n = f & 31;
+        dzs[m][n] = (m < M && n0 + n < N) ? dz[(size_t)m * N + n0 + n] : 0.f;
+    }
+    for (int f = threadIdx.x; f < 32 * 128; f += 256) {
+        const int m = f >> 7, k = f & 127;
+        xs[m][k] = (m < M && k0 + k < K) ? x[(size_t)m * K + k0 + k] : 0.f;
+    }
+    __syncthreads();
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll 4
+    for (int m = 0; m < 32; ++m) {
+        const float xv = xs[m][kl];
+        const float4 *d4 = reinterpret_cast<const float4 *>(&dzs[m][16 * nh]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 d = d4[q];
+            acc[4 * q] = fmaf(d.x, xv, acc[4 * q]), acc[4 * q + 1] = fmaf(d.y, xv, acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(d.z, xv, acc[4 * q + 2]), acc[4 * q + 3] = fmaf(d.w, xv, acc[4 * q + 3]);
+        }
+    }
+    if (k0 + kl < K)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int n = n0 + 16 * nh + j;
+            if (n < N) dw[(size_t)n * K + k0 + kl] = acc[j];
+        }
+}
+
 static int fc_backward_impl(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, hipStream_t st) {
     PNPP_TRY(fc_check(d));
     PNPP_REQUIRE(a && a->x && a->w && a->b && a->dy && a->saved && a->scratch && a->dw && a->db, PNPP_ERR_ARG,
@@ -465,7 +505,12 @@ static int fc_backward_impl(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, hi
     x.lda = d->K;
     int nsplit, kp_pad;
     dw_plan(d->M, d->N, d->K, &nsplit, &kp_pad);
-    if (nsplit == 1 && kp_pad == d->K) {  // a single partial in the gradient's own layout: write it in place
+    if (d->M <= 32) {  // a handful of rows: outer-product kernel, written in place
+        ProfScope ps(st, "dw_fewrows_kernel M=%d N=%d K=%d", d->M, d->N, d->K);
+        hipLaunchKernelGGL(dw_fewrows_kernel, dim3(cdiv(d->K, 128), cdiv(d->N, 32)), dim3(256), 0, st, sc.dz, a->x, d->M, d->N, d->K,
+                           a->dw);
+        PNPP_CHECK_LAUNCH("fc_backward(dw)");
+    } else if (nsplit == 1 && kp_pad == d->K) {  // a single partial in the gradient's own layout: write it in place
         PNPP_TRY(launch_dw(dz, d->N, x, d->K, d->M, a->dw, 1, kp_pad, st));
     } else {
         PNPP_TRY(launch_dw(dz, d->N, x, d->K, d->M, sc.dwslab, nsplit, kp_pad, st));
