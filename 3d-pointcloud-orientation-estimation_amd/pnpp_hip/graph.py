@@ -46,3 +46,65 @@ class GraphedStep:
                 s.copy_(t, non_blocking=True)
         self.graph.replay()
         return self.static_loss
+
+
+class GraphedSplitStep:
+    """The captured step cut in two, for data parallelism: the gradient all-reduce of the layers that finish first
+    overlaps the backward pass of the rest.
+
+        graph 1: zero_grad, stage1 forward, stage2 forward, loss, backward of stage2 (down to stage1's outputs)
+                 -> gradients of the parameters used by stage2 are final: their all-reduce starts (async, RCCL stream)
+        graph 2: backward of stage1                                  (runs while that all-reduce is in flight)
+                 -> all-reduce of the remaining (small) slice, wait for both, optimiser step (caller)
+
+    stage1(*inputs) -> tuple of tensors; stage2(*stage1_outputs) -> scalar loss.  stage2's parameters must be the tail
+    of the optimiser's flat buffer from `tail_offset` on (nn.Module.parameters() order with stage1's modules first).
+    For PointNet++: stage1 = sa1 + sa2 (6 % of the parameters), stage2 = sa3 + head + loss (94 %)."""
+
+    def __init__(self, opt, stage1: Callable, stage2: Callable, example_inputs: Sequence[torch.Tensor], tail_offset: int,
+                 warmup: int = 3, adopt_inputs: bool = False):
+        self.opt, self.tail_offset = opt, int(tail_offset)
+        self.static_in = list(example_inputs) if adopt_inputs else [t.clone() for t in example_inputs]
+
+        def fwd_bwd2():
+            opt.zero_grad()
+            mids = stage1(*self.static_in)
+            mids = mids if isinstance(mids, (tuple, list)) else (mids,)
+            cut = [m.detach().requires_grad_(True) if m.requires_grad else m for m in mids]   # autograd stops here
+            loss = stage2(*cut)
+            loss.backward()
+            return mids, cut, loss
+
+        def bwd1(mids, cut):
+            pairs = [(m, c.grad) for m, c in zip(mids, cut) if m.requires_grad and c.grad is not None]
+            torch.autograd.backward([m for m, _ in pairs], [g for _, g in pairs])
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                mids, cut, _ = fwd_bwd2()
+                bwd1(mids, cut)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph1, self.graph2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph1, capture_error_mode="thread_local"):
+            mids, cut, self.static_loss = fwd_bwd2()
+        with torch.cuda.graph(self.graph2, pool=self.graph1.pool(), capture_error_mode="thread_local"):
+            bwd1(mids, cut)
+        self._keep = (mids, cut)   # the autograd graph of stage1 belongs to the captured memory
+
+    def __call__(self, *inputs: torch.Tensor, all_reduce: Callable = None) -> torch.Tensor:
+        """all_reduce(tensor) -> work handle with .wait() (or None): called on the two slices of the flat gradient."""
+        for s, t in zip(self.static_in, inputs):
+            if s.data_ptr() != t.data_ptr():
+                s.copy_(t, non_blocking=True)
+        g = self.opt.flat_g
+        self.graph1.replay()
+        h1 = all_reduce(g[self.tail_offset:]) if all_reduce is not None else None
+        self.graph2.replay()
+        h2 = all_reduce(g[:self.tail_offset]) if all_reduce is not None and self.tail_offset > 0 else None
+        for h in (h1, h2):
+            if h is not None:
+                h.wait()
+        return self.static_loss

@@ -54,6 +54,15 @@ class FlatAdam:
     def numel(self) -> int:
         return self.flat_p.numel()
 
+    def offset_of(self, param: torch.nn.Parameter) -> int:
+        """Start of `param` in the flat buffers (parameters keep the order they were passed in)."""
+        off = 0
+        for p in self.params:
+            if p is param:
+                return off
+            off += p.numel()
+        raise KeyError("parameter is not managed by this optimiser")
+
     def zero_grad(self) -> None:
         """One memset; autograd then accumulates in place into the flat buffer."""
         self.flat_g.zero_()

@@ -291,3 +291,65 @@ def test_hipgraph_step_equals_eager(oracle):
         assert a != b                                      # consecutive replays keep drawing
     finally:
         PointNetSetAbstraction.sampler = old
+
+
+def test_split_hipgraph_step_equals_eager(oracle):
+    """The two-graph step used under data parallelism (forward + sa3/head backward | sa2/sa1 backward, the gradient
+    slices handed to an all-reduce callback in between): same loss and, bit for bit, the same flat gradient as eager
+    launches; the callback sees the final sa3 + head slice before the second graph has run."""
+    import copy
+    from models.pointnet_pp_vonMises import PointNetPPVonMises
+    from models.pointnet_pp_8dir import PointNetSetAbstraction
+    from pnpp_hip import ops, optim, sampling
+    from pnpp_hip.graph import GraphedSplitStep
+    old = PointNetSetAbstraction.sampler
+    PointNetSetAbstraction.sampler = "device"
+    try:
+        torch.manual_seed(42)
+        m1 = PointNetPPVonMises().cuda().train()
+        m1.drop.p = 0.0
+        m2 = copy.deepcopy(m1)
+        o1, o2 = optim.FlatAdam(m1.parameters()), optim.FlatAdam(m2.parameters())
+        xyz, mu_gt, kappa_gt, _ = oracle.synthetic_clouds(8, 1024, seed=3)
+        xyz, mu_gt, kappa_gt = xyz.cuda(), mu_gt.cuda(), kappa_gt.cuda()
+
+        def stage1(x, m, k):
+            l1_xyz, l1_pts = m1.sa1(x, None)
+            return m1.sa2(l1_xyz, l1_pts)
+
+        def stage2(l2_xyz, l2_pts):
+            _, l3 = m1.sa3(l2_xyz, l2_pts)
+            f = ops.fc_block(l3.view(l3.size(0), -1), m1.fc1, m1.bn1, relu=True, training=True)
+            f = ops.fc_block(f, m1.fc2, m1.bn2, relu=True, dropout=m1.drop, training=True)
+            return ops.vm_head_kl_loss(ops.fc_block(f, m1.fc3, training=True), mu_gt, kappa_gt, reduction="mean")
+
+        tail = o1.offset_of(next(m1.sa3.parameters()))
+        assert 0 < tail < o1.numel and tail == sum(p.numel() for p in list(m1.sa1.parameters()) + list(m1.sa2.parameters()))
+        g = GraphedSplitStep(o1, stage1, stage2, [xyz, mu_gt, kappa_gt], tail)
+        for p, q in zip(m1.buffers(), m2.buffers()):
+            p.copy_(q)
+        seen = []
+
+        class _Done:
+            def wait(self):
+                pass
+
+        def fake_all_reduce(t):
+            seen.append((t.data_ptr(), t.numel(), t.clone()))
+            return _Done()
+
+        for it in range(2):
+            sampling.reset(100 * it)
+            seen.clear()
+            l1 = float(g(xyz, mu_gt, kappa_gt, all_reduce=fake_all_reduce))
+            sampling.reset(100 * it)
+            o2.zero_grad()
+            l2 = ops.vm_head_kl_loss(m2.features(xyz), mu_gt, kappa_gt, reduction="mean")
+            l2.backward()
+            assert l1 == float(l2), (it, l1, float(l2))
+            assert torch.equal(o1.flat_g, o2.flat_g)
+            # first callback: the tail slice, already final (equal to the eager gradient) before graph 2 was replayed
+            assert seen[0][1] == o1.numel - tail and torch.equal(seen[0][2], o2.flat_g[tail:])
+            assert seen[1][1] == tail and torch.equal(seen[1][2], o2.flat_g[:tail])
+    finally:
+        PointNetSetAbstraction.sampler = old
