@@ -85,8 +85,11 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     return v;
 }
 
+// centre != nullptr: the query of (b, q) is xyz[b, centre[b, q]] and the kernel also writes it to out_a / out_b (the
+// caller's new_xyz and the copy kept for backward) -- the set-abstraction forward then needs no separate gather launch.
 __global__ void __launch_bounds__(256) knn_kernel(const float *__restrict__ new_xyz, const float *__restrict__ xyz, int S,
-                                                  int N, int k, int32_t *__restrict__ idx) {
+                                                  int N, int k, int32_t *__restrict__ idx, const int32_t *__restrict__ centre,
+                                                  float *__restrict__ out_a, float *__restrict__ out_b) {
     __shared__ float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE], sn[KNN_TILE];
     __shared__ unsigned long long best[4][2][KNN_KMAX];
     __shared__ unsigned long long pool[4][KNN_POOL];
@@ -97,9 +100,14 @@ __global__ void __launch_bounds__(256) knn_kernel(const float *__restrict__ new_
     const bool active = q < S;  // wave-uniform
     float ax = 0.f, ay = 0.f, az = 0.f, sa = 0.f;
     if (active) {
-        const float *a = new_xyz + ((size_t)b * S + q) * 3;
+        const float *a = centre ? xyz + ((size_t)b * N + centre[(size_t)b * S + q]) * 3 : new_xyz + ((size_t)b * S + q) * 3;
         ax = a[0], ay = a[1], az = a[2];
         sa = sq3_exact(ax, ay, az);
+        if (centre && lane < 3) {
+            const float v = lane == 0 ? ax : (lane == 1 ? ay : az);
+            out_a[((size_t)b * S + q) * 3 + lane] = v;
+            if (out_b) out_b[((size_t)b * S + q) * 3 + lane] = v;
+        }
     }
     int cur = 0;         // which half of best[] holds the current list
     bool have = false;   // best[cur][0..k) is valid (wave-uniform)
@@ -552,7 +560,23 @@ int launch_knn(const float *new_xyz, const float *xyz, int B, int S, int N, int 
     PNPP_REQUIRE(k <= KNN_KMAX, PNPP_ERR_ARG, "knn: nsample=%d exceeds the supported maximum %d", k, KNN_KMAX);
     PNPP_REQUIRE(B <= 65535, PNPP_ERR_ARG, "knn: batch %d exceeds grid limit", B);
     ProfScope ps(st, "knn_kernel B=%d S=%d N=%d k=%d", B, S, N, k);
-    hipLaunchKernelGGL(knn_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, st, new_xyz, xyz, S, N, k, idx);
+    hipLaunchKernelGGL(knn_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, st, new_xyz, xyz, S, N, k, idx, (const int32_t *)nullptr,
+                       (float *)nullptr, (float *)nullptr);
+    PNPP_CHECK_LAUNCH("knn");
+    return PNPP_OK;
+}
+
+// kNN whose queries are gathered centres: also writes the centre coordinates (out_a, optional out_b)
+int launch_knn_centres(const float *xyz, const int32_t *centre, int B, int S, int N, int k, int32_t *idx, float *out_a,
+                       float *out_b, hipStream_t st) {
+    PNPP_REQUIRE(xyz && centre && idx && out_a, PNPP_ERR_ARG, "knn: null pointer");
+    PNPP_REQUIRE(B > 0 && S > 0 && N > 0 && k > 0, PNPP_ERR_ARG, "knn: non-positive size (B=%d S=%d N=%d k=%d)", B, S, N, k);
+    PNPP_REQUIRE(k <= N, PNPP_ERR_RANGE, "selected index k out of range (k=%d > N=%d)", k, N);
+    PNPP_REQUIRE(k <= KNN_KMAX, PNPP_ERR_ARG, "knn: nsample=%d exceeds the supported maximum %d", k, KNN_KMAX);
+    PNPP_REQUIRE(B <= 65535, PNPP_ERR_ARG, "knn: batch %d exceeds grid limit", B);
+    ProfScope ps(st, "knn_kernel B=%d S=%d N=%d k=%d", B, S, N, k);
+    hipLaunchKernelGGL(knn_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, st, (const float *)nullptr, xyz, S, N, k, idx, centre, out_a,
+                       out_b);
     PNPP_CHECK_LAUNCH("knn");
     return PNPP_OK;
 }

@@ -181,12 +181,12 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
         PNPP_TRY(launch_gather_centres(a->xyz, nullptr, d->B, d->N, 1, a->new_xyz, sv.new_xyz, st));  // the origin
     } else {
         PNPP_REQUIRE(d->S <= d->N, PNPP_ERR_RANGE, "sa_forward: npoint=%d > N=%d", d->S, d->N);
-        PNPP_TRY(launch_gather_centres(a->xyz, a->centre_idx, d->B, d->N, d->S, a->new_xyz, sv.new_xyz, st));
         if (a->neighbour_idx) {
+            PNPP_TRY(launch_gather_centres(a->xyz, a->centre_idx, d->B, d->N, d->S, a->new_xyz, sv.new_xyz, st));
             hipError_t e = hipMemcpyAsync(sv.idx, a->neighbour_idx, (size_t)g.M * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
             PNPP_REQUIRE(e == hipSuccess, PNPP_ERR_LAUNCH, "sa_forward: neighbour copy failed: %s", hipGetErrorString(e));
-        } else {
-            PNPP_TRY(launch_knn(sv.new_xyz, a->xyz, d->B, d->S, d->N, d->K, sv.idx, st));
+        } else {  // the neighbour search gathers its own queries and writes the centre coordinates on the way
+            PNPP_TRY(launch_knn_centres(a->xyz, a->centre_idx, d->B, d->S, d->N, d->K, sv.idx, a->new_xyz, sv.new_xyz, st));
         }
     }
 
