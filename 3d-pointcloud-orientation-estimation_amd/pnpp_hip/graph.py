@@ -29,7 +29,7 @@ class GraphedStep:
         with torch.cuda.stream(side):
             for _ in range(warmup):                      # settle workspaces / autotuned allocations before capture
                 opt.zero_grad()
-                loss_fn(*self.static_in).backward()
+                self._run(loss_fn)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
@@ -37,8 +37,14 @@ class GraphedStep:
         # HIP calls of its own; under the default (global) mode such a call during the capture would invalidate it
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             opt.zero_grad()
-            self.static_loss = loss_fn(*self.static_in)
-            self.static_loss.backward()
+            self.static_loss = self._run(loss_fn)
+
+    def _run(self, loss_fn) -> torch.Tensor:
+        """loss_fn may return a loss to differentiate, or (no grad_fn) one whose backward pass it has already run."""
+        loss = loss_fn(*self.static_in)
+        if loss.requires_grad:
+            loss.backward()
+        return loss
 
     def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
         for s, t in zip(self.static_in, inputs):
@@ -72,7 +78,8 @@ class GraphedSplitStep:
             mids = mids if isinstance(mids, (tuple, list)) else (mids,)
             cut = [m.detach().requires_grad_(True) if m.requires_grad else m for m in mids]   # autograd stops here
             loss = stage2(*cut)
-            loss.backward()
+            if loss.requires_grad:   # else stage2 has run its own backward pass (fused loss + seed)
+                loss.backward()
             return mids, cut, loss
 
         def bwd1(mids, cut):

@@ -537,6 +537,24 @@ def vm_head_kl_loss(o, mu_gt, kappa_gt, reduction: str = "mean"):
     return _VmHeadKlLoss.apply(o, mu_gt, kappa_gt, reduction == "mean")
 
 
+def vm_head_kl_loss_backward(o, mu_gt, kappa_gt) -> torch.Tensor:
+    """The training step's `loss = kl(...).mean(); loss.backward()` in one go: the fused launch already produces
+    d loss / d o, so the backward pass is seeded with it directly (autograd would otherwise launch a fill for the
+    scalar's unit gradient and a multiply by it).  Returns the detached mean loss; gradients of everything upstream of
+    `o` are accumulated exactly as by loss.backward()."""
+    o32, mu_gt, kappa_gt = _f32(o, "o"), _f32(mu_gt, "mu_gt"), _f32(kappa_gt, "kappa_gt")
+    B = o32.shape[0]
+    if o32.dim() != 2 or o32.shape[1] != 2 or mu_gt.numel() != B or kappa_gt.numel() != B:
+        raise ValueError("vm_head_kl_loss_backward: o must be (B,2) and the targets (B,)")
+    loss = torch.empty((), device=o32.device, dtype=torch.float32)
+    d_o = torch.empty_like(o32)
+    L.check(L.lib().pnpp_vm_head_kl_mean(o32.data_ptr(), mu_gt.data_ptr(), kappa_gt.data_ptr(), B, None, None, None,
+                                         loss.data_ptr(), d_o.data_ptr(), _stream()))
+    if o.requires_grad:
+        torch.autograd.backward([o], [d_o])
+    return loss
+
+
 class _MatchLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mu, kappa, w, vm_gt, K_gt):

@@ -40,8 +40,8 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
     capture succeeds (falls back to eager launches otherwise); the all-reduce and the fused Adam follow eagerly."""
     from pnpp_hip import ops, dist as pdist
 
-    def loss_fn(x, m, k):   # head + KL + .mean() (train_single_peak_vonMises_KL.py:82-83) as one fused launch
-        return ops.vm_head_kl_loss(model.features(x), m, k, reduction="mean")
+    def loss_fn(x, m, k):   # head + KL + .mean() + the seed of loss.backward() (train_single_peak_vonMises_KL.py:82-84) fused
+        return ops.vm_head_kl_loss_backward(model.features(x), m, k)
 
     graphed, split = None, None
     if use_graph and world > 1 and collective and os.environ.get("PNPP_NO_OVERLAP") != "1":
@@ -60,7 +60,7 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
                 f = l3.view(l3.size(0), -1)
                 f = ops.fc_block(f, model.fc1, model.bn1, relu=True, training=model.training)
                 f = ops.fc_block(f, model.fc2, model.bn2, relu=True, dropout=model.drop, training=model.training)
-                return ops.vm_head_kl_loss(ops.fc_block(f, model.fc3, training=model.training), mu_gt, kappa_gt, reduction="mean")
+                return ops.vm_head_kl_loss_backward(ops.fc_block(f, model.fc3, training=model.training), mu_gt, kappa_gt)
 
             tail = opt.offset_of(next(model.sa3.parameters()))
             split = GraphedSplitStep(opt, stage1, stage2, [xyz, mu_gt, kappa_gt], tail, adopt_inputs=True)
@@ -85,7 +85,8 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
         else:
             opt.zero_grad()
             loss = loss_fn(xyz, mu_gt, kappa_gt)
-            loss.backward()
+            if loss.requires_grad:
+                loss.backward()
         if collective:   # the instrumented roofline pass runs on rank 0 alone: it must not enter a collective
             pdist.all_reduce_flat_grad(opt.flat_g)
         opt.step(grad_scale=1.0 / world)

@@ -270,3 +270,20 @@ def test_fc_block_draws_its_dropout_mask_in_the_kernel(ops):
     assert _rel(x.grad.cpu().numpy(), xd.grad.numpy()) < 1e-4
     assert _rel(lin.weight.grad.cpu().numpy(), wd.grad.numpy()) < 1e-4
     assert _rel(bn.weight.grad.cpu().numpy(), gd.grad.numpy()) < 1e-4 and _rel(bn.bias.grad.cpu().numpy(), hd.grad.numpy()) < 1e-4
+
+
+def test_vm_head_kl_loss_backward_equals_autograd(ops):
+    """loss + backward seed in one call: same loss and the same upstream gradients as loss.backward()."""
+    g = torch.Generator().manual_seed(9)
+    B = 32
+    lin = nn.Linear(16, 2).cuda()
+    x = torch.randn(B, 16, generator=g).cuda()
+    mu_gt = ((torch.rand(B, generator=g) * 2 - 1) * math.pi).cuda()
+    kap_gt = torch.full((B,), 8.0).cuda()
+    loss_a = ops.vm_head_kl_loss(lin(x), mu_gt, kap_gt, reduction="mean")
+    loss_a.backward()
+    ga, gb = lin.weight.grad.clone(), lin.bias.grad.clone()
+    lin.zero_grad()
+    loss_b = ops.vm_head_kl_loss_backward(lin(x), mu_gt, kap_gt)
+    assert not loss_b.requires_grad and float(loss_b) == float(loss_a)
+    assert torch.equal(lin.weight.grad, ga) and torch.equal(lin.bias.grad, gb)
