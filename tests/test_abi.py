@@ -83,7 +83,7 @@ def test_python_surface_names_and_state_dict():
     from models import base
     from models.pointnet_pp_8dir import PointNetSetAbstraction, PointNetPP8Dir, DIRS_8
     from models.pointnet_pp_vonMises import PointNetPPVonMises
-    from models.pointnet_pp_mvM import PointNetPPMvM, mvm_density_on_grid, _maybe_transpose_xyz
+    from models.pointnet_pp_mvM import PointNetPPMvM, mvm_density_on_grid, _as_points_last
     assert callable(base.index_points) and callable(base.square_distance) and callable(base.query_ball_point)
     assert DIRS_8.shape == (8, 3)
     counts = {PointNetPPVonMises: 1465922, PointNetPPMvM: 1469520, PointNetPP8Dir: 1467464}
@@ -101,10 +101,12 @@ def test_python_surface_names_and_state_dict():
     assert sd["head_pi.weight"].abs().sum() == 0 and sd["head_mu.weight"].abs().sum() == 0
     assert "ln1.weight" in sd and "ln2.bias" in sd
     with pytest.raises(ValueError):
-        _maybe_transpose_xyz(torch.zeros(2, 5, 7))
-    assert _maybe_transpose_xyz(torch.zeros(2, 5, 3)).shape == (2, 3, 5)
+        _as_points_last(torch.zeros(2, 5, 7))
+    with pytest.raises(AssertionError):
+        _as_points_last(torch.zeros(5, 3))
+    assert _as_points_last(torch.zeros(2, 5, 3)).shape == (2, 5, 3) and _as_points_last(torch.zeros(2, 3, 5)).shape == (2, 5, 3)
     th, p = mvm_density_on_grid(torch.zeros(2, 4), torch.ones(2, 4), torch.full((2, 4), 0.25), num=90)
-    assert p.shape == (2, 89) and torch.allclose(p.sum(-1), torch.ones(2), atol=1e-5)
+    assert th.shape == (89,) and p.shape == (2, 89) and torch.allclose(p.sum(-1), torch.ones(2), atol=1e-5)
 
 
 def test_no_cpu_fallback():
