@@ -3,11 +3,10 @@ PointNetPPXYZ_Schedmit, the backbone with two unit-vector heads (rotated Y = upr
 import torch.nn as nn
 
 from pnpp_hip import ops
-from .pointnet_pp import _BackboneBNHead
-from .pointnet_pp_8dir import PointNetSetAbstraction  # noqa: F401
+from .pointnet_pp_8dir import BackboneBNHead, PointNetSetAbstraction  # noqa: F401
 
 
-class PointNetPPXYZ_Schedmit(_BackboneBNHead):
+class PointNetPPXYZ_Schedmit(BackboneBNHead):
     """forward(x (B,N,3)) -> (v2, v3), each (B,3), L2-normalised head_y / head_z outputs (lines 47-90)."""
 
     def __init__(self):
@@ -16,7 +15,7 @@ class PointNetPPXYZ_Schedmit(_BackboneBNHead):
         self.head_z = nn.Linear(256, 3)
 
     def forward(self, x, centres=None, drop_mask=None):
-        feat = self.features(x, centres, drop_mask)
+        feat = self.trunk(x, centres, drop_mask)
         v2 = ops.l2_normalize(ops.fc_block(feat, self.head_y, training=self.training))
         v3 = ops.l2_normalize(ops.fc_block(feat, self.head_z, training=self.training))
         return v2, v3

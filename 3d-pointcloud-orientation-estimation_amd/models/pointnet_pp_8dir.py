@@ -85,8 +85,11 @@ DIRS_8 = torch.tensor([
 ])
 
 
-class PointNetPP8Dir(nn.Module):
-    """PointNet++ backbone + 8-way direction head, raw logits out (models/pointnet_pp_8dir.py:58-85)."""
+class BackboneBNHead(nn.Module):
+    """sa1 / sa2 / sa3 + fc1 / bn1 / fc2 / bn2 / drop: the part shared by PointNetPP8Dir, PointNetPPVonMises, PointNetPP,
+    PointNetPPFwd, PointNetPPXYZ and PointNetPPXYZ_Schedmit (identical constructor lines in each of the reference's
+    files, e.g. models/pointnet_pp_8dir.py:61-73).  Subclasses add their output layers AFTER super().__init__(), so
+    parameter creation order -- and with it the seeded default initialisation -- matches the reference."""
 
     def __init__(self):
         super().__init__()
@@ -99,9 +102,10 @@ class PointNetPP8Dir(nn.Module):
         self.fc2 = nn.Linear(512, 256)
         self.bn2 = nn.BatchNorm1d(256)
         self.drop = nn.Dropout(0.5)
-        self.fc3 = nn.Linear(256, 8)
 
-    def forward(self, xyz, centres=None, drop_mask=None):
+    def trunk(self, xyz, centres=None, drop_mask=None):
+        """(B,N,3) -> (B,256): everything up to and including the dropout in front of the output layers.
+        centres = (sa1 centre indices, sa2 centre indices) and drop_mask (B,256) inject the random draws (parity runs)."""
         B = xyz.size(0)
         c1, c2 = centres if centres is not None else (None, None)
         l1_xyz, l1_pts = self.sa1(xyz, None, c1)
@@ -109,5 +113,15 @@ class PointNetPP8Dir(nn.Module):
         _, l3_pts = self.sa3(l2_xyz, l2_pts)
         x = l3_pts.view(B, -1)
         x = ops.fc_block(x, self.fc1, self.bn1, relu=True, training=self.training)
-        x = ops.fc_block(x, self.fc2, self.bn2, relu=True, dropout=self.drop, training=self.training, mask=drop_mask)
-        return ops.fc_block(x, self.fc3, training=self.training)
+        return ops.fc_block(x, self.fc2, self.bn2, relu=True, dropout=self.drop, training=self.training, mask=drop_mask)
+
+
+class PointNetPP8Dir(BackboneBNHead):
+    """PointNet++ backbone + 8-way direction head, raw logits out (models/pointnet_pp_8dir.py:58-85)."""
+
+    def __init__(self):
+        super().__init__()
+        self.fc3 = nn.Linear(256, 8)
+
+    def forward(self, xyz, centres=None, drop_mask=None):
+        return ops.fc_block(self.trunk(xyz, centres, drop_mask), self.fc3, training=self.training)

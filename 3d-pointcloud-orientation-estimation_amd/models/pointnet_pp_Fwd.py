@@ -3,11 +3,10 @@ PointNetSetAbstraction, DIRS_8 and PointNetPPFwd, the backbone with a unit 3-vec
 import torch.nn as nn
 
 from pnpp_hip import ops
-from .pointnet_pp import _BackboneBNHead
-from .pointnet_pp_8dir import DIRS_8, PointNetSetAbstraction  # noqa: F401
+from .pointnet_pp_8dir import DIRS_8, BackboneBNHead, PointNetSetAbstraction  # noqa: F401
 
 
-class PointNetPPFwd(_BackboneBNHead):
+class PointNetPPFwd(BackboneBNHead):
     """forward(xyz (B,N,3)) -> (B,3) unit vector: F.normalize(fc3(x), dim=1) (models/pointnet_pp_Fwd.py:77-98)."""
 
     def __init__(self):
@@ -15,4 +14,4 @@ class PointNetPPFwd(_BackboneBNHead):
         self.fc3 = nn.Linear(256, 3)
 
     def forward(self, xyz, centres=None, drop_mask=None):
-        return ops.l2_normalize(ops.fc_block(self.features(xyz, centres, drop_mask), self.fc3, training=self.training))
+        return ops.l2_normalize(ops.fc_block(self.trunk(xyz, centres, drop_mask), self.fc3, training=self.training))
