@@ -24,22 +24,19 @@ class PointCloudDatasetMvM(Dataset):
 
     @staticmethod
     def _read_mvM(gt_path, max_K=4):
+        """-> (table (max_K,3) float32 [mu, kappa, weight] zero padded / truncated, K as written in the file)."""
         with open(gt_path, "r", encoding="utf-8") as f:
             lines = [ln.strip() for ln in f if ln.strip() and not ln.startswith("#")]
         if len(lines) < 2:
             raise RuntimeError(f"GT file too short or malformed: {gt_path}")
-        parts = lines[0].split()
-        if len(parts) < 2:
+        head = lines[0].split()
+        if len(head) < 2:
             raise RuntimeError(f"GT file K line malformed: {gt_path}")
-        K = int(parts[1])
-        rows = []
-        for ln in lines[2:]:
-            vals = ln.split()
-            if len(vals) >= 3:
-                rows.append([float(vals[0]), float(vals[1]), float(vals[2])])
-        while len(rows) < max_K:
-            rows.append([0.0, 0.0, 0.0])
-        return torch.tensor(np.asarray(rows, dtype=np.float64)[:max_K], dtype=torch.float32), K
+        peaks = [tok[:3] for tok in (ln.split() for ln in lines[2:]) if len(tok) >= 3][:max_K]   # lines[1] is the column header
+        table = np.zeros((max_K, 3), dtype=np.float32)
+        if peaks:
+            table[:len(peaks)] = np.asarray(peaks, dtype=np.float64)
+        return torch.from_numpy(table), int(head[1])
 
     def __len__(self):
         return len(self.samples)
