@@ -739,38 +739,86 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         const float *bp = Ws + lh * BN + wn * TN + l31;
-        {
-            // K loop, software-pipelined by hand: the LDS operand reads of block b+1 (SB k-steps) are issued before
-            // the MFMAs of block b, so an MFMA never waits for a read issued right in front of it
-            constexpr int SB = (KD / 2) % 4 == 0 ? 4 : 2, NBLK = (KD / 2) / SB;
-            float ra[2][SB][MT], rb[2][SB][NT];
-            auto ld = [&](int buf, int s0) {
+        if constexpr (SWZ) {
+            // K loop for the swizzled tile.  The reduction index of an MFMA step is k = 32 c + 2 t + lh; its swizzled column is
+            // 32 c + ((2 t) ^ (lh ^ f(row))), so for a fixed t the NC = KD / 32 reads of a lane differ by the immediate
+            // offset 32 c only: one xor + one add of address arithmetic per t instead of three VALU per read (an fp32 MFMA
+            // and VALU work of the same SIMD do not overlap, so every VALU in this loop is MFMA time lost).  t is the
+            // rolled, software-pipelined loop (reads of t + 1 are issued before the MFMAs of t); c is unrolled.
+            constexpr int NC = KD / 32;
+            const float *arow[MT];
+            int ga[MT];
 #pragma unroll
-                for (int u = 0; u < SB; ++u) {
+            for (int i = 0; i < MT; ++i) {
+                const int r = wm * TM + i * 32 + l31;
+                arow[i] = As + r * KP;
+                ga[i] = lh ^ a_swz(r);
+            }
+            float ra[2][NC][MT], rb[2][NC][NT];
+            auto ld = [&](int buf, int t) {
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) ra[buf][u][i] = As[a_idx(wm * TM + i * 32 + l31, 2 * (s0 + u) + lh)];
+                for (int i = 0; i < MT; ++i) {
+                    const float *pa = arow[i] + ((2 * t) ^ ga[i]);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) rb[buf][u][j] = bp[2 * (s0 + u) * BN + j * 32];
+                    for (int c = 0; c < NC; ++c) ra[buf][c][i] = pa[32 * c];
                 }
+                const float *pb = bp + 2 * t * BN;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) rb[buf][c][j] = pb[32 * c * BN + j * 32];
             };
             auto mm = [&](int buf) {
 #pragma unroll
-                for (int u = 0; u < SB; ++u)
+                for (int c = 0; c < NC; ++c)
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][u][i], rb[buf][u][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][c][i], rb[buf][c][j], acc[i][j], 0, 0, 0);
             };
             ld(0, 0);
 #pragma unroll 1
-            for (int blk = 0; blk + 1 < NBLK; blk += 2) {  // rolled: a fully unrolled loop lets the scheduler hoist reads until it spills
-                ld(1, (blk + 1) * SB);
+            for (int t = 0; t < 16; t += 2) {
+                ld(1, t + 1);
                 mm(0);
-                if (blk + 2 < NBLK) ld(0, (blk + 2) * SB);
+                if (t + 2 < 16) ld(0, t + 2);
                 mm(1);
             }
-            if constexpr (NBLK % 2 == 1) mm(0);
+        } else {
+            {
+                // K loop, software-pipelined by hand: the LDS operand reads of block b+1 (SB k-steps) are issued before
+                // the MFMAs of block b, so an MFMA never waits for a read issued right in front of it
+                constexpr int SB = (KD / 2) % 4 == 0 ? 4 : 2, NBLK = (KD / 2) / SB;
+                float ra[2][SB][MT], rb[2][SB][NT];
+                auto ld = [&](int buf, int s0) {
+    #pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+    #pragma unroll
+                        for (int i = 0; i < MT; ++i) ra[buf][u][i] = As[a_idx(wm * TM + i * 32 + l31, 2 * (s0 + u) + lh)];
+    #pragma unroll
+                        for (int j = 0; j < NT; ++j) rb[buf][u][j] = bp[2 * (s0 + u) * BN + j * 32];
+                    }
+                };
+                auto mm = [&](int buf) {
+    #pragma unroll
+                    for (int u = 0; u < SB; ++u)
+    #pragma unroll
+                        for (int i = 0; i < MT; ++i)
+    #pragma unroll
+                            for (int j = 0; j < NT; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][u][i], rb[buf][u][j], acc[i][j], 0, 0, 0);
+                };
+                ld(0, 0);
+    #pragma unroll 1
+                for (int blk = 0; blk + 1 < NBLK; blk += 2) {  // rolled: a fully unrolled loop lets the scheduler hoist reads until it spills
+                    ld(1, (blk + 1) * SB);
+                    mm(0);
+                    if (blk + 2 < NBLK) ld(0, (blk + 2) * SB);
+                    mm(1);
+                }
+                if constexpr (NBLK % 2 == 1) mm(0);
+            }
         }
 
         // epilogue: each accumulator register is one row; a half-wave writes 32 consecutive floats (128 B)
@@ -810,27 +858,32 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
                 const int tile_id = wave + 4 * t, ct = tile_id / (BN / 32), kt = tile_id % (BN / 32);
-                constexpr int SB = 4, NBLK = (BM / 2) / SB;
-                float da[2][SB], db[2][SB];
-                auto ld = [&](int buf, int s0) {
+                // dW tile (ct, kt) += dZ^T (columns ct*32.. of the A tile) x activation tile.  The reduction index is the tile
+                // row m = 32 c + 2 t + lh; f(m) = f(2 t) | (lh << 2) (the swizzle only looks at m mod 32), so the swizzled
+                // column is ((ct*32 + l31) ^ (lh << 2)) ^ F(t) with F(t) uniform: scalar work plus one xor per t, and the
+                // BM / 32 reads of a t differ by immediate offsets only.
+                constexpr int MC = BM / 32;
+                const int colx = (ct * 32 + l31) ^ (lh << 2);
+                const float *abase = As + lh * KP, *bbase = Ap + lh * BN + kt * 32 + l31;
+                float da[2][MC], db[2][MC];
+                auto ld = [&](int buf, int t) {
+                    const int F = ((t & 3) << 3) | ((t >> 2) & 3);
+                    const float *pa = abase + 2 * t * KP + (colx ^ F), *pb = bbase + 2 * t * BN;
 #pragma unroll
-                    for (int u = 0; u < SB; ++u) {
-                        const int m = 2 * (s0 + u) + lh;
-                        da[buf][u] = As[a_idx(m, ct * 32 + l31)];
-                        db[buf][u] = Ap[m * BN + kt * 32 + l31];
+                    for (int c = 0; c < MC; ++c) {
+                        da[buf][c] = pa[32 * c * KP];
+                        db[buf][c] = pb[32 * c * BN];
                     }
                 };
                 ld(0, 0);
 #pragma unroll 1
-                for (int blk = 0; blk < NBLK; blk += 2) {
-                    ld(1, (blk + 1) * SB);
+                for (int t2 = 0; t2 < 16; t2 += 2) {
+                    ld(1, t2 + 1);
 #pragma unroll
-                    for (int u = 0; u < SB; ++u)
-                        dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[0][u], db[0][u], dwacc[t], 0, 0, 0);
-                    if (blk + 2 < NBLK) ld(0, (blk + 2) * SB);
+                    for (int c = 0; c < MC; ++c) dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[0][c], db[0][c], dwacc[t], 0, 0, 0);
+                    if (t2 + 2 < 16) ld(0, t2 + 2);
 #pragma unroll
-                    for (int u = 0; u < SB; ++u)
-                        dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[1][u], db[1][u], dwacc[t], 0, 0, 0);
+                    for (int c = 0; c < MC; ++c) dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[1][c], db[1][c], dwacc[t], 0, 0, 0);
                 }
             }
         }
