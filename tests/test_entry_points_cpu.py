@@ -124,3 +124,22 @@ def test_results_txt_format(tmp_path):
     assert lines[2] == "Test KL: 0.077724" and lines[4] == "-- Per-Category (last epoch) --"
     assert lines[5] == "[TOTAL] Train=0.084364 Val=0.083457" and lines[6] == "[bathtub] Train=0.710000 Val=0.770000"
     assert lines[7] == "[empty] Train=nan Val=nan"
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The bench line committed under profiles/ (the one the roofline table in DESIGN.md quotes) carries every field of
+    the driver's contract, the roofline and cpu_baseline objects included."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "round1_final_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "clouds/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] is not None
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert abs(d["value"] - d["n_gpus"] * d["config"]["per_gpu_batch"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
