@@ -1531,6 +1531,184 @@ int launch_dw_xyz(const AOperand &dz, int C, const AOperand &a2, int M, float *s
     return PNPP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Layer 0 of a grouped set abstraction with input features ("convolve, then gather").  The 1x1 convolution is linear,
+// so for row (group s, neighbour k) with source point j = idx[s][k]
+//     z = W_xyz (x_j - c_s) + W_f f_j  =  P[j] + W_xyz (x_j - c_s),      P = F W_f^T   (one row per SOURCE point)
+// P costs B*N rows of GEMM instead of B*S*K (8x fewer for SA2); the relative-coordinate term keeps the reference's
+// float32 subtraction (pointnet_pp_8dir.py:28-31) and is three FMAs per output.  This kernel builds Z (row-major,
+// pre-BN, no bias: BatchNorm cancels it) and the per-channel sum / sum of squares partials of the BN statistics.
+// Thread = 4 channels of one row; a workgroup walks `rpb` consecutive rows, 256 / (C/4) at a time.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+gather_rel_stats_kernel(const float *__restrict__ P, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                        const int32_t *__restrict__ idx, const float *__restrict__ W0, int ldw, int N, int S, int K, int M,
+                        int C, int rpb, float *__restrict__ z, double *__restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) double gred[];  // [RPP][2][C]
+    const int LPR = C >> 2, RPP = 256 / LPR;
+    const int cl = threadIdx.x % LPR, rl = threadIdx.x / LPR, c4 = cl * 4;
+    float wx[4], wy[4], wz[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float *w = W0 + (size_t)(c4 + e) * ldw;
+        wx[e] = w[0], wy[e] = w[1], wz[e] = w[2];
+    }
+    const int r0 = blockIdx.x * rpb, r1 = min(M, r0 + rpb);
+    double d1[4] = {0.0, 0.0, 0.0, 0.0}, d2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int rb = r0 + rl; rb < r1; rb += 4 * RPP) {
+        float4 p[4];
+        float rx[4], ry[4], rz[4], ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // four rows in flight per thread
+            const int r = rb + u * RPP;
+            const int rc = min(r, r1 - 1);
+            ok[u] = r < r1 ? 1.f : 0.f;
+            const int grp = rc / K;
+            const size_t src = (size_t)(grp / S) * N + idx[rc];
+            p[u] = *reinterpret_cast<const float4 *>(P + src * C + c4);
+            const float *x = xyz + src * 3, *c = new_xyz + (size_t)grp * 3;
+            rx[u] = __fsub_rn(x[0], c[0]), ry[u] = __fsub_rn(x[1], c[1]), rz[u] = __fsub_rn(x[2], c[2]);
+        }
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v[4] = {p[u].x, p[u].y, p[u].z, p[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = fmaf(rz[u], wz[e], fmaf(ry[u], wy[e], fmaf(rx[u], wx[e], v[e])));
+                const float m = v[e] * ok[u];
+                s1[e] += m, s2[e] = fmaf(m, m, s2[e]);
+            }
+            const int r = rb + u * RPP;
+            if (r < r1) *reinterpret_cast<float4 *>(z + (size_t)r * C + c4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d1[e] += (double)s1[e], d2[e] += (double)s2[e];
+    }
+    if (slab == nullptr) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        gred[(rl * 2 + 0) * C + c4 + e] = d1[e];
+        gred[(rl * 2 + 1) * C + c4 + e] = d2[e];
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < 2 * C; f += 256) {
+        const int which = f / C, c = f - which * C;
+        double t = 0.0;
+        for (int w = 0; w < RPP; ++w) t += gred[(w * 2 + which) * C + c];
+        slab[((size_t)blockIdx.x * 2 + which) * C + c] = t;
+    }
+}
+
+bool delayed_layer0_ok(int C) {  // C/4 lanes per row must divide the 256-thread workgroup; the scatter holds C <= 512
+    return C >= 32 && C <= 512 && (C & (C - 1)) == 0;
+}
+
+int launch_gather_rel_stats(const float *P, const AOperand &geo, const float *W0, int ldw, int M, int C, float *z,
+                            double *slab, int *nslab, hipStream_t st) {
+    PNPP_REQUIRE(delayed_layer0_ok(C) && geo.mode == A_GATHER, PNPP_ERR_ARG, "gather_rel_stats: unsupported width %d", C);
+    const int rpp = 256 / (C / 4);
+    int rpb = 64;  // rows per workgroup: a multiple of the 4 * rpp rows in flight, at most kMaxStatBlocks workgroups
+    while (rpb < 4 * rpp || cdiv(M, rpb) > kMaxStatBlocks) rpb *= 2;
+    const int grid = cdiv(M, rpb);
+    if (nslab) *nslab = grid;
+    ProfScope ps(st, "gather_rel_stats_kernel M=%d C=%d grid=%d", M, C, grid);
+    hipLaunchKernelGGL(gather_rel_stats_kernel, dim3(grid), dim3(256), (size_t)rpp * 2 * C * sizeof(double), st, P, geo.xyz,
+                       geo.new_xyz, geo.idx, W0, ldw, geo.N, geo.S, geo.K, M, C, rpb, z, slab);
+    PNPP_CHECK_LAUNCH("gather_rel_stats");
+    return PNPP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the same layer: the gradient reaches the feature weights and the source features only through
+//     G[j] = sum over the rows r of the cloud with idx[r] == j of dZ[r]            (one row per SOURCE point)
+// (dW_f = G^T F and dF = G W_f are then B*N-row GEMMs).  One wavefront per source point scans its cloud's neighbour
+// lists in order, 256 entries per step, and adds the matching rows in list order: a fixed summation order, no atomics.
+// dZ is rebuilt on the fly from the masked upstream gradient and Z (A_DZ), two coalesced row reads per hit, issued
+// four hits at a time.  Lane = 2 channels of each 128-channel chunk.
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ void __launch_bounds__(256)
+scatter_dz_kernel(const AOperand dz, const int32_t *__restrict__ idx, int N, int Mc, int C, int total, float *__restrict__ G) {
+    const int lane = threadIdx.x & 63;
+    const int dst = blockIdx.x * 4 + (threadIdx.x >> 6);  // b * N + n
+    if (dst >= total) return;
+    const int b = dst / N, n = dst - b * N;
+    const int32_t *ib = idx + (size_t)b * Mc;
+    const size_t row0 = (size_t)b * Mc;
+    float2 cg[NCH], cmu[NCH], cis[NCH], c1[NCH], c2[NCH], acc[NCH];
+    int cc[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        cc[j] = min(j * 128 + 2 * lane, C - 2);
+        cg[j] = make_float2(1.f, 1.f);
+        cmu[j] = cis[j] = c1[j] = c2[j] = acc[j] = make_float2(0.f, 0.f);
+        if (dz.mode == A_DZ) {
+            const float *p = dz.cst + cc[j];
+            cg[j] = *reinterpret_cast<const float2 *>(p), cmu[j] = *reinterpret_cast<const float2 *>(p + dz.C);
+            cis[j] = *reinterpret_cast<const float2 *>(p + 2 * dz.C), c1[j] = *reinterpret_cast<const float2 *>(p + 3 * dz.C);
+            c2[j] = *reinterpret_cast<const float2 *>(p + 4 * dz.C);
+        }
+    }
+    const float *zsrc = dz.mode == A_DZ ? dz.z : dz.a;  // a materialised dZ (small levels) passes through: g = 1, c1 = c2 = 0
+    for (int m0 = 0; m0 < Mc; m0 += 256) {
+        unsigned long long hit[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m0 + q * 64 + lane;
+            hit[q] = __ballot(m < Mc && ib[min(m, Mc - 1)] == n);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned long long h = hit[q];
+            while (h) {  // wave-uniform
+                int pos[4];
+                float mk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = h ? __ffsll((long long)h) - 1 : -1;
+                    mk[u] = f >= 0 ? 1.f : 0.f;
+                    pos[u] = m0 + q * 64 + max(f, 0);
+                    h = h ? (h & (h - 1)) : 0ull;
+                }
+                float2 gy[4][NCH], gz[4][NCH];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) {
+                        const size_t o = (row0 + pos[u]) * dz.lda + cc[j];
+                        gy[u][j] = *reinterpret_cast<const float2 *>(dz.a + o);
+                        gz[u][j] = *reinterpret_cast<const float2 *>(zsrc + o);
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) {
+                        const float vx = cg[j].x * (gy[u][j].x - c1[j].x - (gz[u][j].x - cmu[j].x) * cis[j].x * c2[j].x);
+                        const float vy = cg[j].y * (gy[u][j].y - c1[j].y - (gz[u][j].y - cmu[j].y) * cis[j].y * c2[j].y);
+                        acc[j].x = fmaf(vx, mk[u], acc[j].x), acc[j].y = fmaf(vy, mk[u], acc[j].y);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+        if (j * 128 + 2 * lane < C) *reinterpret_cast<float2 *>(G + (size_t)dst * C + j * 128 + 2 * lane) = acc[j];
+}
+
+int launch_scatter_dz(const AOperand &dz, const int32_t *idx, int B, int N, int Mc, int C, float *G, hipStream_t st) {
+    PNPP_REQUIRE((dz.mode == A_PLAIN || (dz.mode == A_DZ && dz.C == C)) && dz.lda == C && delayed_layer0_ok(C), PNPP_ERR_ARG,
+                 "scatter_dz: bad operand");
+    const int total = B * N;
+    ProfScope ps(st, "scatter_dz_kernel B=%d N=%d C=%d M=%d", B, N, C, Mc);
+    const dim3 grid(cdiv(total, 4));
+    if (C <= 128) hipLaunchKernelGGL(scatter_dz_kernel<1>, grid, dim3(256), 0, st, dz, idx, N, Mc, C, total, G);
+    else if (C <= 256) hipLaunchKernelGGL(scatter_dz_kernel<2>, grid, dim3(256), 0, st, dz, idx, N, Mc, C, total, G);
+    else hipLaunchKernelGGL(scatter_dz_kernel<4>, grid, dim3(256), 0, st, dz, idx, N, Mc, C, total, G);
+    PNPP_CHECK_LAUNCH("scatter_dz");
+    return PNPP_OK;
+}
+
 void dw_plan(int M, int Nc, int Kp, int *nsplit, int *kp_pad) {
     const int tilesC = cdiv(Nc, 64), tilesK = cdiv(Kp, 64);
     const int tiles = tilesC * tilesK;

@@ -104,6 +104,11 @@ int launch_dz_materialize(const AOperand &dz, int M, int C, float *out, hipStrea
 // picks the split count / padded pitch launch_dw will use (so callers can size the slab)
 void dw_plan(int M, int Nc, int Kp, int *nsplit, int *kp_pad);
 // xyz-only layer 0 (second operand A_GATHER with D == 0): streaming kernel, one [Nc][4] partial per 256 rows
+// layer 0 of a grouped level with features, convolved before the gather (see gemm_kernels.hip)
+bool delayed_layer0_ok(int C);
+int launch_gather_rel_stats(const float *P, const AOperand &geo, const float *W0, int ldw, int M, int C, float *z,
+                            double *slab, int *nslab, hipStream_t st);
+int launch_scatter_dz(const AOperand &dz, const int32_t *idx, int B, int N, int Mc, int C, float *G, hipStream_t st);
 int dw_xyz_splits(int M);
 int launch_dw_xyz(const AOperand &dz, int Nc, const AOperand &a2, int M, float *slab, hipStream_t st);
 // out[c][perm(k)] = sum_s slab[s][c][k]; perm_D < 0: identity; else feature-first -> xyz-first column order.

@@ -122,8 +122,14 @@ struct SaScratch {
     float *dm;
     float *cst;
     float *dwslab;
+    float *src;  // convolve-then-gather layer 0: one C_0-wide row per source point (P forward, G backward)
     size_t bytes;
 };
+
+// layer 0 is convolved on the B*N source points and gathered afterwards when the level groups points WITH features
+static bool sa_delayed(const pnpp_sa_desc *d) {
+    return !d->group_all && d->D > 0 && d->D % 4 == 0 && delayed_layer0_ok(d->C[0]) && d->S * d->K > d->N;
+}
 
 static SaScratch sa_scratch_layout(const pnpp_sa_desc *d, const SaGeom &g, void *base) {
     Carver cv(base);
@@ -145,7 +151,15 @@ static SaScratch sa_scratch_layout(const pnpp_sa_desc *d, const SaGeom &g, void 
         need = fused > need ? fused : need;
         dwmax = need > dwmax ? need : dwmax;
     }
+    if (sa_delayed(d)) {  // the per-source-point dW_f partials and the streaming dW_xyz partials share the slab
+        int nsplit, kp_pad;
+        dw_plan(d->B * d->N, d->C[0], d->D, &nsplit, &kp_pad);
+        const size_t a = (size_t)nsplit * d->C[0] * kp_pad, b = (size_t)dw_xyz_splits(g.M) * d->C[0] * 4;
+        dwmax = a > dwmax ? a : dwmax;
+        dwmax = b > dwmax ? b : dwmax;
+    }
     s.dwslab = cv.take<float>(dwmax);
+    s.src = cv.take<float>(sa_delayed(d) ? (size_t)d->B * d->N * d->C[0] : 0);
     s.bytes = cv.bytes();
     return s;
 }
@@ -212,7 +226,27 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
         W.perm_D = l == 0 ? d->D : -1;
         W.rows = g.Cin[l];
         int nslab = 0;
-        if (d->training) {
+        if (l == 0 && sa_delayed(d)) {  // P = F W_f^T on the source points, then Z = P[idx] + W_xyz (x - c) with statistics
+            AOperand F;
+            F.a = a->points;
+            F.lda = d->D;
+            BOperand Wf;
+            Wf.b = a->conv_w[0] + 3;
+            Wf.ldb = g.Cin[0];
+            Wf.trans = 1;
+            Wf.rows = d->D;
+            Epilogue Ep;
+            Ep.mode = E_STORE;
+            Ep.c = sc.src;
+            Ep.ldc = d->C[0];
+            PNPP_TRY(launch_gemm(F, Wf, d->B * d->N, d->C[0], d->D, Ep, nullptr, st));
+            PNPP_TRY(launch_gather_rel_stats(sc.src, A, a->conv_w[0], g.Cin[0], g.M, d->C[0], sv.z[0],
+                                             d->training ? sc.slab : nullptr, &nslab, st));
+            PNPP_TRY(launch_bn_finalize_fwd(d->training ? sc.slab : nullptr, d->training ? nslab : 0, d->C[0], (double)g.M, a->conv_b[0],
+                                            a->bn_w[0], a->bn_b[0], a->bn_rm[0], a->bn_rv[0],
+                                            d->training ? (long long *)a->bn_nbt[0] : nullptr, d->momentum, d->eps, d->training ? 1 : 0,
+                                            sv.mean[0], sv.istd[0], sv.scale[0], sv.shift[0], st));
+        } else if (d->training) {
             E.mode = E_STORE_STATS;
             E.slab = sc.slab;
             PNPP_TRY(launch_gemm(A, W, g.M, d->C[l], g.Kd[l], E, &nslab, st));
@@ -310,6 +344,35 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             fused_slabs = dw_slabs;
         }
         const bool xyz_only = l == 0 && a2.mode == A_GATHER && d->D == 0 && dw_xyz_splits(g.M) <= nsplit * (kp_pad / 4);
+        if (l == 0 && sa_delayed(d)) {
+            // G = dZ_0 summed per source point; dW_f = G^T F, dW_xyz = dZ_0^T (x - c) (streaming), dF = G W_f
+            const int R = d->B * d->N;
+            PNPP_TRY(launch_scatter_dz(dz, sv.idx, d->B, d->N, d->S * d->K, C, sc.src, st));
+            AOperand rel = a2;
+            rel.D = 0;
+            PNPP_TRY(launch_dw_xyz(dz, C, rel, g.M, sc.dwslab, st));
+            PNPP_TRY(launch_slab_reduce(sc.dwslab, dw_xyz_splits(g.M), C, 4, 3, -1, a->d_conv_w[0], g.Cin[0], st));
+            AOperand G, F;
+            G.a = sc.src;
+            G.lda = C;
+            F.a = a->points;
+            F.lda = d->D;
+            dw_plan(R, C, d->D, &nsplit, &kp_pad);
+            PNPP_TRY(launch_dw(G, C, F, d->D, R, sc.dwslab, nsplit, kp_pad, st));
+            PNPP_TRY(launch_slab_reduce(sc.dwslab, nsplit, C, kp_pad, d->D, -1, a->d_conv_w[0] + 3, g.Cin[0], st));
+            if (want_dpoints) {
+                Epilogue E;
+                E.mode = E_STORE;
+                E.c = a->dpoints;
+                E.ldc = d->D;
+                BOperand W;
+                W.b = a->conv_w[0] + 3;
+                W.ldb = g.Cin[0];
+                W.rows = C;
+                PNPP_TRY(launch_gemm(G, W, R, d->D, C, E, nullptr, st));
+            }
+            break;
+        }
         if (xyz_only) {  // C x 3 gradient: streaming kernel (the MFMA tiles would be 95 % padding)
             PNPP_TRY(launch_dw_xyz(dz, C, a2, g.M, sc.dwslab, st));
             nsplit = dw_xyz_splits(g.M), kp_pad = 4;
