@@ -1623,26 +1623,36 @@ int launch_gather_rel_stats(const float *P, const AOperand &geo, const float *W0
 // Backward of the same layer: the gradient reaches the feature weights and the source features only through
 //     G[j] = sum over the rows r of the cloud with idx[r] == j of dZ[r]            (one row per SOURCE point)
 // (dW_f = G^T F and dF = G W_f are then B*N-row GEMMs).  One wavefront per source point scans its cloud's neighbour
-// lists in order, 256 entries per step, and adds the matching rows in list order: a fixed summation order, no atomics.
-// dZ is rebuilt on the fly from the masked upstream gradient and Z (A_DZ), two coalesced row reads per hit, issued
-// four hits at a time.  Lane = 2 channels of each 128-channel chunk.
+// lists in order, 1024 entries per pass, compacts the matching rows into a list (ballot + prefix count, so list order
+// is row order) and adds them in that order: a fixed summation order, no atomics.  dZ is rebuilt on the fly from the
+// masked upstream gradient and Z (A_DZ): two coalesced row reads per match, up to eight matches in flight.  Lane = 2 channels of each 128-channel chunk.  The same pass accumulates the C x 3 gradient of
+// the coordinate columns, dW_xyz = sum_r dZ[r] (x_j - c_s)^T, as one [C][4] partial per workgroup (slab_reduce layout).
 // ---------------------------------------------------------------------------------------------
+constexpr int SCW = 8;       // wavefronts (= source points) per workgroup
+constexpr int SCWIN = 1024;  // neighbour-list entries examined per pass
 template <int NCH>
-__global__ void __launch_bounds__(256)
-scatter_dz_kernel(const AOperand dz, const int32_t *__restrict__ idx, int N, int Mc, int C, int total, float *__restrict__ G) {
-    const int lane = threadIdx.x & 63;
-    const int dst = blockIdx.x * 4 + (threadIdx.x >> 6);  // b * N + n
-    if (dst >= total) return;
+__global__ void __launch_bounds__(SCW * 64)
+scatter_dz_kernel(const AOperand dz, const AOperand geo, int Mc, int C, int total, float *__restrict__ G,
+                  float *__restrict__ wslab) {
+    constexpr int UB = NCH == 1 ? 8 : 4;  // matching rows fetched per batch
+    __shared__ int hl[SCW][SCWIN];
+    __shared__ float wred[SCW][NCH * 128][3];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int N = geo.N;
+    const int dst = min(blockIdx.x * SCW + wv, total - 1);  // b * N + n; a surplus wave repeats the last point, writes nothing
+    const bool live = blockIdx.x * SCW + wv < total;
     const int b = dst / N, n = dst - b * N;
-    const int32_t *ib = idx + (size_t)b * Mc;
+    const int32_t *ib = geo.idx + (size_t)b * Mc;
     const size_t row0 = (size_t)b * Mc;
-    float2 cg[NCH], cmu[NCH], cis[NCH], c1[NCH], c2[NCH], acc[NCH];
+    const float px = geo.xyz[(size_t)dst * 3], py = geo.xyz[(size_t)dst * 3 + 1], pz = geo.xyz[(size_t)dst * 3 + 2];
+    const float *cb = geo.new_xyz + (size_t)b * geo.S * 3;
+    float2 cg[NCH], cmu[NCH], cis[NCH], c1[NCH], c2[NCH], acc[NCH], ax[NCH], ay[NCH], az[NCH];
     int cc[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         cc[j] = min(j * 128 + 2 * lane, C - 2);
         cg[j] = make_float2(1.f, 1.f);
-        cmu[j] = cis[j] = c1[j] = c2[j] = acc[j] = make_float2(0.f, 0.f);
+        cmu[j] = cis[j] = c1[j] = c2[j] = acc[j] = ax[j] = ay[j] = az[j] = make_float2(0.f, 0.f);
         if (dz.mode == A_DZ) {
             const float *p = dz.cst + cc[j];
             cg[j] = *reinterpret_cast<const float2 *>(p), cmu[j] = *reinterpret_cast<const float2 *>(p + dz.C);
@@ -1651,60 +1661,85 @@ scatter_dz_kernel(const AOperand dz, const int32_t *__restrict__ idx, int N, int
         }
     }
     const float *zsrc = dz.mode == A_DZ ? dz.z : dz.a;  // a materialised dZ (small levels) passes through: g = 1, c1 = c2 = 0
-    for (int m0 = 0; m0 < Mc; m0 += 256) {
-        unsigned long long hit[4];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int w0 = 0; w0 < Mc; w0 += SCWIN) {  // uniform over the workgroup
+        // 1. the rows of this window that point at n, in row order, as a list in LDS
+        int v[SCWIN / 64];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int m = m0 + q * 64 + lane;
-            hit[q] = __ballot(m < Mc && ib[min(m, Mc - 1)] == n);
+        for (int q = 0; q < SCWIN / 64; ++q) v[q] = ib[min(w0 + q * 64 + lane, Mc - 1)];
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < SCWIN / 64; ++q) {
+            const int m = w0 + q * 64 + lane;
+            const bool mine = live && m < Mc && v[q] == n;
+            const unsigned long long bal = __ballot(mine);
+            if (mine) hl[wv][cnt + __popcll(bal & below)] = m;
+            cnt += __popcll(bal);
         }
+        __syncthreads();
+        // 2. their dZ rows, UB at a time, added in list order
+        for (int i = 0; i < cnt; i += UB) {  // cnt is wave-uniform
+            int pos[UB];
+            float mk[UB], rx[UB], ry[UB], rz[UB];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned long long h = hit[q];
-            while (h) {  // wave-uniform
-                int pos[4];
-                float mk[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int f = h ? __ffsll((long long)h) - 1 : -1;
-                    mk[u] = f >= 0 ? 1.f : 0.f;
-                    pos[u] = m0 + q * 64 + max(f, 0);
-                    h = h ? (h & (h - 1)) : 0ull;
-                }
-                float2 gy[4][NCH], gz[4][NCH];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int j = 0; j < NCH; ++j) {
-                        const size_t o = (row0 + pos[u]) * dz.lda + cc[j];
-                        gy[u][j] = *reinterpret_cast<const float2 *>(dz.a + o);
-                        gz[u][j] = *reinterpret_cast<const float2 *>(zsrc + o);
-                    }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int j = 0; j < NCH; ++j) {
-                        const float vx = cg[j].x * (gy[u][j].x - c1[j].x - (gz[u][j].x - cmu[j].x) * cis[j].x * c2[j].x);
-                        const float vy = cg[j].y * (gy[u][j].y - c1[j].y - (gz[u][j].y - cmu[j].y) * cis[j].y * c2[j].y);
-                        acc[j].x = fmaf(vx, mk[u], acc[j].x), acc[j].y = fmaf(vy, mk[u], acc[j].y);
-                    }
+            for (int u = 0; u < UB; ++u) {
+                mk[u] = i + u < cnt ? 1.f : 0.f;
+                pos[u] = hl[wv][min(i + u, cnt - 1)];
+                const float *c = cb + (size_t)(pos[u] / geo.K) * 3;  // the forward's float32 subtraction
+                rx[u] = __fsub_rn(px, c[0]) * mk[u], ry[u] = __fsub_rn(py, c[1]) * mk[u], rz[u] = __fsub_rn(pz, c[2]) * mk[u];
             }
+            float2 gy[UB][NCH], gz[UB][NCH];
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    const size_t o = (row0 + pos[u]) * dz.lda + cc[j];
+                    gy[u][j] = *reinterpret_cast<const float2 *>(dz.a + o);
+                    gz[u][j] = *reinterpret_cast<const float2 *>(zsrc + o);
+                }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    const float vx = cg[j].x * (gy[u][j].x - c1[j].x - (gz[u][j].x - cmu[j].x) * cis[j].x * c2[j].x);
+                    const float vy = cg[j].y * (gy[u][j].y - c1[j].y - (gz[u][j].y - cmu[j].y) * cis[j].y * c2[j].y);
+                    acc[j].x = fmaf(vx, mk[u], acc[j].x), acc[j].y = fmaf(vy, mk[u], acc[j].y);
+                    ax[j].x = fmaf(vx, rx[u], ax[j].x), ax[j].y = fmaf(vy, rx[u], ax[j].y);
+                    ay[j].x = fmaf(vx, ry[u], ay[j].x), ay[j].y = fmaf(vy, ry[u], ay[j].y);
+                    az[j].x = fmaf(vx, rz[u], az[j].x), az[j].y = fmaf(vy, rz[u], az[j].y);
+                }
         }
+        __syncthreads();
     }
 #pragma unroll
-    for (int j = 0; j < NCH; ++j)
-        if (j * 128 + 2 * lane < C) *reinterpret_cast<float2 *>(G + (size_t)dst * C + j * 128 + 2 * lane) = acc[j];
+    for (int j = 0; j < NCH; ++j) {
+        const int c = j * 128 + 2 * lane;
+        if (live && c < C) *reinterpret_cast<float2 *>(G + (size_t)dst * C + c) = acc[j];
+        wred[wv][c][0] = ax[j].x, wred[wv][c][1] = ay[j].x, wred[wv][c][2] = az[j].x;
+        wred[wv][c + 1][0] = ax[j].y, wred[wv][c + 1][1] = ay[j].y, wred[wv][c + 1][2] = az[j].y;
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < C * 3; f += SCW * 64) {  // this workgroup's share of dW_xyz: [C][4] partial, waves in order
+        const int c = f / 3, k = f - 3 * c;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < SCW; ++w) t += wred[w][c][k];
+        wslab[((size_t)blockIdx.x * C + c) * 4 + k] = t;
+    }
 }
 
-int launch_scatter_dz(const AOperand &dz, const int32_t *idx, int B, int N, int Mc, int C, float *G, hipStream_t st) {
+int scatter_dz_splits(int rows) { return cdiv(rows, SCW); }
+
+int launch_scatter_dz(const AOperand &dz, const AOperand &geo, int B, int Mc, int C, float *G, float *wslab, hipStream_t st) {
     PNPP_REQUIRE((dz.mode == A_PLAIN || (dz.mode == A_DZ && dz.C == C)) && dz.lda == C && delayed_layer0_ok(C), PNPP_ERR_ARG,
                  "scatter_dz: bad operand");
-    const int total = B * N;
-    ProfScope ps(st, "scatter_dz_kernel B=%d N=%d C=%d M=%d", B, N, C, Mc);
-    const dim3 grid(cdiv(total, 4));
-    if (C <= 128) hipLaunchKernelGGL(scatter_dz_kernel<1>, grid, dim3(256), 0, st, dz, idx, N, Mc, C, total, G);
-    else if (C <= 256) hipLaunchKernelGGL(scatter_dz_kernel<2>, grid, dim3(256), 0, st, dz, idx, N, Mc, C, total, G);
-    else hipLaunchKernelGGL(scatter_dz_kernel<4>, grid, dim3(256), 0, st, dz, idx, N, Mc, C, total, G);
+    PNPP_REQUIRE(geo.mode == A_GATHER && geo.S * geo.K == Mc, PNPP_ERR_ARG, "scatter_dz: bad geometry");
+    const int total = B * geo.N;
+    ProfScope ps(st, "scatter_dz_kernel B=%d N=%d C=%d M=%d", B, geo.N, C, Mc);
+    const dim3 grid(scatter_dz_splits(total));
+    if (C <= 128) hipLaunchKernelGGL(scatter_dz_kernel<1>, grid, dim3(SCW * 64), 0, st, dz, geo, Mc, C, total, G, wslab);
+    else if (C <= 256) hipLaunchKernelGGL(scatter_dz_kernel<2>, grid, dim3(SCW * 64), 0, st, dz, geo, Mc, C, total, G, wslab);
+    else hipLaunchKernelGGL(scatter_dz_kernel<4>, grid, dim3(SCW * 64), 0, st, dz, geo, Mc, C, total, G, wslab);
     PNPP_CHECK_LAUNCH("scatter_dz");
     return PNPP_OK;
 }
@@ -1833,6 +1868,7 @@ __device__ __forceinline__ void slab_column_sums(const double *__restrict__ slab
     double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
     if (c < C) {
         int s = g;
+#pragma unroll 4  // 16 independent loads in flight per lane: the reduction is a chain of L2 round trips otherwise
         for (; s + 32 < nslab; s += 64) {
             a0 += slab[((size_t)s * 2 + 0) * C + c];
             b0 += slab[((size_t)s * 2 + 1) * C + c];

@@ -108,7 +108,8 @@ void dw_plan(int M, int Nc, int Kp, int *nsplit, int *kp_pad);
 bool delayed_layer0_ok(int C);
 int launch_gather_rel_stats(const float *P, const AOperand &geo, const float *W0, int ldw, int M, int C, float *z,
                             double *slab, int *nslab, hipStream_t st);
-int launch_scatter_dz(const AOperand &dz, const int32_t *idx, int B, int N, int Mc, int C, float *G, hipStream_t st);
+int scatter_dz_splits(int rows);  // number of [C][4] dW_xyz partials launch_scatter_dz writes for `rows` source points
+int launch_scatter_dz(const AOperand &dz, const AOperand &geo, int B, int Mc, int C, float *G, float *wslab, hipStream_t st);
 int dw_xyz_splits(int M);
 int launch_dw_xyz(const AOperand &dz, int Nc, const AOperand &a2, int M, float *slab, hipStream_t st);
 // out[c][perm(k)] = sum_s slab[s][c][k]; perm_D < 0: identity; else feature-first -> xyz-first column order.

@@ -154,7 +154,7 @@ static SaScratch sa_scratch_layout(const pnpp_sa_desc *d, const SaGeom &g, void 
     if (sa_delayed(d)) {  // the per-source-point dW_f partials and the streaming dW_xyz partials share the slab
         int nsplit, kp_pad;
         dw_plan(d->B * d->N, d->C[0], d->D, &nsplit, &kp_pad);
-        const size_t a = (size_t)nsplit * d->C[0] * kp_pad, b = (size_t)dw_xyz_splits(g.M) * d->C[0] * 4;
+        const size_t a = (size_t)nsplit * d->C[0] * kp_pad, b = (size_t)scatter_dz_splits(d->B * d->N) * d->C[0] * 4;
         dwmax = a > dwmax ? a : dwmax;
         dwmax = b > dwmax ? b : dwmax;
     }
@@ -345,13 +345,10 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
         }
         const bool xyz_only = l == 0 && a2.mode == A_GATHER && d->D == 0 && dw_xyz_splits(g.M) <= nsplit * (kp_pad / 4);
         if (l == 0 && sa_delayed(d)) {
-            // G = dZ_0 summed per source point; dW_f = G^T F, dW_xyz = dZ_0^T (x - c) (streaming), dF = G W_f
+            // G = dZ_0 summed per source point (dW_xyz = dZ_0^T (x - c) in the same pass); dW_f = G^T F, dF = G W_f
             const int R = d->B * d->N;
-            PNPP_TRY(launch_scatter_dz(dz, sv.idx, d->B, d->N, d->S * d->K, C, sc.src, st));
-            AOperand rel = a2;
-            rel.D = 0;
-            PNPP_TRY(launch_dw_xyz(dz, C, rel, g.M, sc.dwslab, st));
-            PNPP_TRY(launch_slab_reduce(sc.dwslab, dw_xyz_splits(g.M), C, 4, 3, -1, a->d_conv_w[0], g.Cin[0], st));
+            PNPP_TRY(launch_scatter_dz(dz, a2, d->B, d->S * d->K, C, sc.src, sc.dwslab, st));
+            PNPP_TRY(launch_slab_reduce(sc.dwslab, scatter_dz_splits(R), C, 4, 3, -1, a->d_conv_w[0], g.Cin[0], st));
             AOperand G, F;
             G.a = sc.src;
             G.lda = C;
