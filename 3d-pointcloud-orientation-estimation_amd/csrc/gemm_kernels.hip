@@ -1035,16 +1035,17 @@ static bool try_launch_ws(const AOperand &A, const BOperand &B, int M, int Nout,
 // operand), B (weights, [k][n] row-major) is read straight into the MFMA operand layout (the lane
 // index is n: one 128-byte segment per half-wave).  Next chunk's loads fly during the MFMA loop.
 // ---------------------------------------------------------------------------------------------
-template <int AMODE, int EMODE, bool BT>
-__global__ void __launch_bounds__(256)
+template <int AMODE, int EMODE, bool BT, int NW>
+__global__ void __launch_bounds__(NW * 64)
 gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, const Epilogue E) {
-    // per wave: A chunk [32][33] and weight chunk [32 n][33] (BT only); after the K loop the first 4 x 1024 floats
-    // are reused for the K-split partials [4][32][32] (a wave's partial overwrites only its own A chunk)
-    __shared__ __attribute__((aligned(16))) float lds[8 * 32 * APITCH];
+    // per wave: A chunk [32][33] and weight chunk [32 n][33] (BT only); after the K loop the first NW x 1024 floats
+    // are reused for the K-split partials [NW][32][32] (a wave's partial overwrites only its own A chunk)
+    constexpr int NTHR = NW * 64, NJ = 1024 / NTHR;
+    __shared__ __attribute__((aligned(16))) float lds[2 * NW * 32 * APITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     float *As = lds + wave * 32 * APITCH;
-    float *Ws = lds + (4 + wave) * 32 * APITCH;
-    float *part = lds;  // [4][32][32], wave w at part + w * 1056: inside its own A chunk region (32*33 = 1056 floats)
+    float *Ws = lds + (NW + wave) * 32 * APITCH;
+    float *part = lds;  // [NW][32][32], wave w at part + w * 1056: inside its own A chunk region (32*33 = 1056 floats)
     const float *__restrict__ Bm = B.b;
     const int ldb = B.ldb;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
@@ -1091,7 +1092,7 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
         }
     };
     if (wave < nchunks) fetch(wave);
-    for (int c = wave; c < nchunks; c += 4) {
+    for (int c = wave; c < nchunks; c += NW) {
         float cb[KC / 2];
         const int k0 = c * KC;
 #pragma unroll
@@ -1113,7 +1114,7 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
 #pragma unroll
             for (int s2 = 0; s2 < KC / 2; ++s2) cb[s2] = nb[s2];
         }
-        if (c + 4 < nchunks) fetch(c + 4);
+        if (c + NW < nchunks) fetch(c + NW);
 #pragma unroll
         for (int s2 = 0; s2 < KC / 2; ++s2) {
             const float bv = BT ? Ws[l31 * APITCH + 2 * s2 + lh] : cb[s2];
@@ -1124,17 +1125,21 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[wave * 32 * APITCH + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + l31] = acc[r];
     __syncthreads();
-    float v[4], w2[4];
+    float v[NJ], w2[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int e = tid + 256 * j;
-        v[j] = (part[e] + part[32 * APITCH + e]) + (part[2 * 32 * APITCH + e] + part[3 * 32 * APITCH + e]);
+    for (int j = 0; j < NJ; ++j) {
+        const int e = tid + NTHR * j;
+        v[j] = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 4)  // groups of four waves, in wave order
+            v[j] += (part[w * 32 * APITCH + e] + part[(w + 1) * 32 * APITCH + e]) +
+                    (part[(w + 2) * 32 * APITCH + e] + part[(w + 3) * 32 * APITCH + e]);
         w2[j] = 0.f;
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int e = tid + 256 * j, row = m0 + e / 32, col = n0 + e % 32;
+    for (int j = 0; j < NJ; ++j) {
+        const int e = tid + NTHR * j, row = m0 + e / 32, col = n0 + e % 32;
         const bool ok = row < M && col < Nout;
         float x = ok ? v[j] : 0.f;
         if constexpr (EMODE == E_MASK_STATS) {
@@ -1184,8 +1189,8 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
         if (T.nbt && blockIdx.x == 0 && tid == 0) *T.nbt += 1;
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = tid + 256 * j, row = m0 + e / 32, col = n0 + e % 32;
+        for (int j = 0; j < NJ; ++j) {
+            const int e = tid + NTHR * j, row = m0 + e / 32, col = n0 + e % 32;
             if (row < M && col < Nout) {
                 float y = fmaf(part[e], cs[e % 32], cs[32 + e % 32]);
                 if (T.relu) y = fmaxf(y, 0.f);
@@ -1238,8 +1243,17 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
 template <int AM, int EM>
 static void launch_smallm_t(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, dim3 grid,
                             hipStream_t st) {
-    if (B.trans) hipLaunchKernelGGL((gemm_smallm_kernel<AM, EM, true>), grid, dim3(256), 0, st, A, B, M, Nout, Kd, E);
-    else hipLaunchKernelGGL((gemm_smallm_kernel<AM, EM, false>), grid, dim3(256), 0, st, A, B, M, Nout, Kd, E);
+    if constexpr (AM == A_PLAIN) {
+        // one row of tiles (the head, M <= 32): few workgroups and a long reduction, so K is split over 16 waves -- two
+        // 32-deep chunks per wave at K = 1024 instead of eight dependent load round trips
+        if (grid.y == 1 && Kd >= 256) {
+            if (B.trans) hipLaunchKernelGGL((gemm_smallm_kernel<AM, EM, true, 16>), grid, dim3(1024), 0, st, A, B, M, Nout, Kd, E);
+            else hipLaunchKernelGGL((gemm_smallm_kernel<AM, EM, false, 16>), grid, dim3(1024), 0, st, A, B, M, Nout, Kd, E);
+            return;
+        }
+    }
+    if (B.trans) hipLaunchKernelGGL((gemm_smallm_kernel<AM, EM, true, 4>), grid, dim3(256), 0, st, A, B, M, Nout, Kd, E);
+    else hipLaunchKernelGGL((gemm_smallm_kernel<AM, EM, false, 4>), grid, dim3(256), 0, st, A, B, M, Nout, Kd, E);
 }
 template <int AM>
 static int launch_smallm_e(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, dim3 grid,
