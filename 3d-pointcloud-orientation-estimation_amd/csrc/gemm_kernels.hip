@@ -508,12 +508,14 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     constexpr int G4 = KMAIN / 4;                  // column groups per row
     constexpr int RPP = G4 > 0 ? 256 / (G4 > 0 ? G4 : 1) : 1;  // rows staged per pass
     constexpr int NG = G4 > 0 ? BM / RPP : 0;      // passes per tile
-    // A tile addressing: element (r, k) lives at r*KP + (k ^ f(r)), f(r) = ((r & 7) << 2) | ((r >> 3) & 3), when KD is a
-    // multiple of 32 (XOR swizzle, no padding).  f is a bijection of r mod 32 onto 0..31, so lane-per-row reads (fixed
-    // k, the dA operand) and lane-per-column reads (fixed r, the dW operand) are both conflict-free; its upper bits
-    // move whole 16-byte groups and its low two bits only permute inside a group, so a staged float4 is still ONE
-    // ds_write_b128 (of the permuted register quad).  Otherwise (KD = D + 4) element (r, k) is at r*(KD+1) + k.
-    constexpr bool SWZ = (KD % 32 == 0);
+    // A tile addressing: element (r, k) lives at r*KP + (k ^ f(r)), f(r) = (r & 15) << 2, when KD is a multiple of 64:
+    // an XOR swizzle of whole 16-byte groups, no padding.  The dA operand is read lane-per-row as ONE ds_read_b128 per
+    // four MFMA steps (the 16-lane groups of that instruction hold rows that are distinct mod 16, so they land on 16
+    // different groups of a 256-byte bank row); the dW operand is read lane-per-column with ds_read_b32 (fixed r: the
+    // XOR permutes an aligned block of 32 columns, 32 different banks); a staged float4 is one ds_write_b128 of the
+    // registers as loaded.  The weight tile uses the same image, [n][k ^ f(n)].  Otherwise (KD = D + 4) element
+    // (r, k) is at r*(KD+1) + k and the weights are [k][n].
+    constexpr bool SWZ = (KD % 64 == 0);
     constexpr int KP = SWZ ? KD : KD + 1;
     constexpr int GPT = (BM + 31) / 32;            // neighbour groups per tile when nsample == 32
     constexpr int DW_TILES = FDW ? (KD / 32) * (BN / 32) : 0, DT = FDW ? (DW_TILES + 3) / 4 : 1;
@@ -521,10 +523,10 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "tile configuration");
     static_assert(G4 == 0 || (256 % G4 == 0 && BM % RPP == 0 && (32 % RPP == 0 || RPP % 32 == 0)), "staging map");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *Ws = lds;            // [KD][BN]
+    float *Ws = lds;            // [KD][BN], or [BN][KD] swizzled (SWZ)
     float *As = lds + KD * BN;  // [BM][KP]
     float *Ap = As + BM * KP;   // FDW: [BM][BN] = relu(bn(zp)) tile, the dW GEMM's second operand
-    auto a_swz = [](int r) { return ((r & 7) << 2) | ((r >> 3) & 3); };
+    auto a_swz = [](int r) { return (r & 15) << 2; };
     auto a_idx = [&](int r, int k) { return r * KP + (SWZ ? (k ^ a_swz(r)) : k); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -554,7 +556,13 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[e] *= (kk < B.rows && n + e < Nout) ? 1.f : 0.f;
-                *reinterpret_cast<float4 *>(Ws + kk * BN + 4 * (f % (BN / 4))) = make_float4(t[0], t[1], t[2], t[3]);
+                if constexpr (SWZ) {  // transposed image: four scalar stores (once per workgroup)
+                    const int nl = 4 * (f % (BN / 4));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Ws[(nl + e) * KD + (kk ^ a_swz(nl + e))] = t[e];
+                } else {
+                    *reinterpret_cast<float4 *>(Ws + kk * BN + 4 * (f % (BN / 4))) = make_float4(t[0], t[1], t[2], t[3]);
+                }
             } else {
                 const int nl = f % BN, k4 = 4 * (f / BN), n = n0 + nl;
                 const float *src = Bm + (size_t)min(n, Nout - 1) * ldb;
@@ -571,7 +579,13 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Ws[(k4 + e) * BN + nl] = t[e] * ((n < Nout && k4 + e < B.rows) ? 1.f : 0.f);
+                for (int e = 0; e < 4; ++e) t[e] *= (n < Nout && k4 + e < B.rows) ? 1.f : 0.f;
+                if constexpr (SWZ) {
+                    *reinterpret_cast<float4 *>(Ws + nl * KD + (k4 ^ a_swz(nl))) = make_float4(t[0], t[1], t[2], t[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Ws[(k4 + e) * BN + nl] = t[e];
+                }
             }
         }
     }
@@ -687,16 +701,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                 }
             }
             if constexpr (SWZ) {
-                const int f = a_swz(r);
-                if (f & 1) {
-                    float t = v[0]; v[0] = v[1]; v[1] = t;
-                    t = v[2]; v[2] = v[3]; v[3] = t;
-                }
-                if (f & 2) {
-                    float t = v[0]; v[0] = v[2]; v[2] = t;
-                    t = v[1]; v[1] = v[3]; v[3] = t;
-                }
-                *reinterpret_cast<float4 *>(As + r * KP + (kq ^ (f & ~3))) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4 *>(As + r * KP + (kq ^ a_swz(r))) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) As[a_idx(r, kq + e)] = v[e];
@@ -740,33 +745,42 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         const float *bp = Ws + lh * BN + wn * TN + l31;
         if constexpr (SWZ) {
-            // K loop for the swizzled tile.  The reduction index of an MFMA step is k = 32 c + 2 t + lh; its swizzled column is
-            // 32 c + ((2 t) ^ (lh ^ f(row))), so for a fixed t the NC = KD / 32 reads of a lane differ by the immediate
-            // offset 32 c only: one xor + one add of address arithmetic per t instead of three VALU per read (an fp32 MFMA
-            // and VALU work of the same SIMD do not overlap, so every VALU in this loop is MFMA time lost).  t is the
-            // rolled, software-pipelined loop (reads of t + 1 are issued before the MFMAs of t); c is unrolled.
-            constexpr int NC = KD / 32;
-            const float *arow[MT];
-            int ga[MT];
+            // K loop for the swizzled tiles.  Lane (l31, lh) fetches the four reduction indices k = 64 c + 8 t + 4 lh + {0..3}
+            // of its row (A) and of its column (W) with one ds_read_b128 each and feeds them to four MFMA steps -- both
+            // operands of a step carry the same k for the same lh, which is all the instruction asks for.  The swizzled
+            // group is 64 c + ((8 t) ^ (4 lh ^ f)), so for a fixed t the NC = KD / 64 reads of a lane differ by an immediate
+            // offset only: one xor + one add of address arithmetic per operand and t (an fp32 MFMA and VALU work of the
+            // same SIMD do not overlap, so every VALU in this loop is MFMA time lost).  t is the rolled, software-pipelined
+            // loop (reads of t + 1 are issued before the MFMAs of t); c is unrolled.
+            constexpr int NC = KD / 64;
+            const float *arow[MT], *brow[NT];
+            int ga[MT], gb[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int r = wm * TM + i * 32 + l31;
                 arow[i] = As + r * KP;
-                ga[i] = lh ^ a_swz(r);
+                ga[i] = (4 * lh) ^ a_swz(r);
             }
-            float ra[2][NC][MT], rb[2][NC][NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = wn * TN + j * 32 + l31;
+                brow[j] = Ws + n * KD;
+                gb[j] = (4 * lh) ^ a_swz(n);
+            }
+            float4 ra[2][NC][MT], rb[2][NC][NT];
             auto ld = [&](int buf, int t) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const float *pa = arow[i] + ((2 * t) ^ ga[i]);
+                    const float *pa = arow[i] + ((8 * t) ^ ga[i]);
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) ra[buf][c][i] = pa[32 * c];
+                    for (int c = 0; c < NC; ++c) ra[buf][c][i] = *reinterpret_cast<const float4 *>(pa + 64 * c);
                 }
-                const float *pb = bp + 2 * t * BN;
 #pragma unroll
-                for (int c = 0; c < NC; ++c)
+                for (int j = 0; j < NT; ++j) {
+                    const float *pb = brow[j] + ((8 * t) ^ gb[j]);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) rb[buf][c][j] = pb[32 * c * BN + j * 32];
+                    for (int c = 0; c < NC; ++c) rb[buf][c][j] = *reinterpret_cast<const float4 *>(pb + 64 * c);
+                }
             };
             auto mm = [&](int buf) {
 #pragma unroll
@@ -774,16 +788,29 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][c][i], rb[buf][c][j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NT; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][c][i].x, rb[buf][c][j].x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][c][i].y, rb[buf][c][j].y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][c][i].z, rb[buf][c][j].z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][c][i].w, rb[buf][c][j].w, acc[i][j], 0, 0, 0);
+                        }
             };
-            ld(0, 0);
+            if constexpr (FDW && NT > 1) {  // no second operand buffer: the fused dW instantiations with two column tiles per
+                                            // wave are at the 256-register budget of two waves per SIMD
 #pragma unroll 1
-            for (int t = 0; t < 16; t += 2) {
-                ld(1, t + 1);
-                mm(0);
-                if (t + 2 < 16) ld(0, t + 2);
-                mm(1);
+                for (int t = 0; t < 8; ++t) {
+                    ld(0, t);
+                    mm(0);
+                }
+            } else {
+                ld(0, 0);
+#pragma unroll 1
+                for (int t = 0; t < 8; t += 2) {
+                    ld(1, t + 1);
+                    mm(0);
+                    if (t + 2 < 8) ld(0, t + 2);
+                    mm(1);
+                }
             }
         } else {
             {
@@ -832,19 +859,22 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                     const int cc = min(col, Nout - 1);
                     sc = E.scale[cc], sh = E.shift[cc], mu = E.mu[cc], is = E.istd[cc];
                 }
+                // statistics: this lane's 16 rows are summed in float32, the tiles of the worker in float64 (a float64
+                // add per element costs several VALU slots, and VALU time is MFMA time here)
+                float t1 = 0.f, t2 = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     const bool ok = row < M && col < Nout;
                     float v = ok ? acc[i][j][r] : 0.f;
                     if constexpr (EMODE == E_STORE_STATS) {
-                        s1[j] += (double)v;
-                        s2[j] += (double)v * (double)v;
+                        t1 += v;
+                        t2 = fmaf(v, v, t2);
                     } else if constexpr (EMODE == E_MASK_STATS) {
                         const float z0 = zp[i][j][r];
                         v = (fmaf(z0, sc, sh) > 0.f) ? v : 0.f;
-                        s1[j] += (double)v;
-                        s2[j] += (double)v * (double)((z0 - mu) * is);
+                        t1 += v;
+                        t2 = fmaf(v, (z0 - mu) * is, t2);
                     }
                     if (ok) E.c[(size_t)row * E.ldc + col] = v;
                     if constexpr (FDW) {  // a_{l-1} = relu(bn(z_{l-1})), the operand dW_l is contracted with
@@ -852,6 +882,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                         Ap[rl * BN + wn * TN + j * 32 + l31] = fmaxf(fmaf(zp[i][j][r], sc, sh), 0.f);
                     }
                 }
+                if constexpr (EMODE != E_STORE) s1[j] += (double)t1, s2[j] += (double)t2;
             }
         if constexpr (FDW) {
             __syncthreads();  // the whole relu(bn(zp)) tile is in LDS; the dZ tile still is
@@ -859,15 +890,15 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
             for (int t = 0; t < DT; ++t) {
                 const int tile_id = wave + 4 * t, ct = tile_id / (BN / 32), kt = tile_id % (BN / 32);
                 // dW tile (ct, kt) += dZ^T (columns ct*32.. of the A tile) x activation tile.  The reduction index is the tile
-                // row m = 32 c + 2 t + lh; f(m) = f(2 t) | (lh << 2) (the swizzle only looks at m mod 32), so the swizzled
-                // column is ((ct*32 + l31) ^ (lh << 2)) ^ F(t) with F(t) uniform: scalar work plus one xor per t, and the
-                // BM / 32 reads of a t differ by immediate offsets only.
+                // row m = 32 c + 2 t + lh; f(m) = f(2 t) | (lh << 2) (the swizzle only looks at m mod 16), so the swizzled
+                // column is ((ct*32 + l31) ^ (lh << 2)) ^ F(t) with F(t) = (t & 7) << 3 uniform: scalar work plus one xor
+                // per t, and the BM / 32 reads of a t differ by immediate offsets only.
                 constexpr int MC = BM / 32;
                 const int colx = (ct * 32 + l31) ^ (lh << 2);
                 const float *abase = As + lh * KP, *bbase = Ap + lh * BN + kt * 32 + l31;
                 float da[2][MC], db[2][MC];
                 auto ld = [&](int buf, int t) {
-                    const int F = ((t & 3) << 3) | ((t >> 2) & 3);
+                    const int F = (t & 7) << 3;
                     const float *pa = abase + 2 * t * KP + (colx ^ F), *pb = bbase + 2 * t * BN;
 #pragma unroll
                     for (int c = 0; c < MC; ++c) {

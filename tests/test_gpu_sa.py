@@ -186,3 +186,38 @@ def test_sa_config2_shapes(oracle):
     print(f"\nbackbone B=4: flat grad rel L2 {np.sqrt(num / den):.2e}, worst per-tensor rel-to-max {worst:.2e}")
     assert np.sqrt(num / den) < 3e-3          # gate G4 territory: nine BatchNorms deep
     assert worst < 1e-1, worst                # per-tensor, relative to its max: small tensors carry the fp32 noise
+
+
+@pytest.mark.parametrize("c0,npoint,nsample,n", [(256, 96, 64, 256), (512, 40, 16, 128), (64, 160, 32, 512)])
+def test_sa_layer0_convolved_before_the_gather(oracle, c0, npoint, nsample, n):
+    """Grouped levels with input features run layer 0 on the source points and gather afterwards (P[idx] + W_xyz (x - c),
+    csrc/gemm_kernels.hip gather_rel_stats / scatter_dz): wide layers (2 and 4 channel chunks per lane in the scatter),
+    both the on-the-fly dZ (B*S*K > 4096 rows) and the materialised one, against the fp64 oracle of the reference's
+    gather-then-convolve order (pointnet_pp_8dir.py:28-43)."""
+    from models.pointnet_pp_8dir import PointNetSetAbstraction
+    torch.manual_seed(c0)
+    B, D = 3, 32
+    sa = PointNetSetAbstraction(npoint, nsample, D, [c0, 64, 96]).cuda().train()
+    g = torch.Generator().manual_seed(7)
+    xyz = torch.rand(B, n, 3, generator=g) * 2 - 1
+    pts = torch.randn(B, n, D, generator=g)
+    centres = torch.stack([torch.randperm(n, generator=g)[:npoint] for _ in range(B)])
+    pts_gpu = pts.cuda().requires_grad_(True)
+    _, y = sa(xyz.cuda(), pts_gpu, centres.cuda())
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.cuda())
+
+    P = {}
+    for k, v in sa.state_dict().items():
+        if v.is_floating_point():
+            t = v.detach().cpu().double()
+            P["sa." + k] = t.requires_grad_(True) if "running" not in k else t
+    pts64 = pts.double().requires_grad_(True)
+    _, y_ref, _ = oracle.sa_forward(xyz, pts64, P, "sa", centres, nsample, False, True, oracle.BNState())
+    (y_ref * gy.double()).sum().backward()
+    assert _rel(y.detach().cpu(), y_ref.detach()) < 3e-5
+    assert _rel(pts_gpu.grad.cpu(), pts64.grad) < 5e-5
+    for name, p in sa.named_parameters():
+        if name.startswith("convs") and name.endswith("bias"):
+            continue
+        assert _rel(p.grad.cpu(), P["sa." + name].grad.reshape(p.shape)) < 5e-5, name
