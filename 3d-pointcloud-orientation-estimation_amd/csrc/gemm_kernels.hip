@@ -529,7 +529,8 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     auto a_swz = [](int r) { return (r & 15) << 2; };
     auto a_idx = [&](int r, int k) { return r * KP + (SWZ ? (k ^ a_swz(r)) : k); };
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index is uniform: telling the compiler so moves the tile-row / tile-column arithmetic of every address to the scalar unit
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int col_blk = blockIdx.x % ncol, worker = blockIdx.x / ncol, nworkers = gridDim.x / ncol;
@@ -849,6 +850,32 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
         }
 
         // epilogue: each accumulator register is one row; a half-wave writes 32 consecutive floats (128 B)
+        bool done = false;
+        if constexpr (EMODE != E_MASK_STATS) {
+            // interior tiles of the forward kernels: no bounds tests, and every store is (uniform row pointer) + (one 32-bit
+            // lane offset) -- scalar address arithmetic instead of a 64-bit multiply-add, a compare and an EXEC branch per row
+            if (m0 + BM <= M && n0 + BN <= Nout) {
+                done = true;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        float *tb = E.c + (size_t)(m0 + wm * TM + i * 32) * E.ldc + (n0 + wn * TN + j * 32);
+                        const unsigned lo = (unsigned)(4 * lh) * (unsigned)E.ldc + (unsigned)l31;
+                        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = acc[i][j][r];
+                            float *tr = tb + (size_t)((r & 3) + 8 * (r >> 2)) * E.ldc;
+                            tr[lo] = v;
+                            t1 += v;
+                            t2 = fmaf(v, v, t2);
+                        }
+                        if constexpr (EMODE == E_STORE_STATS) s1[j] += (double)t1, s2[j] += (double)t2;
+                    }
+            }
+        }
+        if (!done)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
