@@ -875,6 +875,34 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                     }
             }
         }
+        if constexpr (EMODE == E_MASK_STATS && NT == 1) {  // (two column tiles per wave: hipcc hoists the straight-line copy into spills)
+            if (m0 + BM <= M && n0 + BN <= Nout) {  // the same for the backward kernels: ReLU mask, BN-backward sums, a_{l-1} tile
+                done = true;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int col = n0 + wn * TN + j * 32 + l31;
+                        const float sc = E.scale[col], sh = E.shift[col], mu = E.mu[col], is = E.istd[col];
+                        float *tb = E.c + (size_t)(m0 + wm * TM + i * 32) * E.ldc + (n0 + wn * TN + j * 32);
+                        const unsigned lo = (unsigned)(4 * lh) * (unsigned)E.ldc + (unsigned)l31;
+                        float *apb = Ap + (wm * TM + i * 32 + 4 * lh) * BN + wn * TN + j * 32 + l31;
+                        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float z0 = zp[i][j][r];
+                            const float a0 = fmaf(z0, sc, sh);
+                            const float v = a0 > 0.f ? acc[i][j][r] : 0.f;
+                            float *tr = tb + (size_t)((r & 3) + 8 * (r >> 2)) * E.ldc;
+                            tr[lo] = v;
+                            t1 += v;
+                            t2 = fmaf(v, (z0 - mu) * is, t2);
+                            if constexpr (FDW) apb[((r & 3) + 8 * (r >> 2)) * BN] = fmaxf(a0, 0.f);
+                        }
+                        s1[j] += (double)t1, s2[j] += (double)t2;
+                    }
+            }
+        }
         if (!done)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
