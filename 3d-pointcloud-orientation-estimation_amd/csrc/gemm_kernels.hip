@@ -941,36 +941,45 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
             }
         if constexpr (FDW) {
             __syncthreads();  // the whole relu(bn(zp)) tile is in LDS; the dZ tile still is
+            // dW tile (ct, kt) += dZ^T (columns ct*32.. of the A tile) x activation tile (columns kt*32..).  A wave's DT tiles
+            // (tile_id = wave + 4 t) share kt, so one activation operand feeds DT MFMAs on DT independent accumulators.
+            // The reduction index is the tile row m = 32 c + 2 t2 + lh; f(m) = f(2 t2) | (lh << 2) (the swizzle only looks at
+            // m mod 16), so the swizzled column is ((ct*32 + l31) ^ (lh << 2)) ^ F(t2) with F(t2) = (t2 & 7) << 3 uniform:
+            // scalar work plus one xor per tile and t2, and the BM / 32 reads of a t2 differ by immediate offsets only.
+            static_assert(4 % (BN / 32) == 0, "a wave's dW tiles must share their activation columns");
+            constexpr int MC = BM / 32;
+            const int kt = wave % (BN / 32);
+            int colx[DT];
 #pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                const int tile_id = wave + 4 * t, ct = tile_id / (BN / 32), kt = tile_id % (BN / 32);
-                // dW tile (ct, kt) += dZ^T (columns ct*32.. of the A tile) x activation tile.  The reduction index is the tile
-                // row m = 32 c + 2 t + lh; f(m) = f(2 t) | (lh << 2) (the swizzle only looks at m mod 16), so the swizzled
-                // column is ((ct*32 + l31) ^ (lh << 2)) ^ F(t) with F(t) = (t & 7) << 3 uniform: scalar work plus one xor
-                // per t, and the BM / 32 reads of a t differ by immediate offsets only.
-                constexpr int MC = BM / 32;
-                const int colx = (ct * 32 + l31) ^ (lh << 2);
-                const float *abase = As + lh * KP, *bbase = Ap + lh * BN + kt * 32 + l31;
-                float da[2][MC], db[2][MC];
-                auto ld = [&](int buf, int t) {
-                    const int F = (t & 7) << 3;
-                    const float *pa = abase + 2 * t * KP + (colx ^ F), *pb = bbase + 2 * t * BN;
+            for (int t = 0; t < DT; ++t) colx[t] = (((wave + 4 * t) / (BN / 32)) * 32 + l31) ^ (lh << 2);
+            const float *abase = As + lh * KP, *bbase = Ap + lh * BN + kt * 32 + l31;
+            float da[2][MC][DT], db[2][MC];
+            auto ld = [&](int buf, int t2) {
+                const int F = (t2 & 7) << 3;
+                const float *pb = bbase + 2 * t2 * BN;
 #pragma unroll
-                    for (int c = 0; c < MC; ++c) {
-                        da[buf][c] = pa[32 * c * KP];
-                        db[buf][c] = pb[32 * c * BN];
-                    }
-                };
-                ld(0, 0);
-#pragma unroll 1
-                for (int t2 = 0; t2 < 16; t2 += 2) {
-                    ld(1, t2 + 1);
+                for (int c = 0; c < MC; ++c) db[buf][c] = pb[32 * c * BN];
 #pragma unroll
-                    for (int c = 0; c < MC; ++c) dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[0][c], db[0][c], dwacc[t], 0, 0, 0);
-                    if (t2 + 2 < 16) ld(0, t2 + 2);
+                for (int t = 0; t < DT; ++t) {
+                    const float *pa = abase + 2 * t2 * KP + (colx[t] ^ F);
 #pragma unroll
-                    for (int c = 0; c < MC; ++c) dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[1][c], db[1][c], dwacc[t], 0, 0, 0);
+                    for (int c = 0; c < MC; ++c) da[buf][c][t] = pa[32 * c * KP];
                 }
+            };
+            auto mm = [&](int buf) {
+#pragma unroll
+                for (int c = 0; c < MC; ++c)
+#pragma unroll
+                    for (int t = 0; t < DT; ++t)
+                        dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[buf][c][t], db[buf][c], dwacc[t], 0, 0, 0);
+            };
+            ld(0, 0);
+#pragma unroll 1
+            for (int t2 = 0; t2 < 16; t2 += 2) {
+                ld(1, t2 + 1);
+                mm(0);
+                if (t2 + 2 < 16) ld(0, t2 + 2);
+                mm(1);
             }
         }
     }
