@@ -600,6 +600,11 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
         c_is = *reinterpret_cast<const float4 *>(c + 2 * A.C);
         c_c1 = *reinterpret_cast<const float4 *>(c + 3 * A.C);
         c_c2 = *reinterpret_cast<const float4 *>(c + 4 * A.C);
+        // dz = g (dy - c1 - (z - mu) istd c2) as two FMAs per element: g dy + (a z + b), a = -g istd c2, b = -g c1 - a mu
+        // (c_is keeps a, c_c1 keeps b from here on; six dependent VALU per element otherwise, and VALU time is MFMA time)
+        c_is = make_float4(-c_g.x * c_is.x * c_c2.x, -c_g.y * c_is.y * c_c2.y, -c_g.z * c_is.z * c_c2.z, -c_g.w * c_is.w * c_c2.w);
+        c_c1 = make_float4(-c_g.x * c_c1.x - c_is.x * c_mu.x, -c_g.y * c_c1.y - c_is.y * c_mu.y, -c_g.z * c_c1.z - c_is.z * c_mu.z,
+                           -c_g.w * c_c1.w - c_is.w * c_mu.w);
     } else if constexpr (G4 > 0 && AMODE == A_BNRELU) {
         c_sc = *reinterpret_cast<const float4 *>(A.scale + kq);
         c_sh = *reinterpret_cast<const float4 *>(A.shift + kq);
@@ -695,10 +700,10 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                         dy.x = kk == ia.x ? dm.x : 0.f, dy.y = kk == ia.y ? dm.y : 0.f;
                         dy.z = kk == ia.z ? dm.z : 0.f, dy.w = kk == ia.w ? dm.w : 0.f;
                     }
-                    v[0] = c_g.x * (dy.x - c_c1.x - (z.x - c_mu.x) * c_is.x * c_c2.x);
-                    v[1] = c_g.y * (dy.y - c_c1.y - (z.y - c_mu.y) * c_is.y * c_c2.y);
-                    v[2] = c_g.z * (dy.z - c_c1.z - (z.z - c_mu.z) * c_is.z * c_c2.z);
-                    v[3] = c_g.w * (dy.w - c_c1.w - (z.w - c_mu.w) * c_is.w * c_c2.w);
+                    v[0] = fmaf(c_g.x, dy.x, fmaf(c_is.x, z.x, c_c1.x));
+                    v[1] = fmaf(c_g.y, dy.y, fmaf(c_is.y, z.y, c_c1.y));
+                    v[2] = fmaf(c_g.z, dy.z, fmaf(c_is.z, z.z, c_c1.z));
+                    v[3] = fmaf(c_g.w, dy.w, fmaf(c_is.w, z.w, c_c1.w));
                 }
             }
             if constexpr (SWZ) {
