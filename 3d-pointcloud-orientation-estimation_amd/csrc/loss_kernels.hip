@@ -367,6 +367,43 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const 
     }
 }
 
+// The same update with the step count in device memory, for launches that are captured in a hipGraph: state[0] = steps
+// taken so far, state[1] = ticket.  Every workgroup reads state[0] before it takes its ticket and the last one
+// advances the count, so each replay applies its own bias correction.  zero_grad != 0 clears every gradient once it has
+// been consumed (the next step's zero_grad() memset, folded in).
+__global__ void __launch_bounds__(256) adam_dev_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                       float *__restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                       float gscale, unsigned long long *__restrict__ state, int zero_grad) {
+    __shared__ float bc[2];
+    __shared__ unsigned long long step_s;
+    if (threadIdx.x == 0) {
+        const unsigned long long step = state[0] + 1ull;
+        step_s = step;
+        const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+        bc[0] = (float)((double)lr / bc1);
+        bc[1] = (float)(1.0 / sqrt(bc2));
+    }
+    __syncthreads();
+    const float lr_over_bc1 = bc[0], inv_sqrt_bc2 = bc[1];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        if (zero_grad) g[i] = 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = atomicAdd(&state[1], 1ull);
+        if (t == (unsigned long long)gridDim.x - 1ull) {
+            state[1] = 0ull;
+            state[0] = step_s;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) sumsq_partial_kernel(const float *__restrict__ x, size_t n, double *__restrict__ part) {
     __shared__ double red[4];
     double acc = 0.0;
@@ -657,6 +694,17 @@ extern "C" int pnpp_adam_step(float *param, const float *grad, float *exp_avg, f
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
                        (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale);
     PNPP_CHECK_LAUNCH("adam_step");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_adam_step_dev(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, uint64_t *step_state,
+                                  float lr, float beta1, float beta2, float eps, float grad_scale, int zero_grad, void *stream) {
+    PNPP_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_state, PNPP_ERR_ARG, "adam_step_dev: null pointer");
+    PNPP_REQUIRE(n > 0, PNPP_ERR_ARG, "adam_step_dev: n must be positive");
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                       beta2, eps, grad_scale, reinterpret_cast<unsigned long long *>(step_state), zero_grad);
+    PNPP_CHECK_LAUNCH("adam_step_dev");
     return PNPP_OK;
 }
 

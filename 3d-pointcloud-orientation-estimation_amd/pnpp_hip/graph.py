@@ -3,9 +3,9 @@
 A training step of this path is ~100 short launches; once the kernels are fast the host cannot issue them as
 quickly as the GPU retires them.  Everything the C ABI enqueues is stream-ordered and allocation-free, so
 zero_grad + forward + loss + backward can be captured once and replayed: inputs are copied into static buffers,
-centre sampling reads its counter from device memory, dropout uses torch's graph-safe Philox offsets.  The
-gradient all-reduce and the fused Adam launch stay outside the graph (they depend on host-side step counts and
-on the process group).
+centre sampling reads its counter from device memory, dropout draws from a device-side counter.  In a single
+process the fused Adam launch is captured as well (step count in device memory, FlatAdam.step_dev); with data
+parallelism the gradient all-reduce and the update stay outside the graph (they depend on the process group).
 """
 from __future__ import annotations
 
@@ -16,13 +16,24 @@ import torch
 
 class GraphedStep:
     def __init__(self, opt, loss_fn: Callable[..., torch.Tensor], example_inputs: Sequence[torch.Tensor], warmup: int = 3,
-                 adopt_inputs: bool = False):
+                 adopt_inputs: bool = False, fused_optimizer: bool = False, grad_scale: float = 1.0,
+                 zero_grad_in_graph: bool = True):
         """loss_fn(*inputs) -> scalar loss; `opt` is a pnpp_hip.optim.FlatAdam (its flat gradient buffer is static).
+
+        fused_optimizer=True (single process: nothing sits between backward and the update) captures the Adam launch
+        too -- opt.step_dev keeps its step count on the device -- and lets that launch clear the gradients it has
+        consumed, so a replay is forward + backward + update with no memset and no eager launch; the caller then does
+        NOT call opt.step().  (Measured on MI355X: back-to-back graph launches cost more than a graph followed by
+        one eager launch -- the next graph's start-up hides behind the eager kernel -- so bench.py keeps Adam eager.)
+
+        zero_grad_in_graph=False leaves the memset out of the graph: the caller's update clears the gradients it
+        consumed (opt.step_dev(zero_grad=True)) instead.
 
         adopt_inputs=True makes `example_inputs` themselves the static input buffers (`self.static_in`): a loader that
         writes the next batch into them (H2D copy target) and then calls the step with the same tensors pays no
         device-to-device copy; any other tensor passed later is copied in as usual."""
         self.opt = opt
+        self.fused_optimizer = fused_optimizer
         self.static_in = list(example_inputs) if adopt_inputs else [t.clone() for t in example_inputs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -35,9 +46,19 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: with torch.distributed initialised, the process group's watchdog thread polls its events with
         # HIP calls of its own; under the default (global) mode such a call during the capture would invalidate it
+        if fused_optimizer or not zero_grad_in_graph:
+            opt.zero_grad()                               # the update leaves the buffer cleared from here on
+        if fused_optimizer:
+            opt.seed_dev_steps()
+            steps_before = opt.step_count
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            opt.zero_grad()
+            if not fused_optimizer and zero_grad_in_graph:
+                opt.zero_grad()
             self.static_loss = self._run(loss_fn)
+            if fused_optimizer:
+                opt.step_dev(grad_scale=grad_scale, zero_grad=True)
+        if fused_optimizer:                               # capturing is not stepping
+            opt.step_count = opt._dev_steps = steps_before
 
     def _run(self, loss_fn) -> torch.Tensor:
         """loss_fn may return a loss to differentiate, or (no grad_fn) one whose backward pass it has already run."""
@@ -51,6 +72,9 @@ class GraphedStep:
             if s.data_ptr() != t.data_ptr():
                 s.copy_(t, non_blocking=True)
         self.graph.replay()
+        if self.fused_optimizer:
+            self.opt.step_count += 1
+            self.opt._dev_steps = self.opt.step_count
         return self.static_loss
 
 

@@ -48,6 +48,7 @@ class FlatAdam:
             self._views.append(g)
             off += n
         self.step_count = 0
+        self._step_state = torch.zeros(2, device=dev, dtype=torch.int64)   # step_dev(): [steps taken, ticket]
         self._scratch = torch.empty(1024 * 8 + 8, device=dev, dtype=torch.uint8)
 
     @property
@@ -90,3 +91,23 @@ class FlatAdam:
         L.check(L.lib().pnpp_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                                        self.exp_avg_sq.data_ptr(), self.flat_p.numel(), self.step_count, self.lr,
                                        self.betas[0], self.betas[1], self.eps, float(scale), _stream()))
+
+    def seed_dev_steps(self) -> None:
+        """Copies the host step count into the device word step_dev() reads, if they differ (not capturable: call it
+        before a capture starts)."""
+        if getattr(self, "_dev_steps", None) != self.step_count:
+            self._step_state.copy_(torch.tensor([self.step_count, 0], dtype=torch.int64))
+            self._dev_steps = self.step_count
+
+    def step_dev(self, grad_scale: float = 1.0, zero_grad: bool = False) -> None:
+        """step() with the step count kept in device memory, so the launch can be captured in a hipGraph and replayed
+        (pnpp_hip.graph.GraphedStep(fused_optimizer=True)); `zero_grad` clears the flat gradient buffer in the same launch.
+        The device count is re-seeded from `step_count` whenever the two disagree (first use, after eager step()s);
+        callers that replay a captured step_dev bump `step_count` themselves."""
+        self.seed_dev_steps()
+        self.step_count += 1
+        self._dev_steps = self.step_count
+        L.check(L.lib().pnpp_adam_step_dev(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                                           self.exp_avg_sq.data_ptr(), self.flat_p.numel(), self._step_state.data_ptr(), self.lr,
+                                           self.betas[0], self.betas[1], self.eps, float(grad_scale), int(bool(zero_grad)),
+                                           _stream()))

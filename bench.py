@@ -70,7 +70,10 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
     if use_graph and split is None:
         try:
             from pnpp_hip.graph import GraphedStep
-            graphed = GraphedStep(opt, loss_fn, [xyz, mu_gt, kappa_gt], adopt_inputs=True)   # the batch is resident: no staging copy
+            # the batch is resident: no staging copy.  The Adam launch stays eager: PNPP_CAPTURED_ADAM=1 captures it too
+            # (device-side step count), measured 2.5 % slower -- DESIGN.md 9
+            graphed = GraphedStep(opt, loss_fn, [xyz, mu_gt, kappa_gt], adopt_inputs=True,
+                                  fused_optimizer=(world == 1 and os.environ.get("PNPP_CAPTURED_ADAM") == "1"))
         except Exception as e:  # capture is an optimisation, never a requirement
             print(f"[bench] hipGraph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr)
             graphed = None
@@ -82,6 +85,8 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
             return loss
         if graphed is not None:
             loss = graphed(xyz, mu_gt, kappa_gt)
+            if graphed.fused_optimizer:
+                return loss
         else:
             opt.zero_grad()
             loss = loss_fn(xyz, mu_gt, kappa_gt)
@@ -93,6 +98,7 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
         return loss
 
     mode = ("two hipGraphs (fwd + sa3/head bwd | sa2/sa1 bwd) with the bucketed all-reduce overlapped + eager Adam" if split is not None
+            else "hipGraph(fwd+loss+bwd+Adam, gradients cleared by the update)" if graphed is not None and graphed.fused_optimizer
             else "hipGraph(zero_grad+fwd+loss+bwd) + eager all-reduce/Adam" if graphed is not None else "eager")
     return step, mode
 

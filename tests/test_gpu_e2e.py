@@ -293,6 +293,52 @@ def test_hipgraph_step_equals_eager(oracle):
         PointNetSetAbstraction.sampler = old
 
 
+def test_hipgraph_step_with_captured_adam_equals_eager(oracle):
+    """fused_optimizer=True: forward + loss + backward + Adam in one hipGraph, the step count in device memory and
+    the gradients cleared by the update itself.  Five replays leave the parameters, both Adam moments and the loss
+    history bit-identical to five eager zero_grad / backward / step() iterations."""
+    import copy
+    from models.pointnet_pp_vonMises import PointNetPPVonMises
+    from models.pointnet_pp_8dir import PointNetSetAbstraction
+    from pnpp_hip import ops, optim, sampling
+    from pnpp_hip.graph import GraphedStep
+    old = PointNetSetAbstraction.sampler
+    PointNetSetAbstraction.sampler = "device"
+    try:
+        torch.manual_seed(7)
+        m1 = PointNetPPVonMises().cuda().train()
+        m1.drop.p = 0.0
+        m2 = copy.deepcopy(m1)
+        o1, o2 = optim.FlatAdam(m1.parameters(), lr=1e-3), optim.FlatAdam(m2.parameters(), lr=1e-3)
+        xyz, mu_gt, kappa_gt, _ = oracle.synthetic_clouds(8, 1024, seed=4)
+        xyz, mu_gt, kappa_gt = xyz.cuda(), mu_gt.cuda(), kappa_gt.cuda()
+
+        def loss_fn(model):
+            return lambda x, m, k: ops.kl_von_mises_single(*model(x), m, k).mean()
+
+        g = GraphedStep(o1, loss_fn(m1), [xyz, mu_gt, kappa_gt], fused_optimizer=True)
+        assert o1.step_count == 0 and torch.equal(o1.flat_p, o2.flat_p)    # capture and warm-up took no optimiser step
+        for p, q in zip(m1.buffers(), m2.buffers()):
+            p.copy_(q)
+        for it in range(5):
+            sampling.reset(10 * it)
+            l1 = float(g(xyz, mu_gt, kappa_gt))
+            sampling.reset(10 * it)
+            o2.zero_grad()
+            l2 = loss_fn(m2)(xyz, mu_gt, kappa_gt)
+            l2.backward()
+            o2.step()
+            assert l1 == float(l2), (it, l1, float(l2))
+            assert torch.equal(o1.flat_p, o2.flat_p), it
+        assert o1.step_count == 5 and int(o1._step_state[0]) == 5 and int(o1._step_state[1]) == 0
+        assert torch.equal(o1.exp_avg, o2.exp_avg) and torch.equal(o1.exp_avg_sq, o2.exp_avg_sq)
+        assert float(o1.flat_g.abs().max()) == 0.0                           # cleared by the update
+        o1.step_dev(zero_grad=False)                                         # eager use of the same entry point: a 6th step
+        assert o1.step_count == 6 and int(o1._step_state[0]) == 6
+    finally:
+        PointNetSetAbstraction.sampler = old
+
+
 def test_split_hipgraph_step_equals_eager(oracle):
     """The two-graph step used under data parallelism (forward + sa3/head backward | sa2/sa1 backward, the gradient
     slices handed to an all-reduce callback in between): same loss and, bit for bit, the same flat gradient as eager
