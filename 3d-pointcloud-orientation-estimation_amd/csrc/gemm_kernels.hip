@@ -1858,6 +1858,81 @@ int launch_scatter_dz(const AOperand &dz, const AOperand &geo, int B, int Mc, in
     return PNPP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// dW for the small-M levels (group_all: M = 32 B rows, wide layers).  dw_kernel's waves each pull their own operand
+// rows from L2 one dword per lane; here a workgroup owns a 128 x 128 block of dW over one row range, stages 32-row
+// chunks of both operands through LDS with 16-byte loads (8 per thread and chunk instead of 64 dword loads per lane),
+// and its four waves (64 x 64 each, 2 x 2 MFMA tiles) read them back lane-per-column -- every staged element feeds two
+// MFMA tiles.  Same partial-slab output as dw_kernel (slab[split][c][kp_pad]).
+// ---------------------------------------------------------------------------------------------
+template <int DZMODE, int A2MODE>
+__global__ void __launch_bounds__(256)
+dw_lds_kernel(const AOperand dz, const AOperand a2, int M, int Nc, int Kp, int tilesC, int tilesK, int rps, int kp_pad,
+              float *__restrict__ slab) {
+    __shared__ __attribute__((aligned(16))) float Dz[32][128];
+    __shared__ __attribute__((aligned(16))) float A2[32][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int tiles = tilesC * tilesK;
+    const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+    const int c0 = (tile % tilesC) * 128, k0 = (tile / tilesC) * 128;
+    const int r0 = min(M, split * rps), r1 = min(M, r0 + rps);  // an empty range still writes its (zero) slab block
+    const int wc = wave >> 1, wk = wave & 1;
+    const int q4 = 4 * (tid & 31), rb = tid >> 5;  // staging map: 4 columns of rows rb + 8 i
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    RawA nd[4], na[4];
+    auto fetch = [&](int m0) {  // rows >= r1 belong to the next split: r1 plays M for the loaders (clamped loads, zeroed values)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            nd[i] = fetch_a4<DZMODE>(dz, m0 + rb + 8 * i, c0 + q4, r1, Nc);
+            na[i] = fetch_a4<A2MODE>(a2, m0 + rb + 8 * i, k0 + q4, r1, Kp);
+        }
+    };
+    if (r0 < r1) fetch(r0);
+    for (int m0 = r0; m0 < r1; m0 += 32) {
+        __syncthreads();  // the previous chunk's operand reads are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v[4];
+            xform_a4<DZMODE>(dz, nd[i], m0 + rb + 8 * i, c0 + q4, r1, Nc, v);
+            *reinterpret_cast<float4 *>(&Dz[rb + 8 * i][q4]) = make_float4(v[0], v[1], v[2], v[3]);
+            xform_a4<A2MODE>(a2, na[i], m0 + rb + 8 * i, k0 + q4, r1, Kp, v);
+            *reinterpret_cast<float4 *>(&A2[rb + 8 * i][q4]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __syncthreads();
+        if (m0 + 32 < r1) fetch(m0 + 32);  // the next chunk's loads fly during the MFMA loop
+        const float *pd = &Dz[lh][wc * 64 + l31], *pa = &A2[lh][wk * 64 + l31];
+#pragma unroll 4
+        for (int rp = 0; rp < 16; ++rp) {  // reduction index = row 2 rp + lh of the chunk
+            const float d0 = pd[rp * 256], d1 = pd[rp * 256 + 32], b0 = pa[rp * 256], b1 = pa[rp * 256 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    float *o = slab + (size_t)split * Nc * kp_pad;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + wk * 64 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + wc * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (c < Nc && k < kp_pad) o[(size_t)c * kp_pad + k] = acc[i][j][r];
+            }
+        }
+}
+
 void dw_plan(int M, int Nc, int Kp, int *nsplit, int *kp_pad) {
     const int tilesC = cdiv(Nc, 64), tilesK = cdiv(Kp, 64);
     const int tiles = tilesC * tilesK;
@@ -1879,6 +1954,27 @@ int launch_dw(const AOperand &dz, int Nc, const AOperand &a2, int Kp, int M, flo
     PNPP_REQUIRE(kp_pad == tilesK * 64, PNPP_ERR_ARG, "dw: kp_pad mismatch");
     int rps = cdiv(M, nsplit);
     rps = (rps + 7) & ~7;  // multiple of 8: a fetch batch (4 row pairs) never straddles two splits or two groups
+    if (M <= 4096 && Nc >= 128 && Kp >= 128 && dz.mode == A_PLAIN && (dz.lda & 3) == 0 && ((uintptr_t)dz.a & 15) == 0 &&
+        (a2.mode == A_PLAIN || a2.mode == A_BNRELU || a2.mode == A_CONCAT) &&
+        (a2.mode == A_CONCAT || ((a2.lda & 3) == 0 && ((uintptr_t)a2.a & 15) == 0))) {
+        // small-M, wide layers: LDS-staged 128 x 128 blocks
+        const int tc = cdiv(Nc, 128), tk = cdiv(Kp, 128);
+        const dim3 grid(tc * tk * nsplit);
+        ProfScope ps(st, "dw_lds_kernel<A%d,A%d> M=%d N=%d K=%d split=%d grid=%d", dz.mode, a2.mode, M, Nc, Kp, nsplit, grid.x);
+        switch (a2.mode) {
+            case A_PLAIN:
+                hipLaunchKernelGGL((dw_lds_kernel<A_PLAIN, A_PLAIN>), grid, dim3(256), 0, st, dz, a2, M, Nc, Kp, tc, tk, rps, kp_pad, slab);
+                break;
+            case A_BNRELU:
+                hipLaunchKernelGGL((dw_lds_kernel<A_PLAIN, A_BNRELU>), grid, dim3(256), 0, st, dz, a2, M, Nc, Kp, tc, tk, rps, kp_pad, slab);
+                break;
+            default:
+                hipLaunchKernelGGL((dw_lds_kernel<A_PLAIN, A_CONCAT>), grid, dim3(256), 0, st, dz, a2, M, Nc, Kp, tc, tk, rps, kp_pad, slab);
+                break;
+        }
+        PNPP_CHECK_LAUNCH("dw(lds)");
+        return PNPP_OK;
+    }
     const int waves = tilesC * tilesK * nsplit;
     const dim3 grid(cdiv(waves, 4)), block(256);
     ProfScope ps(st, "dw_kernel<A%d,A%d> M=%d N=%d K=%d split=%d grid=%dx1", dz.mode, a2.mode, M, Nc, Kp, nsplit, grid.x);
