@@ -181,7 +181,7 @@ def test_soft_ce(ops, golden):
 
 
 @pytest.mark.parametrize("kind", ["bn", "ln", "none"])
-@pytest.mark.parametrize("M,K,N", [(32, 1024, 512), (8, 256, 16), (5, 512, 256)])
+@pytest.mark.parametrize("M,K,N", [(32, 1024, 512), (8, 256, 16), (5, 512, 256), (100, 512, 256), (64, 1024, 512), (300, 260, 132)])
 def test_fc_block(ops, oracle, kind, M, K, N):
     torch.manual_seed(M * 7 + N)
     lin = nn.Linear(K, N)
