@@ -2048,9 +2048,62 @@ __device__ __forceinline__ void slab_reduce_block(const SlabReduceArgs &R, int b
     }
 }
 
+// the same reduction on groups of four consecutive k (16-byte loads and stores, a quarter of the threads and load
+// instructions): block = EPB groups x (256/EPB) split lanes.  Needs Kvalid, kp_pad, ldo multiples of 4, no permutation.
 template <int EPB>
+__device__ __forceinline__ void slab_reduce_block4(const SlabReduceArgs &R, int bid) {
+    constexpr int SL = 256 / EPB;
+    __shared__ float4 red4[SL][EPB];
+    const int kg = R.Kvalid >> 2, total = R.Nc * kg;
+    const int e = threadIdx.x % EPB, sl = threadIdx.x / EPB;
+    const int i = bid * EPB + e;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int c = 0, k = 0;
+    if (i < total) {
+        c = i / kg, k = 4 * (i - c * kg);
+        const float *p = R.slab + (size_t)c * R.kp_pad + k;
+        const size_t stride = (size_t)R.Nc * R.kp_pad;
+        float4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int s = sl;
+        for (; s + 3 * SL < R.nsplit; s += 4 * SL) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 q = *reinterpret_cast<const float4 *>(p + (size_t)(s + u * SL) * stride);
+                a[u].x += q.x, a[u].y += q.y, a[u].z += q.z, a[u].w += q.w;
+            }
+        }
+        for (; s < R.nsplit; s += SL) {
+            const float4 q = *reinterpret_cast<const float4 *>(p + (size_t)s * stride);
+            a[0].x += q.x, a[0].y += q.y, a[0].z += q.z, a[0].w += q.w;
+        }
+        acc = make_float4((a[0].x + a[1].x) + (a[2].x + a[3].x), (a[0].y + a[1].y) + (a[2].y + a[3].y),
+                          (a[0].z + a[1].z) + (a[2].z + a[3].z), (a[0].w + a[1].w) + (a[2].w + a[3].w));
+    }
+    red4[sl][e] = acc;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < SL; ++j) {
+            const float4 q = red4[j][e];
+            t.x += q.x, t.y += q.y, t.z += q.z, t.w += q.w;
+        }
+        *reinterpret_cast<float4 *>(R.out + (size_t)c * R.ldo + k) = t;
+    }
+}
+
+static inline bool slab_reduce_vec4(const SlabReduceArgs &R) {  // few, wide partials (measured: no gain once nsplit > 32)
+    return R.nsplit <= 32 && R.perm_D < 0 && (R.Kvalid & 3) == 0 && (R.kp_pad & 3) == 0 && (R.ldo & 3) == 0 && (((uintptr_t)R.slab | (uintptr_t)R.out) & 15) == 0;
+}
+// groups per block for the 16-byte form: few splits -> many groups per block; many splits -> many split lanes
+static inline int slab_reduce_epb4(int nsplit) { return nsplit <= 32 ? 64 : nsplit <= 128 ? 16 : 4; }
+
+template <int EPB, bool V4 = false>
 __global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduceArgs R) {
-    slab_reduce_block<EPB>(R, blockIdx.x);
+    if constexpr (V4) slab_reduce_block4<EPB>(R, blockIdx.x);
+    else slab_reduce_block<EPB>(R, blockIdx.x);
 }
 
 static inline bool slab_reduce_wide(int total, int nsplit) { return total >= 16384 || nsplit <= 8; }
@@ -2060,7 +2113,12 @@ int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kv
     const int total = Nc * Kvalid;
     const SlabReduceArgs R{slab, nsplit, Nc, kp_pad, Kvalid, perm_D, out, ldo};
     ProfScope ps(st, "slab_reduce_kernel N=%d K=%d split=%d", Nc, Kvalid, nsplit);
-    if (slab_reduce_wide(total, nsplit))
+    if (slab_reduce_vec4(R)) {
+        const int groups = total / 4, epb = slab_reduce_epb4(nsplit);
+        if (epb == 64) hipLaunchKernelGGL((slab_reduce_kernel<64, true>), dim3(cdiv(groups, 64)), dim3(256), 0, st, R);
+        else if (epb == 16) hipLaunchKernelGGL((slab_reduce_kernel<16, true>), dim3(cdiv(groups, 16)), dim3(256), 0, st, R);
+        else hipLaunchKernelGGL((slab_reduce_kernel<4, true>), dim3(cdiv(groups, 4)), dim3(256), 0, st, R);
+    } else if (slab_reduce_wide(total, nsplit))
         hipLaunchKernelGGL(slab_reduce_kernel<64>, dim3(cdiv(total, 64)), dim3(256), 0, st, R);
     else
         hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3(cdiv(total, 16)), dim3(256), 0, st, R);
@@ -2169,9 +2227,10 @@ __global__ void __launch_bounds__(256) bn_finalize_bwd_kernel(BnFinalizeBwdArgs 
 
 // the two reductions that follow a backward GEMM -- the weight-gradient partials of layer l and the BatchNorm-backward
 // column sums of layer l-1 -- share one launch: the first nfin workgroups finalise, the rest reduce slabs
-template <int EPB>
+template <int EPB, bool V4 = false>
 __global__ void __launch_bounds__(256) post_gemm_kernel(BnFinalizeBwdArgs F, int nfin, SlabReduceArgs R) {
     if ((int)blockIdx.x < nfin) bn_finalize_bwd_block(F, blockIdx.x);
+    else if constexpr (V4) slab_reduce_block4<EPB>(R, blockIdx.x - nfin);
     else slab_reduce_block<EPB>(R, blockIdx.x - nfin);
 }
 
@@ -2202,7 +2261,12 @@ int launch_post_gemm(const double *slab, int nslab, int C, double count, int tra
     const SlabReduceArgs R{dwslab, nsplit, Nc, kp_pad, Kvalid, perm_D, dw, ldo};
     const int total = Nc * Kvalid, nfin = cdiv(C, FIN_COLS);
     ProfScope ps(st, "post_gemm_kernel C=%d | N=%d K=%d split=%d", C, Nc, Kvalid, nsplit);
-    if (slab_reduce_wide(total, nsplit))
+    if (slab_reduce_vec4(R)) {
+        const int groups = total / 4, epb = slab_reduce_epb4(nsplit);
+        if (epb == 64) hipLaunchKernelGGL((post_gemm_kernel<64, true>), dim3(nfin + cdiv(groups, 64)), dim3(256), 0, st, F, nfin, R);
+        else if (epb == 16) hipLaunchKernelGGL((post_gemm_kernel<16, true>), dim3(nfin + cdiv(groups, 16)), dim3(256), 0, st, F, nfin, R);
+        else hipLaunchKernelGGL((post_gemm_kernel<4, true>), dim3(nfin + cdiv(groups, 4)), dim3(256), 0, st, F, nfin, R);
+    } else if (slab_reduce_wide(total, nsplit))
         hipLaunchKernelGGL(post_gemm_kernel<64>, dim3(nfin + cdiv(total, 64)), dim3(256), 0, st, F, nfin, R);
     else
         hipLaunchKernelGGL(post_gemm_kernel<16>, dim3(nfin + cdiv(total, 16)), dim3(256), 0, st, F, nfin, R);
