@@ -2108,6 +2108,28 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduceArgs R) {
 
 static inline bool slab_reduce_wide(int total, int nsplit) { return total >= 16384 || nsplit <= 8; }
 
+// two independent reductions in one launch (scalar form): blocks [0, n1) take R1, the rest R2
+template <int EPB1, int EPB2>
+__global__ void __launch_bounds__(256) slab_reduce2_kernel(SlabReduceArgs R1, int n1, SlabReduceArgs R2) {
+    if ((int)blockIdx.x < n1) slab_reduce_block<EPB1>(R1, blockIdx.x);
+    else slab_reduce_block<EPB2>(R2, blockIdx.x - n1);
+}
+
+int launch_slab_reduce2(const float *slab1, int nsplit1, int Nc1, int kp_pad1, int Kvalid1, float *out1, int ldo1, const float *slab2,
+                        int nsplit2, int Nc2, int kp_pad2, int Kvalid2, float *out2, int ldo2, hipStream_t st) {
+    const SlabReduceArgs R1{slab1, nsplit1, Nc1, kp_pad1, Kvalid1, -1, out1, ldo1}, R2{slab2, nsplit2, Nc2, kp_pad2, Kvalid2, -1, out2, ldo2};
+    const int t1 = Nc1 * Kvalid1, t2 = Nc2 * Kvalid2;
+    const bool w1 = slab_reduce_wide(t1, nsplit1), w2 = slab_reduce_wide(t2, nsplit2);
+    const int n1 = cdiv(t1, w1 ? 64 : 16), n2 = cdiv(t2, w2 ? 64 : 16);
+    ProfScope ps(st, "slab_reduce2_kernel N=%d K=%d split=%d | N=%d K=%d split=%d", Nc1, Kvalid1, nsplit1, Nc2, Kvalid2, nsplit2);
+    if (w1 && w2) hipLaunchKernelGGL((slab_reduce2_kernel<64, 64>), dim3(n1 + n2), dim3(256), 0, st, R1, n1, R2);
+    else if (w1) hipLaunchKernelGGL((slab_reduce2_kernel<64, 16>), dim3(n1 + n2), dim3(256), 0, st, R1, n1, R2);
+    else if (w2) hipLaunchKernelGGL((slab_reduce2_kernel<16, 64>), dim3(n1 + n2), dim3(256), 0, st, R1, n1, R2);
+    else hipLaunchKernelGGL((slab_reduce2_kernel<16, 16>), dim3(n1 + n2), dim3(256), 0, st, R1, n1, R2);
+    PNPP_CHECK_LAUNCH("slab_reduce2");
+    return PNPP_OK;
+}
+
 int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kvalid, int perm_D, float *out, int ldo,
                        hipStream_t st) {
     const int total = Nc * Kvalid;
@@ -2280,7 +2302,13 @@ int launch_post_gemm(const double *slab, int nslab, int C, double count, int tra
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) pool_fwd_kernel(const float *__restrict__ z, const float *__restrict__ scale,
                                                        const float *__restrict__ shift, int G, int K, int C,
-                                                       float *__restrict__ out, int32_t *__restrict__ arg) {
+                                                       float *__restrict__ out, int32_t *__restrict__ arg,
+                                                       float *__restrict__ origin_a, float *__restrict__ origin_b, int norigin) {
+    if (blockIdx.x == 0)  // group_all levels: the centre of every cloud is the origin (pointnet_pp_8dir.py:24); no launch of its own
+        for (int i = threadIdx.x; i < norigin; i += 256) {
+            if (origin_a) origin_a[i] = 0.f;
+            if (origin_b) origin_b[i] = 0.f;
+        }
     const size_t total = (size_t)G * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t g = i / C;
@@ -2310,11 +2338,11 @@ __global__ void __launch_bounds__(256) pool_fwd_kernel(const float *__restrict__
 }
 
 int launch_pool_fwd(const float *z, const float *scale, const float *shift, int G, int K, int C, float *out, int32_t *arg,
-                    hipStream_t st) {
+                    hipStream_t st, float *origin_a, float *origin_b, int norigin) {
     const size_t total = (size_t)G * C;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     ProfScope ps(st, "pool_fwd_kernel G=%d K=%d C=%d", G, K, C);
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid), dim3(256), 0, st, z, scale, shift, G, K, C, out, arg);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid), dim3(256), 0, st, z, scale, shift, G, K, C, out, arg, origin_a, origin_b, norigin);
     PNPP_CHECK_LAUNCH("pool_fwd");
     return PNPP_OK;
 }

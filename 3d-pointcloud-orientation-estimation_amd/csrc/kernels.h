@@ -113,6 +113,8 @@ int launch_scatter_dz(const AOperand &dz, const AOperand &geo, int B, int Mc, in
 int dw_xyz_splits(int M);
 int launch_dw_xyz(const AOperand &dz, int Nc, const AOperand &a2, int M, float *slab, hipStream_t st);
 // out[c][perm(k)] = sum_s slab[s][c][k]; perm_D < 0: identity; else feature-first -> xyz-first column order.
+int launch_slab_reduce2(const float *slab1, int nsplit1, int Nc1, int kp_pad1, int Kvalid1, float *out1, int ldo1, const float *slab2,
+                        int nsplit2, int Nc2, int kp_pad2, int Kvalid2, float *out2, int ldo2, hipStream_t st);
 int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kvalid, int perm_D, float *out, int ldo,
                        hipStream_t st);
 
@@ -129,7 +131,7 @@ int launch_post_gemm(const double *slab, int nslab, int C, double count, int tra
                      int Nc, int kp_pad, int Kvalid, int perm_D, float *dw, int ldo, hipStream_t st);
 
 int launch_pool_fwd(const float *z, const float *scale, const float *shift, int G, int K, int C, float *out, int32_t *arg,
-                    hipStream_t st);
+                    hipStream_t st, float *origin_a = nullptr, float *origin_b = nullptr, int norigin = 0);
 // backward of max + ReLU without materialising the dense gradient: writes the masked pooled gradient dm (G x C)
 // and collects the BatchNorm-backward column sums; consumers rebuild dy on the fly (A_DZ_POOL)
 int launch_pool_bwd(const float *dout, const int32_t *arg, const float *z, const float *scale, const float *shift,

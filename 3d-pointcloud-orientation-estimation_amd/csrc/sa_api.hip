@@ -123,6 +123,7 @@ struct SaScratch {
     float *cst;
     float *dwslab;
     float *src;  // convolve-then-gather layer 0: one C_0-wide row per source point (P forward, G backward)
+    float *xslab;  // ... and the [C_0][4] dW_xyz partials of its backward scatter
     size_t bytes;
 };
 
@@ -151,15 +152,15 @@ static SaScratch sa_scratch_layout(const pnpp_sa_desc *d, const SaGeom &g, void 
         need = fused > need ? fused : need;
         dwmax = need > dwmax ? need : dwmax;
     }
-    if (sa_delayed(d)) {  // the per-source-point dW_f partials and the streaming dW_xyz partials share the slab
+    if (sa_delayed(d)) {  // the per-source-point dW_f partials
         int nsplit, kp_pad;
         dw_plan(d->B * d->N, d->C[0], d->D, &nsplit, &kp_pad);
-        const size_t a = (size_t)nsplit * d->C[0] * kp_pad, b = (size_t)scatter_dz_splits(d->B * d->N) * d->C[0] * 4;
+        const size_t a = (size_t)nsplit * d->C[0] * kp_pad;
         dwmax = a > dwmax ? a : dwmax;
-        dwmax = b > dwmax ? b : dwmax;
     }
     s.dwslab = cv.take<float>(dwmax);
     s.src = cv.take<float>(sa_delayed(d) ? (size_t)d->B * d->N * d->C[0] : 0);
+    s.xslab = cv.take<float>(sa_delayed(d) ? (size_t)scatter_dz_splits(d->B * d->N) * d->C[0] * 4 : 0);
     s.bytes = cv.bytes();
     return s;
 }
@@ -192,7 +193,7 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
 
     // 1. centres and neighbours (pointnet_pp_8dir.py:23-31)
     if (d->group_all) {
-        PNPP_TRY(launch_gather_centres(a->xyz, nullptr, d->B, d->N, 1, a->new_xyz, sv.new_xyz, st));  // the origin
+        // the centres are the origin: written by the pooling launch that ends this forward (nothing in between reads them)
     } else {
         PNPP_REQUIRE(d->S <= d->N, PNPP_ERR_RANGE, "sa_forward: npoint=%d > N=%d", d->S, d->N);
         if (a->neighbour_idx) {
@@ -264,7 +265,8 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
 
     // 3. max over the neighbourhood (pointnet_pp_8dir.py:42-43)
     const int Lm = d->L - 1;
-    PNPP_TRY(launch_pool_fwd(sv.z[Lm], sv.scale[Lm], sv.shift[Lm], g.G, d->K, d->C[Lm], a->out, sv.arg, st));
+    PNPP_TRY(launch_pool_fwd(sv.z[Lm], sv.scale[Lm], sv.shift[Lm], g.G, d->K, d->C[Lm], a->out, sv.arg, st,
+                             d->group_all ? a->new_xyz : nullptr, d->group_all ? sv.new_xyz : nullptr, d->group_all ? g.G * 3 : 0));
     return PNPP_OK;
 }
 
@@ -347,8 +349,7 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
         if (l == 0 && sa_delayed(d)) {
             // G = dZ_0 summed per source point (dW_xyz = dZ_0^T (x - c) in the same pass); dW_f = G^T F, dF = G W_f
             const int R = d->B * d->N;
-            PNPP_TRY(launch_scatter_dz(dz, a2, d->B, d->S * d->K, C, sc.src, sc.dwslab, st));
-            PNPP_TRY(launch_slab_reduce(sc.dwslab, scatter_dz_splits(R), C, 4, 3, -1, a->d_conv_w[0], g.Cin[0], st));
+            PNPP_TRY(launch_scatter_dz(dz, a2, d->B, d->S * d->K, C, sc.src, sc.xslab, st));
             AOperand G, F;
             G.a = sc.src;
             G.lda = C;
@@ -356,7 +357,9 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             F.lda = d->D;
             dw_plan(R, C, d->D, &nsplit, &kp_pad);
             PNPP_TRY(launch_dw(G, C, F, d->D, R, sc.dwslab, nsplit, kp_pad, st));
-            PNPP_TRY(launch_slab_reduce(sc.dwslab, nsplit, C, kp_pad, d->D, -1, a->d_conv_w[0] + 3, g.Cin[0], st));
+            // both partial sets of W_0 -- coordinate columns 0..2, feature columns 3.. -- in one launch
+            PNPP_TRY(launch_slab_reduce2(sc.xslab, scatter_dz_splits(R), C, 4, 3, a->d_conv_w[0], g.Cin[0], sc.dwslab, nsplit, C, kp_pad,
+                                         d->D, a->d_conv_w[0] + 3, g.Cin[0], st));
             if (want_dpoints) {
                 Epilogue E;
                 E.mode = E_STORE;
