@@ -1136,8 +1136,8 @@ static bool try_launch_ws(const AOperand &A, const BOperand &B, int M, int Nout,
 // index is n: one 128-byte segment per half-wave).  Next chunk's loads fly during the MFMA loop.
 // ---------------------------------------------------------------------------------------------
 template <int AMODE, int EMODE, bool BT, int NW>
-__global__ void __launch_bounds__(NW * 64)
-gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, const Epilogue E) {
+__device__ __forceinline__ void gemm_smallm_body(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E,
+                                                 int bx, int by, int nblocks) {
     // per wave: A chunk [32][33] and weight chunk [32 n][33] (BT only); after the K loop the first NW x 1024 floats
     // are reused for the K-split partials [NW][32][32] (a wave's partial overwrites only its own A chunk)
     constexpr int NTHR = NW * 64, NJ = 1024 / NTHR;
@@ -1148,7 +1148,7 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
     float *part = lds;  // [NW][32][32], wave w at part + w * 1056: inside its own A chunk region (32*33 = 1056 floats)
     const float *__restrict__ Bm = B.b;
     const int ldb = B.ldb;
-    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int n0 = bx * 32, m0 = by * 32;
     const int nchunks = (Kd + KC - 1) / KC;
     const bool bvec = (ldb & 3) == 0 && ((uintptr_t)Bm & 15) == 0 && B.perm_D < 0 && B.rows >= 4 && (B.rows & 3) == 0;  // uniform
 
@@ -1286,7 +1286,7 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
                 T.rv[c] = (float)((1.0 - (double)T.momentum) * (double)T.rv[c] + (double)T.momentum * unbiased);
             }
         }
-        if (T.nbt && blockIdx.x == 0 && tid == 0) *T.nbt += 1;
+        if (T.nbt && bx == 0 && tid == 0) *T.nbt += 1;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -1318,7 +1318,7 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
             __syncthreads();
             if (tid == 0) {
                 const unsigned long long t = atomicAdd(&T.rng_counter[1], 1ull);
-                if (t == (unsigned long long)gridDim.x * gridDim.y - 1) {
+                if (t == (unsigned long long)nblocks - 1) {
                     T.rng_counter[1] = 0ull;
                     T.rng_counter[0] += 1ull;
                 }
@@ -1334,10 +1334,16 @@ gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, 
                 if constexpr (EMODE == E_STORE_STATS) s2 += x * x;
                 else s2 += (double)part[1024 + r * 32 + tid];
             }
-            E.slab[((size_t)blockIdx.y * 2 + 0) * Nout + n0 + tid] = s1;
-            E.slab[((size_t)blockIdx.y * 2 + 1) * Nout + n0 + tid] = s2;
+            E.slab[((size_t)by * 2 + 0) * Nout + n0 + tid] = s1;
+            E.slab[((size_t)by * 2 + 1) * Nout + n0 + tid] = s2;
         }
     }
+}
+
+template <int AMODE, int EMODE, bool BT, int NW>
+__global__ void __launch_bounds__(NW * 64)
+gemm_smallm_kernel(const AOperand A, const BOperand B, int M, int Nout, int Kd, const Epilogue E) {
+    gemm_smallm_body<AMODE, EMODE, BT, NW>(A, B, M, Nout, Kd, E, blockIdx.x, blockIdx.y, gridDim.x * gridDim.y);
 }
 
 template <int AM, int EM>
@@ -1866,15 +1872,14 @@ int launch_scatter_dz(const AOperand &dz, const AOperand &geo, int B, int Mc, in
 // MFMA tiles.  Same partial-slab output as dw_kernel (slab[split][c][kp_pad]).
 // ---------------------------------------------------------------------------------------------
 template <int DZMODE, int A2MODE>
-__global__ void __launch_bounds__(256)
-dw_lds_kernel(const AOperand dz, const AOperand a2, int M, int Nc, int Kp, int tilesC, int tilesK, int rps, int kp_pad,
-              float *__restrict__ slab) {
+__device__ __forceinline__ void dw_lds_body(const AOperand &dz, const AOperand &a2, int M, int Nc, int Kp, int tilesC, int tilesK, int rps,
+                                            int kp_pad, float *__restrict__ slab, int bx) {
     __shared__ __attribute__((aligned(16))) float Dz[32][128];
     __shared__ __attribute__((aligned(16))) float A2[32][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int tiles = tilesC * tilesK;
-    const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+    const int tile = bx % tiles, split = bx / tiles;
     const int c0 = (tile % tilesC) * 128, k0 = (tile / tilesC) * 128;
     const int r0 = min(M, split * rps), r1 = min(M, r0 + rps);  // an empty range still writes its (zero) slab block
     const int wc = wave >> 1, wk = wave & 1;
@@ -1931,6 +1936,26 @@ dw_lds_kernel(const AOperand dz, const AOperand a2, int M, int Nc, int Kp, int t
                 if (c < Nc && k < kp_pad) o[(size_t)c * kp_pad + k] = acc[i][j][r];
             }
         }
+}
+
+template <int DZMODE, int A2MODE>
+__global__ void __launch_bounds__(256)
+dw_lds_kernel(const AOperand dz, const AOperand a2, int M, int Nc, int Kp, int tilesC, int tilesK, int rps, int kp_pad,
+              float *__restrict__ slab) {
+    dw_lds_body<DZMODE, A2MODE>(dz, a2, M, Nc, Kp, tilesC, tilesK, rps, kp_pad, slab, blockIdx.x);
+}
+
+// The two products of a small-M backward layer that only share their input -- dA = dZ W (32 x 32 split-K tiles) and
+// dW = dZ^T A (LDS-staged 128 x 128 blocks) -- in ONE launch: the first g1 workgroups take the GEMM tiles, the rest
+// the dW blocks.  These launches are latency-bound, so the pair costs about as much as the longer of the two.
+template <int EMODE, int A2MODE>
+__global__ void __launch_bounds__(256)
+da_dw_kernel(const AOperand dzA, const BOperand W, int M, int Nout, int Kd, const Epilogue E, int g1x, int g1, const AOperand a2, int Nc,
+             int Kp, int tilesC, int tilesK, int rps, int kp_pad, float *__restrict__ slab) {
+    if ((int)blockIdx.x < g1)
+        gemm_smallm_body<A_PLAIN, EMODE, false, 4>(dzA, W, M, Nout, Kd, E, blockIdx.x % g1x, blockIdx.x / g1x, g1);
+    else
+        dw_lds_body<A_PLAIN, A2MODE>(dzA, a2, M, Nc, Kp, tilesC, tilesK, rps, kp_pad, slab, blockIdx.x - g1);
 }
 
 void dw_plan(int M, int Nc, int Kp, int *nsplit, int *kp_pad) {
@@ -2000,6 +2025,47 @@ int launch_dw(const AOperand &dz, int Nc, const AOperand &a2, int Kp, int M, flo
 #undef PNPP_DW
     PNPP_CHECK_LAUNCH("dw");
     return PNPP_OK;
+}
+
+// dA (+ its epilogue) and dW of one small-M backward layer in one launch; returns false (nothing launched) when the
+// pair does not fit that form, and the caller launches the two separately.
+bool try_launch_da_dw(const AOperand &dz, const BOperand &Win, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,
+                      int Kp, float *slab, int nsplit, int kp_pad, hipStream_t st, int *rc) {
+    *rc = PNPP_OK;
+    const int Nc = Kd;  // dZ is M x Nc; dA = dZ W contracts over Nc, dW is Nc x Kp
+    if (!(M > 32 && M <= 4096 && cdiv(M, 32) <= kMaxStatBlocks && dz.mode == A_PLAIN && (dz.lda & 3) == 0 && ((uintptr_t)dz.a & 15) == 0))
+        return false;
+    if (!(Nc >= 128 && Kp >= 128 && Kd % 4 == 0 && !Win.trans && (E.mode == E_STORE || E.mode == E_MASK_STATS))) return false;
+    if (!(a2.mode == A_PLAIN || a2.mode == A_BNRELU || a2.mode == A_CONCAT)) return false;
+    if (a2.mode != A_CONCAT && ((a2.lda & 3) != 0 || ((uintptr_t)a2.a & 15) != 0)) return false;
+    if (kp_pad != cdiv(Kp, 64) * 64 || nsplit < 1) return false;
+    BOperand W = Win;
+    if (W.rows <= 0 || W.rows > Kd) W.rows = Kd;
+    const int g1x = cdiv(Nout, 32), g1y = cdiv(M, 32), g1 = g1x * g1y;
+    const int tc = cdiv(Nc, 128), tk = cdiv(Kp, 128);
+    int rps = cdiv(M, nsplit);
+    rps = (rps + 7) & ~7;
+    const dim3 grid(g1 + tc * tk * nsplit);
+    if (nslab) *nslab = g1y;
+    ProfScope ps(st, "da_dw_kernel<E%d,A%d> M=%d | dA N=%d K=%d grid=%d | dW N=%d K=%d split=%d grid=%d", E.mode, a2.mode, M, Nout, Kd, g1,
+                 Nc, Kp, nsplit, tc * tk * nsplit);
+#define PNPP_DADW(EM, AM) \
+    hipLaunchKernelGGL((da_dw_kernel<EM, AM>), grid, dim3(256), 0, st, dz, W, M, Nout, Kd, E, g1x, g1, a2, Nc, Kp, tc, tk, rps, kp_pad, slab)
+    if (E.mode == E_STORE) {
+        if (a2.mode == A_PLAIN) PNPP_DADW(E_STORE, A_PLAIN);
+        else if (a2.mode == A_BNRELU) PNPP_DADW(E_STORE, A_BNRELU);
+        else PNPP_DADW(E_STORE, A_CONCAT);
+    } else {
+        if (a2.mode == A_PLAIN) PNPP_DADW(E_MASK_STATS, A_PLAIN);
+        else if (a2.mode == A_BNRELU) PNPP_DADW(E_MASK_STATS, A_BNRELU);
+        else PNPP_DADW(E_MASK_STATS, A_CONCAT);
+    }
+#undef PNPP_DADW
+    if (hipGetLastError() != hipSuccess) {
+        set_error("da_dw: launch failed");
+        *rc = PNPP_ERR_LAUNCH;
+    }
+    return true;
 }
 
 // out[c][perm(k)] = sum_s slab[s][c][k], fixed summation order: block = EPB outputs x (256/EPB) split lanes,

@@ -290,6 +290,7 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
     // layer l's weight-gradient reduction) by the post-GEMM launch that ends iteration l
     PNPP_TRY(launch_bn_finalize_bwd(sc.slab, nslab, d->C[Lm], (double)g.M, d->training, a->bn_w[Lm], sv.mean[Lm], sv.istd[Lm],
                                     sc.cst, a->d_bn_w[Lm], a->d_bn_b[Lm], a->d_conv_b[Lm], st));
+    bool dpoints_done = false;
     for (int l = Lm; l >= 0; --l) {
         const int C = d->C[l];
         AOperand dz;  // the top layer's dense gradient is never materialised (A_DZ_POOL rebuilds it from dm / arg)
@@ -322,6 +323,7 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
         int nsplit, kp_pad;
         dw_plan(g.M, C, g.Cin[l], &nsplit, &kp_pad);
         int fused_slabs = 0;
+        bool pair_done = false;
         if (l > 0) {
             // dY_{l-1} = (dZ_l * W_l) masked by ReLU'(layer l-1), with layer l-1's BN-backward sums; where the
             // weights-stationary kernel applies, dW_l = dZ_l^T * relu(bn(Z_{l-1})) is accumulated in the same launch
@@ -341,8 +343,13 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             W.b = a->conv_w[l];
             W.ldb = d->C[l - 1];
             W.rows = C;
-            int dw_slabs = 0;
-            PNPP_TRY(launch_gemm(dz, W, g.M, d->C[l - 1], C, E, &nslab_next, st, &dw_slabs));
+            int dw_slabs = 0, rc = PNPP_OK;
+            if (try_launch_da_dw(dz, W, g.M, d->C[l - 1], C, E, &nslab_next, a2, g.Cin[l], sc.dwslab, nsplit, kp_pad, st, &rc)) {
+                PNPP_TRY(rc);  // small-M level: dA and dW of this layer went out as one launch
+                pair_done = true;
+            } else {
+                PNPP_TRY(launch_gemm(dz, W, g.M, d->C[l - 1], C, E, &nslab_next, st, &dw_slabs));
+            }
             fused_slabs = dw_slabs;
         }
         const bool xyz_only = l == 0 && a2.mode == A_GATHER && d->D == 0 && dw_xyz_splits(g.M) <= nsplit * (kp_pad / 4);
@@ -356,11 +363,25 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             F.a = a->points;
             F.lda = d->D;
             dw_plan(R, C, d->D, &nsplit, &kp_pad);
-            PNPP_TRY(launch_dw(G, C, F, d->D, R, sc.dwslab, nsplit, kp_pad, st));
+            bool paired = false;
+            if (want_dpoints) {  // dW_f = G^T F and dF = G W_f only share G: one launch
+                Epilogue E;
+                E.mode = E_STORE;
+                E.c = a->dpoints;
+                E.ldc = d->D;
+                BOperand W;
+                W.b = a->conv_w[0] + 3;
+                W.ldb = g.Cin[0];
+                W.rows = C;
+                int rc = PNPP_OK;
+                paired = try_launch_da_dw(G, W, R, d->D, C, E, nullptr, F, d->D, sc.dwslab, nsplit, kp_pad, st, &rc);
+                if (paired) PNPP_TRY(rc);
+            }
+            if (!paired) PNPP_TRY(launch_dw(G, C, F, d->D, R, sc.dwslab, nsplit, kp_pad, st));
             // both partial sets of W_0 -- coordinate columns 0..2, feature columns 3.. -- in one launch
             PNPP_TRY(launch_slab_reduce2(sc.xslab, scatter_dz_splits(R), C, 4, 3, a->d_conv_w[0], g.Cin[0], sc.dwslab, nsplit, C, kp_pad,
                                          d->D, a->d_conv_w[0] + 3, g.Cin[0], st));
-            if (want_dpoints) {
+            if (want_dpoints && !paired) {
                 Epilogue E;
                 E.mode = E_STORE;
                 E.c = a->dpoints;
@@ -376,8 +397,24 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
         if (xyz_only) {  // C x 3 gradient: streaming kernel (the MFMA tiles would be 95 % padding)
             PNPP_TRY(launch_dw_xyz(dz, C, a2, g.M, sc.dwslab, st));
             nsplit = dw_xyz_splits(g.M), kp_pad = 4;
-        } else if (fused_slabs == 0) {  // dW_l = dZ_l^T * A_l as its own launch (layer 0, group_all layers, odd shapes)
-            PNPP_TRY(launch_dw(dz, C, a2, g.Cin[l], g.M, sc.dwslab, nsplit, kp_pad, st));
+        } else if (fused_slabs == 0 && !pair_done) {  // dW_l = dZ_l^T * A_l as its own launch (layer 0, group_all layers, odd shapes)
+            // group_all layer 0 with a feature gradient to return: dW_0 and dF = dZ_0 W_f only share dZ_0 -- one launch
+            bool paired0 = false;
+            if (l == 0 && want_dpoints && d->group_all) {
+                Epilogue E;
+                E.mode = E_STORE;
+                E.ldc = d->D;
+                E.c = a->dpoints;
+                BOperand W;
+                W.b = a->conv_w[0] + 3;
+                W.ldb = g.Cin[0];
+                W.rows = C;
+                int rc = PNPP_OK;
+                paired0 = try_launch_da_dw(dz, W, g.M, d->D, C, E, nullptr, a2, g.Cin[0], sc.dwslab, nsplit, kp_pad, st, &rc);
+                if (paired0) PNPP_TRY(rc);
+                dpoints_done = paired0;
+            }
+            if (!paired0) PNPP_TRY(launch_dw(dz, C, a2, g.Cin[l], g.M, sc.dwslab, nsplit, kp_pad, st));
         }
         if (l > 0) {  // reduce dW_l's partials and finalise layer l-1's BatchNorm-backward sums in one launch
             const int Cp = d->C[l - 1];
@@ -402,7 +439,7 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             W.rows = C;
             if (d->group_all) {  // rows are the points themselves
                 E.c = a->dpoints;
-                PNPP_TRY(launch_gemm(dz, W, g.M, d->D, C, E, nullptr, st));
+                if (!dpoints_done) PNPP_TRY(launch_gemm(dz, W, g.M, d->D, C, E, nullptr, st));
             } else {
                 E.c = sc.dy[cur ^ 1];
                 PNPP_TRY(launch_gemm(dz, W, g.M, d->D, C, E, nullptr, st));
