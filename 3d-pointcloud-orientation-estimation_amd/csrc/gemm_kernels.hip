@@ -2311,15 +2311,96 @@ __device__ __forceinline__ void bn_finalize_bwd_block(const BnFinalizeBwdArgs &F
     if (F.dbias) F.dbias[c] = F.training ? 0.f : (float)((double)cst[c] * s1);
 }
 
-__global__ void __launch_bounds__(256) bn_finalize_bwd_kernel(BnFinalizeBwdArgs F) { bn_finalize_bwd_block(F, blockIdx.x); }
+// Small-M levels materialise dZ once per layer (dz_materialize_kernel).  The BatchNorm-backward constants it needs are
+// a 32-slab column reduction, so the workgroups that write dZ redo that reduction for their own 64 columns (in their
+// own fixed order: the constants can differ from `cst` in the last float32 bit, deterministically) and the materialisation rides in the launch that finalises: no
+// launch of its own, no wait for `cst`.
+struct DzJob {
+    const float *dy = nullptr;   // masked upstream gradient (M x C), or the pooled gradient (G x C) when arg != nullptr
+    const float *z = nullptr;    // pre-BN activations (M x C)
+    const int32_t *arg = nullptr;  // pooled form: arg-max neighbour per (group, channel)
+    int K = 1;                   // pooled form: rows per group
+    int M = 0;
+    float *out = nullptr;        // dZ (M x C); nullptr = no job
+};
+
+__device__ __forceinline__ void dz_fused_block(const BnFinalizeBwdArgs &F, const DzJob &J, int bid) {
+    __shared__ double red[4][2][64];
+    __shared__ float kc[5][64];  // g, mu, istd, c1, c2 of this block's 64 columns
+    const int C = F.C, ncg = (C + 63) / 64;
+    const int c0 = (bid % ncg) * 64, r0 = (bid / ncg) * 64;
+    {   // column sums of the slabs: 64 columns x 4 slab lanes, every load of a lane in flight at once, lanes combined in order
+        const int cl = threadIdx.x & 63, q = threadIdx.x >> 6, c = min(c0 + cl, C - 1);
+        double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+        int sidx = q;
+#pragma unroll 4
+        for (; sidx + 4 < F.nslab; sidx += 8) {
+            a1 += F.slab[((size_t)sidx * 2 + 0) * C + c];
+            a2 += F.slab[((size_t)sidx * 2 + 1) * C + c];
+            b1 += F.slab[((size_t)(sidx + 4) * 2 + 0) * C + c];
+            b2 += F.slab[((size_t)(sidx + 4) * 2 + 1) * C + c];
+        }
+        for (; sidx < F.nslab; sidx += 4) {
+            a1 += F.slab[((size_t)sidx * 2 + 0) * C + c];
+            a2 += F.slab[((size_t)sidx * 2 + 1) * C + c];
+        }
+        red[q][0][cl] = a1 + b1;
+        red[q][1][cl] = a2 + b2;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const double s1 = (red[0][0][cl] + red[1][0][cl]) + (red[2][0][cl] + red[3][0][cl]);
+            const double s2 = (red[0][1][cl] + red[1][1][cl]) + (red[2][1][cl] + red[3][1][cl]);
+            const float g = F.gamma ? F.gamma[c] : 1.f;
+            kc[0][cl] = g * F.istd[c];
+            kc[1][cl] = F.mean[c];
+            kc[2][cl] = F.istd[c];
+            kc[3][cl] = F.training ? (float)(s1 / F.count) : 0.f;
+            kc[4][cl] = F.training ? (float)(s2 / F.count) : 0.f;
+        }
+        __syncthreads();
+    }
+    const int q4 = 4 * (threadIdx.x & 15), c = c0 + q4;
+    if (c >= C) return;
+    const float4 g = *reinterpret_cast<const float4 *>(&kc[0][q4]), mu = *reinterpret_cast<const float4 *>(&kc[1][q4]);
+    const float4 is = *reinterpret_cast<const float4 *>(&kc[2][q4]), c1 = *reinterpret_cast<const float4 *>(&kc[3][q4]);
+    const float4 c2 = *reinterpret_cast<const float4 *>(&kc[4][q4]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = r0 + (threadIdx.x >> 4) + 16 * i;
+        if (row >= J.M) continue;
+        const float4 z = *reinterpret_cast<const float4 *>(J.z + (size_t)row * C + c);
+        float4 dy;
+        if (J.arg) {
+            const int grp = row / J.K, kk = row - grp * J.K;
+            const float4 dm = *reinterpret_cast<const float4 *>(J.dy + (size_t)grp * C + c);
+            const int4 ia = *reinterpret_cast<const int4 *>(J.arg + (size_t)grp * C + c);
+            dy = make_float4(kk == ia.x ? dm.x : 0.f, kk == ia.y ? dm.y : 0.f, kk == ia.z ? dm.z : 0.f, kk == ia.w ? dm.w : 0.f);
+        } else {
+            dy = *reinterpret_cast<const float4 *>(J.dy + (size_t)row * C + c);
+        }
+        float4 o;  // the operand loaders' formula (xform_a4<A_DZ>)
+        o.x = g.x * (dy.x - c1.x - (z.x - mu.x) * is.x * c2.x);
+        o.y = g.y * (dy.y - c1.y - (z.y - mu.y) * is.y * c2.y);
+        o.z = g.z * (dy.z - c1.z - (z.z - mu.z) * is.z * c2.z);
+        o.w = g.w * (dy.w - c1.w - (z.w - mu.w) * is.w * c2.w);
+        *reinterpret_cast<float4 *>(J.out + (size_t)row * C + c) = o;
+    }
+}
+static inline int dz_job_blocks(const DzJob &J, int C) { return J.out ? ((C + 63) / 64) * ((J.M + 63) / 64) : 0; }
+
+__global__ void __launch_bounds__(256) bn_finalize_bwd_kernel(BnFinalizeBwdArgs F, int nfin, DzJob J) {
+    if ((int)blockIdx.x < nfin) bn_finalize_bwd_block(F, blockIdx.x);
+    else dz_fused_block(F, J, blockIdx.x - nfin);
+}
 
 // the two reductions that follow a backward GEMM -- the weight-gradient partials of layer l and the BatchNorm-backward
 // column sums of layer l-1 -- share one launch: the first nfin workgroups finalise, the rest reduce slabs
 template <int EPB, bool V4 = false>
-__global__ void __launch_bounds__(256) post_gemm_kernel(BnFinalizeBwdArgs F, int nfin, SlabReduceArgs R) {
+__global__ void __launch_bounds__(256) post_gemm_kernel(BnFinalizeBwdArgs F, int nfin, SlabReduceArgs R, int ndz, DzJob J) {
     if ((int)blockIdx.x < nfin) bn_finalize_bwd_block(F, blockIdx.x);
-    else if constexpr (V4) slab_reduce_block4<EPB>(R, blockIdx.x - nfin);
-    else slab_reduce_block<EPB>(R, blockIdx.x - nfin);
+    else if ((int)blockIdx.x < nfin + ndz) dz_fused_block(F, J, blockIdx.x - nfin);
+    else if constexpr (V4) slab_reduce_block4<EPB>(R, blockIdx.x - nfin - ndz);
+    else slab_reduce_block<EPB>(R, blockIdx.x - nfin - ndz);
 }
 
 int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, const float *bias, const float *gamma,
@@ -2332,32 +2413,45 @@ int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, c
     return PNPP_OK;
 }
 
+static DzJob make_dz_job(const AOperand *dz, int M, int C, float *out) {
+    DzJob J;
+    if (dz && out && (C & 3) == 0 && dz->lda == C && (dz->mode == A_DZ || dz->mode == A_DZ_POOL)) {
+        J.dy = dz->a, J.z = dz->z, J.M = M, J.out = out;
+        if (dz->mode == A_DZ_POOL) J.arg = dz->arg, J.K = dz->K;
+    }
+    return J;
+}
+
 int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, int training, const float *gamma,
                            const float *mean, const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias,
-                           hipStream_t st) {
+                           hipStream_t st, const AOperand *dz, int M, float *dz_out) {
     const BnFinalizeBwdArgs F{slab, nslab, C, count, training, gamma, mean, istd, cst, dgamma, dbeta, dbias};
-    ProfScope ps(st, "bn_finalize_bwd_kernel C=%d", C);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, st, F);
+    const DzJob J = make_dz_job(dz, M, C, dz_out);
+    const int nfin = cdiv(C, FIN_COLS), ndz = dz_job_blocks(J, C);
+    ProfScope ps(st, "bn_finalize_bwd_kernel C=%d%s", C, ndz ? " +dZ" : "");
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(nfin + ndz), dim3(256), 0, st, F, nfin, J);
     PNPP_CHECK_LAUNCH("bn_finalize_bwd");
     return PNPP_OK;
 }
 
 int launch_post_gemm(const double *slab, int nslab, int C, double count, int training, const float *gamma, const float *mean,
                      const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias, const float *dwslab, int nsplit,
-                     int Nc, int kp_pad, int Kvalid, int perm_D, float *dw, int ldo, hipStream_t st) {
+                     int Nc, int kp_pad, int Kvalid, int perm_D, float *dw, int ldo, hipStream_t st, const AOperand *dz, int M,
+                     float *dz_out) {
     const BnFinalizeBwdArgs F{slab, nslab, C, count, training, gamma, mean, istd, cst, dgamma, dbeta, dbias};
     const SlabReduceArgs R{dwslab, nsplit, Nc, kp_pad, Kvalid, perm_D, dw, ldo};
-    const int total = Nc * Kvalid, nfin = cdiv(C, FIN_COLS);
-    ProfScope ps(st, "post_gemm_kernel C=%d | N=%d K=%d split=%d", C, Nc, Kvalid, nsplit);
+    const DzJob J = make_dz_job(dz, M, C, dz_out);
+    const int total = Nc * Kvalid, nfin = cdiv(C, FIN_COLS), ndz = dz_job_blocks(J, C), nf = nfin + ndz;
+    ProfScope ps(st, "post_gemm_kernel C=%d%s | N=%d K=%d split=%d", C, ndz ? " +dZ" : "", Nc, Kvalid, nsplit);
     if (slab_reduce_vec4(R)) {
         const int groups = total / 4, epb = slab_reduce_epb4(nsplit);
-        if (epb == 64) hipLaunchKernelGGL((post_gemm_kernel<64, true>), dim3(nfin + cdiv(groups, 64)), dim3(256), 0, st, F, nfin, R);
-        else if (epb == 16) hipLaunchKernelGGL((post_gemm_kernel<16, true>), dim3(nfin + cdiv(groups, 16)), dim3(256), 0, st, F, nfin, R);
-        else hipLaunchKernelGGL((post_gemm_kernel<4, true>), dim3(nfin + cdiv(groups, 4)), dim3(256), 0, st, F, nfin, R);
+        if (epb == 64) hipLaunchKernelGGL((post_gemm_kernel<64, true>), dim3(nf + cdiv(groups, 64)), dim3(256), 0, st, F, nfin, R, ndz, J);
+        else if (epb == 16) hipLaunchKernelGGL((post_gemm_kernel<16, true>), dim3(nf + cdiv(groups, 16)), dim3(256), 0, st, F, nfin, R, ndz, J);
+        else hipLaunchKernelGGL((post_gemm_kernel<4, true>), dim3(nf + cdiv(groups, 4)), dim3(256), 0, st, F, nfin, R, ndz, J);
     } else if (slab_reduce_wide(total, nsplit))
-        hipLaunchKernelGGL(post_gemm_kernel<64>, dim3(nfin + cdiv(total, 64)), dim3(256), 0, st, F, nfin, R);
+        hipLaunchKernelGGL(post_gemm_kernel<64>, dim3(nf + cdiv(total, 64)), dim3(256), 0, st, F, nfin, R, ndz, J);
     else
-        hipLaunchKernelGGL(post_gemm_kernel<16>, dim3(nfin + cdiv(total, 16)), dim3(256), 0, st, F, nfin, R);
+        hipLaunchKernelGGL(post_gemm_kernel<16>, dim3(nf + cdiv(total, 16)), dim3(256), 0, st, F, nfin, R, ndz, J);
     PNPP_CHECK_LAUNCH("post_gemm");
     return PNPP_OK;
 }

@@ -125,12 +125,14 @@ int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, c
                            float *mean, float *istd, float *scale, float *shift, hipStream_t st);
 int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, int training, const float *gamma,
                            const float *mean, const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias,
-                           hipStream_t st);
+                           hipStream_t st, const AOperand *dz = nullptr, int M = 0, float *dz_out = nullptr);
 
 // bn_finalize_bwd of one layer and the weight-gradient slab reduction of the layer above it, in one launch
+// dz / M / dz_out (optional): also materialise dZ = BN-backward(dz operand) of the layer being finalised (small-M levels)
 int launch_post_gemm(const double *slab, int nslab, int C, double count, int training, const float *gamma, const float *mean,
                      const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias, const float *dwslab, int nsplit,
-                     int Nc, int kp_pad, int Kvalid, int perm_D, float *dw, int ldo, hipStream_t st);
+                     int Nc, int kp_pad, int Kvalid, int perm_D, float *dw, int ldo, hipStream_t st, const AOperand *dz = nullptr, int M = 0,
+                     float *dz_out = nullptr);
 
 int launch_pool_fwd(const float *z, const float *scale, const float *shift, int G, int K, int C, float *out, int32_t *arg,
                     hipStream_t st, float *origin_a = nullptr, float *origin_b = nullptr, int norigin = 0);

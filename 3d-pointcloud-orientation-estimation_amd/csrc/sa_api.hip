@@ -288,22 +288,32 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
                              d->C[Lm], sc.dm, sc.slab, &nslab, st));
     // sc.cst holds the BatchNorm-backward constants of the layer being processed; layer l-1's are produced (together with
     // layer l's weight-gradient reduction) by the post-GEMM launch that ends iteration l
+    // small-M levels materialise dZ once per layer; that pass rides in the launch that finalises the layer's BatchNorm sums
+    const bool small = g.M <= kSmallM;
+    auto dz_operand = [&](int l, int buf) {
+        AOperand dz;  // the top layer's dense gradient is never materialised (A_DZ_POOL rebuilds it from dm / arg)
+        dz.mode = l == Lm ? A_DZ_POOL : A_DZ;
+        dz.a = l == Lm ? sc.dm : sc.dy[buf];
+        dz.arg = sv.arg;
+        dz.K = d->K;
+        dz.lda = d->C[l];
+        dz.z = sv.z[l];
+        dz.cst = sc.cst;
+        dz.C = d->C[l];
+        return dz;
+    };
+    const AOperand dz_top = dz_operand(Lm, 0);
     PNPP_TRY(launch_bn_finalize_bwd(sc.slab, nslab, d->C[Lm], (double)g.M, d->training, a->bn_w[Lm], sv.mean[Lm], sv.istd[Lm],
-                                    sc.cst, a->d_bn_w[Lm], a->d_bn_b[Lm], a->d_conv_b[Lm], st));
+                                    sc.cst, a->d_bn_w[Lm], a->d_bn_b[Lm], a->d_conv_b[Lm], st, small ? &dz_top : nullptr, g.M,
+                                    small ? sc.dzbuf : nullptr));
+    bool dz_ready = small;  // sc.dzbuf holds dZ of the layer about to be processed
     bool dpoints_done = false;
     for (int l = Lm; l >= 0; --l) {
         const int C = d->C[l];
-        AOperand dz;  // the top layer's dense gradient is never materialised (A_DZ_POOL rebuilds it from dm / arg)
-        dz.mode = l == Lm ? A_DZ_POOL : A_DZ;
-        dz.a = l == Lm ? sc.dm : sc.dy[cur];
-        dz.arg = sv.arg;
-        dz.K = d->K;
-        dz.lda = C;
-        dz.z = sv.z[l];
-        dz.cst = sc.cst;
-        dz.C = C;
-        if (g.M <= kSmallM) {  // every consumer would rebuild dZ per 32 x 32 tile: write it out once instead
-            PNPP_TRY(launch_dz_materialize(dz, g.M, C, sc.dzbuf, st));
+        AOperand dz = dz_operand(l, cur);
+        if (small) {  // every consumer would rebuild dZ per 32 x 32 tile: it was written out once instead
+            if (!dz_ready) PNPP_TRY(launch_dz_materialize(dz, g.M, C, sc.dzbuf, st));
+            dz_ready = false;
             dz = AOperand();
             dz.mode = A_PLAIN;
             dz.a = sc.dzbuf;
@@ -418,10 +428,13 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
         }
         if (l > 0) {  // reduce dW_l's partials and finalise layer l-1's BatchNorm-backward sums in one launch
             const int Cp = d->C[l - 1];
+            const AOperand dz_next = dz_operand(l - 1, cur ^ 1);  // dY_{l-1} was just written to sc.dy[cur ^ 1]
             PNPP_TRY(launch_post_gemm(sc.slab, nslab_next, Cp, (double)g.M, d->training, a->bn_w[l - 1], sv.mean[l - 1],
                                       sv.istd[l - 1], sc.cst, a->d_bn_w[l - 1], a->d_bn_b[l - 1],
                                       a->d_conv_b[l - 1], sc.dwslab, fused_slabs > 0 ? fused_slabs : nsplit, C,
-                                      fused_slabs > 0 ? Cp : kp_pad, g.Cin[l], -1, a->d_conv_w[l], g.Cin[l], st));
+                                      fused_slabs > 0 ? Cp : kp_pad, g.Cin[l], -1, a->d_conv_w[l], g.Cin[l], st,
+                                      small ? &dz_next : nullptr, g.M, small ? sc.dzbuf : nullptr));
+            dz_ready = small;
         } else {
             PNPP_TRY(launch_slab_reduce(sc.dwslab, nsplit, C, kp_pad, g.Cin[l], d->D, a->d_conv_w[l], g.Cin[l], st));
         }
