@@ -354,7 +354,8 @@ __global__ void __launch_bounds__(64) soft_ce_kernel(const float *__restrict__ l
 }
 
 // ---- flat-buffer Adam (torch.optim.Adam defaults: no amsgrad, no weight decay) ---------------------
-__global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+template <bool ZERO>
+__global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                    float *__restrict__ v, size_t n, float lr_over_bc1, float inv_sqrt_bc2,
                                                    float b1, float b2, float eps, float gscale) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -364,6 +365,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const 
         m[i] = mi;
         v[i] = vi;
         p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        if (ZERO) g[i] = 0.f;  // the next iteration's opt.zero_grad(), folded in
     }
 }
 
@@ -691,9 +693,21 @@ extern "C" int pnpp_adam_step(float *param, const float *grad, float *exp_avg, f
     PNPP_REQUIRE(n > 0 && step > 0, PNPP_ERR_ARG, "adam_step: n and step must be positive");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
-                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale);
+    hipLaunchKernelGGL(adam_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), param, const_cast<float *>(grad), exp_avg,
+                       exp_avg_sq, n, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale);
     PNPP_CHECK_LAUNCH("adam_step");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_adam_step_zero(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, int step, float lr,
+                                   float beta1, float beta2, float eps, float grad_scale, void *stream) {
+    PNPP_REQUIRE(param && grad && exp_avg && exp_avg_sq, PNPP_ERR_ARG, "adam_step_zero: null pointer");
+    PNPP_REQUIRE(n > 0 && step > 0, PNPP_ERR_ARG, "adam_step_zero: n and step must be positive");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(adam_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale);
+    PNPP_CHECK_LAUNCH("adam_step_zero");
     return PNPP_OK;
 }
 

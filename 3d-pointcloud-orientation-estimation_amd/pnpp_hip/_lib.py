@@ -106,6 +106,7 @@ SIGNATURES = {
     "pnpp_add_layernorm_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp, _fp, _fp, _fp]),
     "pnpp_mean_points_bwd": (_i, [_fp, _i, _i, _i, _fp, _fp]),
     "pnpp_adam_step": (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _f, _f, _f, _f, _fp]),
+    "pnpp_adam_step_zero": (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _f, _f, _f, _f, _fp]),
     "pnpp_adam_step_dev": (_i, [_fp, _fp, _fp, _fp, _sz, _fp, _f, _f, _f, _f, _f, _i, _fp]),
     "pnpp_sumsq": (_i, [_fp, _sz, _fp, _fp, _sz, _fp]),
 }

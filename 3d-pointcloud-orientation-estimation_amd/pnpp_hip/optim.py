@@ -84,11 +84,13 @@ class FlatAdam:
         self._pending_scale = min(1.0, max_norm / (norm + 1e-6))
         return norm
 
-    def step(self, grad_scale: float = 1.0) -> None:
+    def step(self, grad_scale: float = 1.0, zero_grad: bool = False) -> None:
+        """zero_grad=True clears the flat gradient buffer in the same launch (the next iteration's zero_grad())."""
         self.step_count += 1
         scale = grad_scale * getattr(self, "_pending_scale", 1.0)
         self._pending_scale = 1.0
-        L.check(L.lib().pnpp_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+        fn = L.lib().pnpp_adam_step_zero if zero_grad else L.lib().pnpp_adam_step
+        L.check(fn(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                                        self.exp_avg_sq.data_ptr(), self.flat_p.numel(), self.step_count, self.lr,
                                        self.betas[0], self.betas[1], self.eps, float(scale), _stream()))
 

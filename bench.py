@@ -73,7 +73,8 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
             # the batch is resident: no staging copy.  The Adam launch stays eager: PNPP_CAPTURED_ADAM=1 captures it too
             # (device-side step count), measured 2.5 % slower -- DESIGN.md 9
             graphed = GraphedStep(opt, loss_fn, [xyz, mu_gt, kappa_gt], adopt_inputs=True,
-                                  fused_optimizer=(world == 1 and os.environ.get("PNPP_CAPTURED_ADAM") == "1"))
+                                  fused_optimizer=(world == 1 and os.environ.get("PNPP_CAPTURED_ADAM") == "1"),
+                                  zero_grad_in_graph=False)   # the eager Adam launch clears the gradients it has consumed
         except Exception as e:  # capture is an optimisation, never a requirement
             print(f"[bench] hipGraph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr)
             graphed = None
@@ -94,12 +95,12 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
                 loss.backward()
         if collective:   # the instrumented roofline pass runs on rank 0 alone: it must not enter a collective
             pdist.all_reduce_flat_grad(opt.flat_g)
-        opt.step(grad_scale=1.0 / world)
+        opt.step(grad_scale=1.0 / world, zero_grad=graphed is not None)
         return loss
 
     mode = ("two hipGraphs (fwd + sa3/head bwd | sa2/sa1 bwd) with the bucketed all-reduce overlapped + eager Adam" if split is not None
             else "hipGraph(fwd+loss+bwd+Adam, gradients cleared by the update)" if graphed is not None and graphed.fused_optimizer
-            else "hipGraph(zero_grad+fwd+loss+bwd) + eager all-reduce/Adam" if graphed is not None else "eager")
+            else "hipGraph(fwd+loss+bwd) + eager all-reduce/Adam (the update clears the gradients)" if graphed is not None else "eager")
     return step, mode
 
 

@@ -311,6 +311,10 @@ int pnpp_mean_points_bwd(const float *dy, int B, int N, int E, float *dx, void *
 /* torch.optim.Adam(lr, betas, eps, weight_decay=0) single fused update; step is 1-based. */
 int pnpp_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, int step, float lr,
                    float beta1, float beta2, float eps, float grad_scale, void *stream);
+/* The same update, clearing each gradient once it has been consumed: the opt.zero_grad() of the next iteration
+ * (train_single_peak_vonMises_KL.py:80) folded into the optimiser launch. */
+int pnpp_adam_step_zero(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, int step, float lr,
+                        float beta1, float beta2, float eps, float grad_scale, void *stream);
 
 /* The same update for launches captured in a hipGraph: the step count lives in device memory (step_state[0] = steps
  * taken so far, step_state[1] = ticket word, both zero-initialised by the caller) and is advanced by the launch

@@ -238,7 +238,8 @@ def test_flat_adam_matches_torch_adam(oracle):
         if it == 1:   # gradient norm helper (train_multi_peaks_vonMises_KL.py:235)
             ref = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m1.parameters()))   # the helper's own gradients
             assert abs(float(o1.grad_norm()) - float(ref)) < 1e-5 * float(ref)
-        o1.step(), o2.step(), o3.step()
+        o1.step(), o2.step(), o3.step(zero_grad=True)           # o3: the update also clears the gradients it consumed
+        assert float(o3.flat_g.abs().max()) == 0.0 and float(o1.flat_g.abs().max()) > 0.0
         for (n, a), b, c in zip(m1.named_parameters(), m2.parameters(), m3.parameters()):
             assert torch.equal(a, c), n
             if it == 0:                                           # later steps: see the docstring
