@@ -161,6 +161,83 @@ __global__ void __launch_bounds__(256) vm_head_kl_mean_kernel(const float *__res
     if (threadIdx.x == 0) *loss_mean = (float)(red[0] * inv_b);
 }
 
+// The whole tail of the single-peak training step in ONE single-workgroup launch: o = x W^T + b (the model's fc3,
+// pointnet_pp_vonMises.py:35), head activations, KL, batch mean (train_single_peak_vonMises_KL.py:82-84) and their
+// backward -- d loss / d W, d b and d x.  x: (B, K) features, W: (2, K).  Eager PyTorch terms: a Linear, the head,
+// the loss, a mean and seven autograd nodes.  The mean is a fixed-order fp64 tree; everything is deterministic.
+__global__ void __launch_bounds__(256)
+vm_fc_head_kl_step_kernel(const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ bias,
+                          const float *__restrict__ mu_gt, const float *__restrict__ kappa_gt, int B, int K, int x_in_lds,
+                          float *__restrict__ loss_mean, float *__restrict__ dW, float *__restrict__ db, float *__restrict__ dx) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // o[B][2] (then d_o in place), xs[B][K] when it fits
+    __shared__ double red[256];
+    float *o = sm;
+    float *xs = sm + ((2 * B + 3) & ~3);
+    const int tid = threadIdx.x;
+    const float *xr = x;  // where the features are read from after staging
+    if (x_in_lds) {       // one pass of independent 16-byte loads; every later read of x is an LDS read
+        const int n4 = (B * K) >> 2;
+        for (int f = tid; f < n4; f += 256) reinterpret_cast<float4 *>(xs)[f] = reinterpret_cast<const float4 *>(x)[f];
+        xr = xs;
+    }
+    __syncthreads();
+    // 1. o = x W^T + b: eight lanes per row, each a strided eighth of the features
+    const int part8 = tid & 7;
+    for (int i = tid >> 3; i < ((B + 31) & ~31); i += 32) {
+        const int ic = min(i, B - 1);
+        float a0 = 0.f, a1 = 0.f;
+        for (int k = part8; k < K; k += 8) {
+            const float xv = xr[(size_t)ic * K + k];
+            a0 = fmaf(xv, W[k], a0), a1 = fmaf(xv, W[K + k], a1);
+        }
+#pragma unroll
+        for (int m = 4; m >= 1; m >>= 1) a0 += __shfl_xor(a0, m), a1 += __shfl_xor(a1, m);
+        if (part8 == 0 && i < B) o[2 * i] = a0 + bias[0], o[2 * i + 1] = a1 + bias[1];
+    }
+    __syncthreads();
+    // 2. head + KL + mean; d loss / d o overwrites o
+    const double inv_b = 1.0 / (double)B;
+    double part = 0.0;
+    for (int i = tid; i < B; i += 256) {
+        const double o0 = (double)o[2 * i], o1 = (double)o[2 * i + 1];
+        const double th = tanh(o0);
+        const float mu_f = (float)(th * kPi);
+        const double sp = o1 > 20.0 ? o1 : log1p(exp(o1));
+        const float kap_f = (float)sp;
+        double v, a, b;
+        kl_single_eval((double)mu_f, (double)kap_f, (double)mu_gt[i], (double)kappa_gt[i], v, a, b);
+        part += (double)(float)v;
+        const double sig = o1 > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-o1));
+        o[2 * i] = (float)(a * kPi * (1.0 - th * th) * inv_b);
+        o[2 * i + 1] = (float)(b * sig * inv_b);
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) *loss_mean = (float)(red[0] * inv_b);
+    // 3. dW = d_o^T x, db = column sums of d_o, dx = d_o W: one thread per feature, rows in order
+    for (int k = tid; k < K; k += 256) {
+        const float w0 = W[k], w1 = W[K + k];
+        float g0 = 0.f, g1 = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < B; ++i) {
+            const float d0 = o[2 * i], d1 = o[2 * i + 1];
+            const float xv = xr[(size_t)i * K + k];
+            g0 = fmaf(d0, xv, g0), g1 = fmaf(d1, xv, g1);
+            if (dx) dx[(size_t)i * K + k] = fmaf(d0, w0, d1 * w1);
+        }
+        dW[k] = g0, dW[K + k] = g1;
+    }
+    if (tid < 2) {
+        float g = 0.f;
+        for (int i = 0; i < B; ++i) g += o[2 * i + tid];
+        db[tid] = g;
+    }
+}
+
 __global__ void __launch_bounds__(256) vm_head_bwd_kernel(const float *__restrict__ o, const float *__restrict__ dmu,
                                                           const float *__restrict__ dkappa, int B, float *__restrict__ d_o) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -574,6 +651,19 @@ extern "C" int pnpp_vm_head_kl(const float *o, const float *mu_gt, const float *
     hipLaunchKernelGGL(vm_head_kl_kernel, dim3(cdiv(B, 256)), dim3(256), 0, as_stream(stream), o, mu_gt, kappa_gt, B, mu, kappa,
                        loss_vec, d_o);
     PNPP_CHECK_LAUNCH("vm_head_kl");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_vm_fc_head_kl_step(const float *x, const float *w, const float *b, const float *mu_gt, const float *kappa_gt, int B,
+                                       int K, float *loss_mean, float *dw, float *db, float *dx, void *stream) {
+    PNPP_REQUIRE(x && w && b && mu_gt && kappa_gt && loss_mean && dw && db, PNPP_ERR_ARG, "vm_fc_head_kl_step: null pointer");
+    PNPP_REQUIRE(B > 0 && K > 0 && B <= 8192, PNPP_ERR_ARG, "vm_fc_head_kl_step: B must be in 1..8192 and K positive");
+    const size_t o_floats = ((size_t)2 * B + 3) & ~(size_t)3;
+    const int x_in_lds = ((size_t)B * K <= 12288 && (((size_t)B * K) & 3) == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;  // <= 48 KB
+    const size_t lds = (o_floats + (x_in_lds ? (size_t)B * K : 0)) * sizeof(float);
+    hipLaunchKernelGGL(vm_fc_head_kl_step_kernel, dim3(1), dim3(256), lds, as_stream(stream), x, w, b, mu_gt, kappa_gt, B, K, x_in_lds,
+                       loss_mean, dw, db, dx);
+    PNPP_CHECK_LAUNCH("vm_fc_head_kl_step");
     return PNPP_OK;
 }
 

@@ -555,6 +555,31 @@ def vm_head_kl_loss_backward(o, mu_gt, kappa_gt) -> torch.Tensor:
     return loss
 
 
+def vm_fc_head_kl_loss_backward(x, linear, mu_gt, kappa_gt) -> torch.Tensor:
+    """`o = linear(x)` (the model's fc3, two outputs), head, single-peak KL, `.mean()` and `loss.backward()` in ONE launch
+    (pointnet_pp_vonMises.py:35-37 + train_single_peak_vonMises_KL.py:82-84): the gradients of `linear` land in its
+    .grad (or the optimiser's flat buffer), the gradient of x seeds the rest of the backward pass.  Returns the
+    detached mean loss.  Equals vm_head_kl_loss_backward(fc_block(x, linear), ...) to float32 rounding."""
+    x32, mu_gt, kappa_gt = _f32(x, "x"), _f32(mu_gt, "mu_gt"), _f32(kappa_gt, "kappa_gt")
+    w, b = _f32(linear.weight, "weight"), _f32(linear.bias, "bias")
+    B, K = x32.shape
+    if w.shape != (2, K) or b.numel() != 2 or mu_gt.numel() != B or kappa_gt.numel() != B:
+        raise ValueError("vm_fc_head_kl_loss_backward: linear must map K -> 2 and the targets must be (B,)")
+    loss = torch.empty((), device=x32.device, dtype=torch.float32)
+    sinks = [getattr(p, "_pnpp_grad_sink", None) for p in (linear.weight, linear.bias)]
+    dw = sinks[0] if sinks[0] is not None else torch.empty_like(w)
+    db = sinks[1] if sinks[1] is not None else torch.empty_like(b)
+    dx = torch.empty_like(x32) if x.requires_grad else None
+    L.check(L.lib().pnpp_vm_fc_head_kl_step(x32.data_ptr(), w.data_ptr(), b.data_ptr(), mu_gt.data_ptr(), kappa_gt.data_ptr(), B, K,
+                                            loss.data_ptr(), dw.data_ptr(), db.data_ptr(), _p(dx), _stream()))
+    for p, g, sink in ((linear.weight, dw, sinks[0]), (linear.bias, db, sinks[1])):
+        if sink is None and p.requires_grad:                     # plain autograd semantics: accumulate into .grad
+            p.grad = g.view_as(p) if p.grad is None else p.grad + g.view_as(p)
+    if dx is not None:
+        torch.autograd.backward([x], [dx])
+    return loss
+
+
 class _MatchLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mu, kappa, w, vm_gt, K_gt):

@@ -220,6 +220,11 @@ int pnpp_fc_backward(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, void *str
  * d_o (B,2) = d loss_vec[b] / d o[b,:]  (the host scales by the upstream gradient, 1/B for .mean()). */
 int pnpp_vm_head_kl(const float *o, const float *mu_gt, const float *kappa_gt, int B, float *mu, float *kappa,
                     float *loss_vec, float *d_o, void *stream);
+/* The whole tail of the single-peak step in one launch: o = x W^T + b (the model's fc3: pointnet_pp_vonMises.py:35,
+ * W is (2,K)), head activations, KL, .mean() (train_single_peak_vonMises_KL.py:82-84) and their backward:
+ * loss_mean[0], dw (2,K), db (2), dx (B,K; may be NULL).  Gradients are written, not accumulated. */
+int pnpp_vm_fc_head_kl_step(const float *x, const float *w, const float *b, const float *mu_gt, const float *kappa_gt, int B,
+                            int K, float *loss_mean, float *dw, float *db, float *dx, void *stream);
 /* The same, followed by the batch mean of train_single_peak_vonMises_KL.py:83 (`loss = kl_von_mises(...).mean()`),
  * in one single-workgroup launch: loss_mean[0] = mean_b loss_vec[b] (fixed-order fp64 sum),
  * d_o_mean (B,2) = d loss_mean / d o.  mu, kappa and loss_vec may be NULL. */

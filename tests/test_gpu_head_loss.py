@@ -287,3 +287,36 @@ def test_vm_head_kl_loss_backward_equals_autograd(ops):
     loss_b = ops.vm_head_kl_loss_backward(lin(x), mu_gt, kap_gt)
     assert not loss_b.requires_grad and float(loss_b) == float(loss_a)
     assert torch.equal(lin.weight.grad, ga) and torch.equal(lin.bias.grad, gb)
+
+
+@pytest.mark.parametrize("B,K", [(32, 256), (7, 64), (300, 260)])
+def test_vm_fc_head_kl_loss_backward_equals_the_unfused_ops(ops, B, K):
+    """fc3 + head + KL + mean + backward in one launch vs Linear (fc_block) -> vm_head_kl_loss_backward and vs float64
+    autograd of the reference's expressions (pointnet_pp_vonMises.py:35-37, train_single_peak_vonMises_KL.py:82-84)."""
+    torch.manual_seed(B)
+    lin = nn.Linear(K, 2).cuda()
+    x = torch.randn(B, K, device="cuda")
+    mu_gt = (torch.rand(B, device="cuda") * 2 - 1) * 3.1
+    kappa_gt = torch.rand(B, device="cuda") * 30 + 0.5
+    xa = x.clone().requires_grad_(True)
+    la = ops.vm_fc_head_kl_loss_backward(xa, lin, mu_gt, kappa_gt)
+    ga = (lin.weight.grad.clone(), lin.bias.grad.clone(), xa.grad.clone())
+    lin.zero_grad(set_to_none=True)
+    xb = x.clone().requires_grad_(True)
+    lb = ops.vm_head_kl_loss_backward(ops.fc_block(xb, lin, training=True), mu_gt, kappa_gt)
+    gb = (lin.weight.grad.clone(), lin.bias.grad.clone(), xb.grad.clone())
+    assert abs(float(la) - float(lb)) <= 2e-6 * max(1.0, abs(float(lb)))
+    for a, b in zip(ga, gb):
+        assert _rel(a.cpu(), b.cpu()) < 2e-5
+    # float64 reference
+    x64 = x.double().cpu().requires_grad_(True)
+    W, b = lin.weight.detach().double().cpu().requires_grad_(True), lin.bias.detach().double().cpu().requires_grad_(True)
+    o = x64 @ W.t() + b
+    mu, kappa = torch.tanh(o[:, 0]) * np.pi, torch.nn.functional.softplus(o[:, 1])
+    kq = kappa_gt.double().cpu()
+    i0 = lambda k: torch.special.i0e(k) * torch.exp(k)
+    a1 = torch.special.i1e(kappa) / torch.special.i0e(kappa)
+    loss = (torch.log(i0(kq)) - torch.log(i0(kappa)) + a1 * (kappa - kq * torch.cos(mu - mu_gt.double().cpu()))).mean()
+    loss.backward()
+    assert abs(float(la) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
+    assert _rel(ga[0].cpu(), W.grad) < 2e-5 and _rel(ga[1].cpu(), b.grad) < 2e-5 and _rel(ga[2].cpu(), x64.grad) < 2e-5
