@@ -505,6 +505,10 @@ static int fc_backward_impl(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, hi
     x.lda = d->K;
     int nsplit, kp_pad;
     dw_plan(d->M, d->N, d->K, &nsplit, &kp_pad);
+    {
+        int rc = PNPP_OK;  // head layers with a gradient to pass on: dW and dx = dz W in one launch
+        if (a->dx && try_launch_fc_dx_dw(sc.dz, a->w, a->x, d->M, d->N, d->K, a->dx, a->dw, st, &rc)) return rc;
+    }
     if (d->M <= 32) {  // a handful of rows: outer-product kernel, written in place
         ProfScope ps(st, "dw_fewrows_kernel M=%d N=%d K=%d", d->M, d->N, d->K);
         hipLaunchKernelGGL(dw_fewrows_kernel, dim3(cdiv(d->K, 128), cdiv(d->N, 32)), dim3(256), 0, st, sc.dz, a->x, d->M, d->N, d->K,

@@ -2027,6 +2027,73 @@ int launch_dw(const AOperand &dz, int Nc, const AOperand &a2, int Kp, int M, flo
     return PNPP_OK;
 }
 
+// The head layers (M <= 32 rows): dx = dz W as one row of 32 x 32 split-K tiles (16 waves) and dW = dz^T x as an outer
+// product (no reduction worth an MFMA tile; workgroup = 32 output rows n x 128 columns k, dz and x tiles in LDS, each
+// thread one k and four n) only share dz: one launch, the first g1 workgroups take the GEMM tiles.
+__device__ __forceinline__ void dw_fewrows_body(const float *__restrict__ dz, const float *__restrict__ x, int M, int N, int K,
+                                                float *__restrict__ dw, int bx, int by) {
+    __shared__ __attribute__((aligned(16))) float dzs[32][32];
+    __shared__ float xs[32][128];
+    const int kl = threadIdx.x & 127, nh = threadIdx.x >> 7;  // 1024 threads: 8 groups of 4 output rows
+    const int k0 = bx * 128, n0 = by * 32;
+    for (int f = threadIdx.x; f < 32 * 32; f += 1024) {
+        const int m = f >> 5, n = f & 31;
+        dzs[m][n] = (m < M && n0 + n < N) ? dz[(size_t)m * N + n0 + n] : 0.f;
+    }
+    for (int f = threadIdx.x; f < 32 * 128; f += 1024) {
+        const int m = f >> 7, k = f & 127;
+        xs[m][k] = (m < M && k0 + k < K) ? x[(size_t)m * K + k0 + k] : 0.f;
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int m = 0; m < 32; ++m) {
+        const float xv = xs[m][kl];
+        const float4 d = *reinterpret_cast<const float4 *>(&dzs[m][4 * nh]);
+        acc[0] = fmaf(d.x, xv, acc[0]), acc[1] = fmaf(d.y, xv, acc[1]);
+        acc[2] = fmaf(d.z, xv, acc[2]), acc[3] = fmaf(d.w, xv, acc[3]);
+    }
+    if (k0 + kl < K)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 4 * nh + j;
+            if (n < N) dw[(size_t)n * K + k0 + kl] = acc[j];
+        }
+}
+
+__global__ void __launch_bounds__(1024)
+fc_dx_dw_kernel(const AOperand dzA, const BOperand W, int M, int Nout, int Kd, const Epilogue E, int g1, const float *__restrict__ x,
+                int N, int K, int gx2, float *__restrict__ dw) {
+    if ((int)blockIdx.x < g1) gemm_smallm_body<A_PLAIN, E_STORE, false, 16>(dzA, W, M, Nout, Kd, E, blockIdx.x, 0, g1);
+    else dw_fewrows_body(dzA.a, x, M, N, K, dw, (blockIdx.x - g1) % gx2, (blockIdx.x - g1) / gx2);
+}
+
+// dz: (M, N) row-major with pitch N; W: (N, K) row-major; dx: (M, K); dw: (N, K).  false = not this form, nothing launched.
+bool try_launch_fc_dx_dw(const float *dz, const float *w, const float *x, int M, int N, int K, float *dx, float *dw, hipStream_t st,
+                         int *rc) {
+    *rc = PNPP_OK;
+    if (!(M <= 32 && N >= 256 && N % 4 == 0 && K % 4 == 0 && ((uintptr_t)dz & 15) == 0)) return false;
+    AOperand A;
+    A.a = dz;
+    A.lda = N;
+    BOperand B;
+    B.b = w;
+    B.ldb = K;
+    B.rows = N;
+    Epilogue E;
+    E.mode = E_STORE;
+    E.c = dx;
+    E.ldc = K;
+    const int g1 = cdiv(K, 32), gx2 = cdiv(K, 128), gy2 = cdiv(N, 32);
+    ProfScope ps(st, "fc_dx_dw_kernel M=%d N=%d K=%d grid=%d+%d", M, N, K, g1, gx2 * gy2);
+    hipLaunchKernelGGL(fc_dx_dw_kernel, dim3(g1 + gx2 * gy2), dim3(1024), 0, st, A, B, M, K, N, E, g1, x, N, K, gx2, dw);
+    if (hipGetLastError() != hipSuccess) {
+        set_error("fc_dx_dw: launch failed");
+        *rc = PNPP_ERR_LAUNCH;
+    }
+    return true;
+}
+
 // dA (+ its epilogue) and dW of one small-M backward layer in one launch; returns false (nothing launched) when the
 // pair does not fit that form, and the caller launches the two separately.
 bool try_launch_da_dw(const AOperand &dz, const BOperand &Win, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,

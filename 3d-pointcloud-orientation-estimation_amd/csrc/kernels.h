@@ -113,6 +113,8 @@ int launch_scatter_dz(const AOperand &dz, const AOperand &geo, int B, int Mc, in
 int dw_xyz_splits(int M);
 int launch_dw_xyz(const AOperand &dz, int Nc, const AOperand &a2, int M, float *slab, hipStream_t st);
 // out[c][perm(k)] = sum_s slab[s][c][k]; perm_D < 0: identity; else feature-first -> xyz-first column order.
+bool try_launch_fc_dx_dw(const float *dz, const float *w, const float *x, int M, int N, int K, float *dx, float *dw, hipStream_t st,
+                         int *rc);
 bool try_launch_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,
                       int Kp, float *slab, int nsplit, int kp_pad, hipStream_t st, int *rc);
 int launch_slab_reduce2(const float *slab1, int nsplit1, int Nc1, int kp_pad1, int Kvalid1, float *out1, int ldo1, const float *slab2,
