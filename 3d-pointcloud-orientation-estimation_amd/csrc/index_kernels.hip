@@ -334,14 +334,20 @@ __device__ __forceinline__ unsigned philox_key(unsigned c0, unsigned c1, unsigne
 // about npoint + 4 sqrt(npoint) + 16 of them (all of them when that is >= N); the survivors go to LDS as 64-bit (key, index) words --
 // the lexicographic order of the reference rank -- and each survivor counts the survivors below it.  A cloud whose
 // cut kept fewer than npoint keys (a > 5 sigma event) is redone without the cut, so the result never depends on it.
+// A second draw (B1 > 0: workgroups B1.. take N2 / npoint2 / out2 with the NEXT stream id) rides in the same launch:
+// two consecutive calls' results from one launch, the device counter advances by two.
 __global__ void __launch_bounds__(256) sample_random_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_lo,
                                                             unsigned str_hi, unsigned long long *__restrict__ str_dev,
-                                                            int N, int npoint, int32_t *__restrict__ out) {
+                                                            int N, int npoint, int32_t *__restrict__ out, int B1, int N2,
+                                                            int npoint2, int32_t *__restrict__ out2) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long cand[];
     __shared__ int nc_s;
-    const int b = blockIdx.x;
-    if (str_dev) {  // stream id lives in device memory (graph replays draw fresh centres): str_dev[0] + (str_hi:str_lo)
-        const unsigned long long sid = str_dev[0] + (((unsigned long long)str_hi << 32) | str_lo);
+    int b = blockIdx.x;
+    const bool second = B1 > 0 && b >= B1;
+    if (second) b -= B1, N = N2, npoint = npoint2, out = out2;
+    {   // stream id: (str_hi:str_lo) [+ the device counter: graph replays draw fresh centres] [+ 1 for the second draw]
+        unsigned long long sid = (((unsigned long long)str_hi << 32) | str_lo) + (second ? 1ull : 0ull);
+        if (str_dev) sid += str_dev[0];
         str_lo = (unsigned)sid, str_hi = (unsigned)(sid >> 32);
     }
     const double keep = (npoint + 4.0 * sqrt((double)npoint) + 16.0) / (double)N;  // >= 5 sigma above npoint survivors
@@ -391,7 +397,7 @@ __global__ void __launch_bounds__(256) sample_random_kernel(unsigned seed_lo, un
             const unsigned long long t = atomicAdd(&str_dev[1], 1ull);
             if (t == gridDim.x - 1) {
                 str_dev[1] = 0ull;
-                str_dev[0] += 1ull;
+                str_dev[0] += B1 > 0 ? 2ull : 1ull;
             }
         }
     }
@@ -694,8 +700,27 @@ static int sample_random_impl(uint64_t seed, uint64_t stream_id, uint64_t *strea
     ProfScope ps(as_stream(stream), "sample_random_kernel B=%d N=%d npoint=%d", B, N, npoint);
     hipLaunchKernelGGL(sample_random_kernel, dim3(B), dim3(256), lds, as_stream(stream), (unsigned)seed,
                        (unsigned)(seed >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32),
-                       reinterpret_cast<unsigned long long *>(stream_id_dev), N, npoint, out);
+                       reinterpret_cast<unsigned long long *>(stream_id_dev), N, npoint, out, 0, 0, 0, (int32_t *)nullptr);
     PNPP_CHECK_LAUNCH("sample_random");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_sample_random_dev2(uint64_t seed, uint64_t *stream_id_dev, uint64_t offset, int B, int N1, int npoint1,
+                                       int32_t *out1, int N2, int npoint2, int32_t *out2, void *stream) {
+    PNPP_REQUIRE(stream_id_dev && out1 && out2, PNPP_ERR_ARG, "sample_random_dev2: null pointer");
+    PNPP_REQUIRE(B > 0 && N1 > 0 && npoint1 > 0 && N2 > 0 && npoint2 > 0, PNPP_ERR_ARG, "sample_random_dev2: non-positive size");
+    PNPP_REQUIRE(npoint1 <= N1 && npoint2 <= N2, PNPP_ERR_RANGE, "sample_random_dev2: npoint exceeds N");
+    const int Nmax = N1 > N2 ? N1 : N2;
+    PNPP_REQUIRE((size_t)(Nmax + 1) * 8 <= 128 * 1024, PNPP_ERR_ARG, "sample_random_dev2: N=%d too large", Nmax);
+    PNPP_REQUIRE(2 * B <= 65535, PNPP_ERR_ARG, "sample_random_dev2: batch exceeds grid limit");
+    const size_t lds = (size_t)(Nmax + 1) * sizeof(unsigned long long);
+    if (lds > 48 * 1024)
+        hipFuncSetAttribute((const void *)sample_random_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ProfScope ps(as_stream(stream), "sample_random_kernel B=%d N=%d npoint=%d + N=%d npoint=%d", B, N1, npoint1, N2, npoint2);
+    hipLaunchKernelGGL(sample_random_kernel, dim3(2 * B), dim3(256), lds, as_stream(stream), (unsigned)seed, (unsigned)(seed >> 32),
+                       (unsigned)offset, (unsigned)(offset >> 32), reinterpret_cast<unsigned long long *>(stream_id_dev), N1, npoint1,
+                       out1, B, N2, npoint2, out2);
+    PNPP_CHECK_LAUNCH("sample_random_dev2");
     return PNPP_OK;
 }
 

@@ -108,6 +108,10 @@ class BackboneBNHead(nn.Module):
         centres = (sa1 centre indices, sa2 centre indices) and drop_mask (B,256) inject the random draws (parity runs)."""
         B = xyz.size(0)
         c1, c2 = centres if centres is not None else (None, None)
+        if (centres is None and self.sa1.sampler == "device" and self.sa2.sampler == "device" and not self.sa1.group_all
+                and not self.sa2.group_all):
+            # neither draw depends on data: both levels' centres from one launch (same centres as the per-level draws)
+            c1, c2 = sampling.device_random_centres_pair(B, xyz.size(1), self.sa1.npoint, self.sa1.npoint, self.sa2.npoint, xyz.device)
         l1_xyz, l1_pts = self.sa1(xyz, None, c1)
         l2_xyz, l2_pts = self.sa2(l1_xyz, l1_pts, c2)
         _, l3_pts = self.sa3(l2_xyz, l2_pts)

@@ -69,6 +69,7 @@ SIGNATURES = {
     "pnpp_sample_random": (_i, [_u64, _u64, _i, _i, _i, _fp, _fp]),
     "pnpp_subsample_points": (_i, [_u64, _u64, _fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
     "pnpp_sample_random_dev": (_i, [_u64, _fp, _u64, _i, _i, _i, _fp, _fp]),
+    "pnpp_sample_random_dev2": (_i, [_u64, _fp, _u64, _i, _i, _i, _fp, _i, _i, _fp, _fp]),
     "pnpp_index_points": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp]),
     "pnpp_index_points_bwd": (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp]),
     "pnpp_sa_saved_bytes": (_sz, [C.POINTER(SaDesc)]),

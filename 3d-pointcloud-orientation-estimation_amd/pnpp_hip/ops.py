@@ -145,6 +145,19 @@ def sample_random_dev(seed: int, counter: torch.Tensor, offset: int, B: int, N: 
     return out
 
 
+def sample_random_dev2(seed: int, counter: torch.Tensor, offset: int, B: int, N1: int, npoint1: int, N2: int, npoint2: int):
+    """Two consecutive sample_random_dev draws in one launch: (B,npoint1) from N1 with the counter's value, (B,npoint2)
+    from N2 with the next one; counter[0] += 2.  Bit-identical to the two separate calls."""
+    _need_gpu(counter, "counter")
+    if counter.dtype != torch.int64 or counter.numel() != 2 or not counter.is_contiguous():
+        raise ValueError("counter must be a contiguous int64 tensor of 2 elements")
+    out1 = torch.empty(B, npoint1, device=counter.device, dtype=torch.int32)
+    out2 = torch.empty(B, npoint2, device=counter.device, dtype=torch.int32)
+    L.check(L.lib().pnpp_sample_random_dev2(int(seed) & (2**64 - 1), counter.data_ptr(), int(offset) & (2**64 - 1), B, N1,
+                                            int(npoint1), out1.data_ptr(), N2, int(npoint2), out2.data_ptr(), _stream()))
+    return out1, out2
+
+
 def subsample_points(seed: int, stream_id: int, bank: torch.Tensor, lengths: torch.Tensor, num: int,
                      cloud_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`num` points of each selected cloud of a device-resident bank (n_clouds,Lmax,3): without replacement where the

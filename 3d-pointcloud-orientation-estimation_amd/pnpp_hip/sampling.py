@@ -33,3 +33,10 @@ def _counter(device) -> torch.Tensor:
 def device_random_centres(B: int, N: int, npoint: int, device) -> torch.Tensor:
     # stream id = (rank << 40) + 1 + calls so far; the kernel bumps the counter after reading it
     return ops.sample_random_dev(torch.initial_seed(), _counter(device), (_state["rank"] << 40) + 1, B, N, npoint)
+
+
+
+def device_random_centres_pair(B: int, N1: int, npoint1: int, N2: int, npoint2: int, device):
+    """The draws of two stacked levels (sa1 from the cloud, sa2 from sa1's centres) in one launch; the same centres as
+    device_random_centres(B, N1, npoint1) followed by device_random_centres(B, N2, npoint2)."""
+    return ops.sample_random_dev2(torch.initial_seed(), _counter(device), (_state["rank"] << 40) + 1, B, N1, npoint1, N2, npoint2)

@@ -88,6 +88,11 @@ int pnpp_subsample_points(uint64_t seed, uint64_t stream_id, const float *bank, 
  * a ticket word that must be zero before the first call (the kernel leaves it zero). */
 int pnpp_sample_random_dev(uint64_t seed, uint64_t *stream_id_dev, uint64_t offset, int B, int N, int npoint,
                            int32_t *out, void *stream);
+/* Two consecutive pnpp_sample_random_dev draws (the centres of two stacked set-abstraction levels: pointnet_pp_8dir.py:28
+ * of sa1 and sa2) in one launch: out1 (B,npoint1) uses the counter's value, out2 (B,npoint2) the next one, the counter
+ * advances by two -- bit-identical to the two separate calls. */
+int pnpp_sample_random_dev2(uint64_t seed, uint64_t *stream_id_dev, uint64_t offset, int B, int N1, int npoint1, int32_t *out1,
+                            int N2, int npoint2, int32_t *out2, void *stream);
 
 /* models/base.py:4-18  index_points(points (B,N,C), idx (B,M)) -> out (B,M,C); idx is int32, flattened
  * over its trailing dims.  _bwd accumulates dpoints (B,N,C) += scatter(dout) deterministically

@@ -228,3 +228,17 @@ def test_subsample_points_on_device(ops):
     assert sorted(seen) == list(range(len(clouds)))
     with pytest.raises(ValueError):
         dc.DeviceCloudBank([np.zeros((20000, 3), np.float32)], "cuda")
+
+
+def test_paired_device_draw_equals_two_draws():
+    """pnpp_sample_random_dev2: the centre draws of two stacked levels in one launch are bit-identical to the two
+    separate launches and leave the device counter where they would."""
+    from pnpp_hip import ops
+    for base in (0, 41):
+        c_a = torch.tensor([base, 0], dtype=torch.int64, device="cuda")
+        c_b = c_a.clone()
+        a1 = ops.sample_random_dev(1234, c_a, 7, 5, 1000, 128)
+        a2 = ops.sample_random_dev(1234, c_a, 7, 5, 128, 32)
+        b1, b2 = ops.sample_random_dev2(1234, c_b, 7, 5, 1000, 128, 128, 32)
+        assert torch.equal(a1, b1) and torch.equal(a2, b2)
+        assert torch.equal(c_a, c_b) and int(c_b[0]) == base + 2 and int(c_b[1]) == 0
