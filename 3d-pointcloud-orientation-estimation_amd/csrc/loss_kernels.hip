@@ -431,10 +431,21 @@ __global__ void __launch_bounds__(64) soft_ce_kernel(const float *__restrict__ l
 }
 
 // ---- flat-buffer Adam (torch.optim.Adam defaults: no amsgrad, no weight decay) ---------------------
+// torch.nn.utils.clip_grad_norm_(params, max_norm) (train_multi_peaks_vonMises_KL.py:235) folded into the update: sumsq[0]
+// is the sum of squares of the flat gradient buffer as it stands (pnpp_sumsq), gscale the factor that turns the buffer into
+// the gradient (1/world under data parallelism), so the gradient's norm is sqrt(sumsq) * gscale and the coefficient is
+// min(1, max_norm / (norm + 1e-6)), torch's formula.  A null sumsq means no clipping.  No host round trip.
+__device__ __forceinline__ float clip_coef(const double *__restrict__ sumsq, float gscale, float max_norm) {
+    if (!sumsq) return 1.f;
+    const float norm = (float)(sqrt(sumsq[0]) * (double)gscale);
+    return fminf(1.f, max_norm / (norm + 1e-6f));
+}
 template <bool ZERO>
 __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                    float *__restrict__ v, size_t n, float lr_over_bc1, float inv_sqrt_bc2,
-                                                   float b1, float b2, float eps, float gscale) {
+                                                   float b1, float b2, float eps, float gscale,
+                                                   const double *__restrict__ sumsq, float max_norm) {
+    gscale *= clip_coef(sumsq, gscale, max_norm);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -452,7 +463,9 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, float 
 // been consumed (the next step's zero_grad() memset, folded in).
 __global__ void __launch_bounds__(256) adam_dev_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                        float *__restrict__ v, size_t n, float lr, float b1, float b2, float eps,
-                                                       float gscale, unsigned long long *__restrict__ state, int zero_grad) {
+                                                       float gscale, unsigned long long *__restrict__ state, int zero_grad,
+                                                       const double *__restrict__ sumsq, float max_norm) {
+    gscale *= clip_coef(sumsq, gscale, max_norm);
     __shared__ float bc[2];
     __shared__ unsigned long long step_s;
     if (threadIdx.x == 0) {
@@ -784,7 +797,8 @@ extern "C" int pnpp_adam_step(float *param, const float *grad, float *exp_avg, f
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(adam_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), param, const_cast<float *>(grad), exp_avg,
-                       exp_avg_sq, n, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale);
+                       exp_avg_sq, n, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale,
+                       (const double *)nullptr, 0.f);
     PNPP_CHECK_LAUNCH("adam_step");
     return PNPP_OK;
 }
@@ -796,8 +810,26 @@ extern "C" int pnpp_adam_step_zero(float *param, float *grad, float *exp_avg, fl
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(adam_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
-                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale);
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale, (const double *)nullptr, 0.f);
     PNPP_CHECK_LAUNCH("adam_step_zero");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_adam_step_clip(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, int step, float lr,
+                                   float beta1, float beta2, float eps, float grad_scale, const double *grad_sumsq, float max_norm,
+                                   int zero_grad, void *stream) {
+    PNPP_REQUIRE(param && grad && exp_avg && exp_avg_sq && grad_sumsq, PNPP_ERR_ARG, "adam_step_clip: null pointer");
+    PNPP_REQUIRE(n > 0 && step > 0 && max_norm > 0.f, PNPP_ERR_ARG, "adam_step_clip: n, step and max_norm must be positive");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    const float a = (float)((double)lr / bc1), b = (float)(1.0 / sqrt(bc2));
+    if (zero_grad)
+        hipLaunchKernelGGL(adam_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, a, b,
+                           beta1, beta2, eps, grad_scale, grad_sumsq, max_norm);
+    else
+        hipLaunchKernelGGL(adam_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, a, b,
+                           beta1, beta2, eps, grad_scale, grad_sumsq, max_norm);
+    PNPP_CHECK_LAUNCH("adam_step_clip");
     return PNPP_OK;
 }
 
@@ -807,8 +839,20 @@ extern "C" int pnpp_adam_step_dev(float *param, float *grad, float *exp_avg, flo
     PNPP_REQUIRE(n > 0, PNPP_ERR_ARG, "adam_step_dev: n must be positive");
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(adam_dev_kernel, dim3(grid), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                       beta2, eps, grad_scale, reinterpret_cast<unsigned long long *>(step_state), zero_grad);
+                       beta2, eps, grad_scale, reinterpret_cast<unsigned long long *>(step_state), zero_grad, (const double *)nullptr, 0.f);
     PNPP_CHECK_LAUNCH("adam_step_dev");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_adam_step_dev_clip(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, uint64_t *step_state,
+                                       float lr, float beta1, float beta2, float eps, float grad_scale, const double *grad_sumsq,
+                                       float max_norm, int zero_grad, void *stream) {
+    PNPP_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_state && grad_sumsq, PNPP_ERR_ARG, "adam_step_dev_clip: null pointer");
+    PNPP_REQUIRE(n > 0 && max_norm > 0.f, PNPP_ERR_ARG, "adam_step_dev_clip: n and max_norm must be positive");
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                       beta2, eps, grad_scale, reinterpret_cast<unsigned long long *>(step_state), zero_grad, grad_sumsq, max_norm);
+    PNPP_CHECK_LAUNCH("adam_step_dev_clip");
     return PNPP_OK;
 }
 

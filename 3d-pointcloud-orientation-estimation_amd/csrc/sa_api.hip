@@ -523,6 +523,11 @@ extern "C" const int32_t *pnpp_sa_saved_neighbours(const pnpp_sa_desc *d, const 
     if (sa_geom(d, &g) != PNPP_OK || d->group_all) return nullptr;
     return sa_saved_layout(d, g, const_cast<void *>(saved)).idx;
 }
+extern "C" const int32_t *pnpp_sa_saved_argmax(const pnpp_sa_desc *d, const void *saved) {
+    SaGeom g;
+    if (sa_geom(d, &g) != PNPP_OK) return nullptr;
+    return sa_saved_layout(d, g, const_cast<void *>(saved)).arg;
+}
 extern "C" int pnpp_sa_forward(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, void *stream) {
     return sa_forward_impl(d, a, as_stream(stream));
 }

@@ -5,39 +5,26 @@ PointCloudDataset(samples, num_points, uniform_set, label_map=None):
     item ->  (xyz (N,3), prob_gt (8,), label_idx int); classes in `uniform_set`, a missing or an unreadable
              `_8dir.txt` give the uniform distribution 0.125 (reference lines 46-55).
 """
-import os
-
 import numpy as np
 import torch
 from torch.utils.data import Dataset
 
-from dataloader_common import read_ply, sample_pts  # noqa: F401
+from dataloader_common import LabelledPlyDataset, read_ply, sample_pts  # noqa: F401
 
 
-class PointCloudDataset(Dataset):
+def parse_8dir_probs(path):
+    """First eight numbers of the soft-label file as float32, or None when it cannot be read."""
+    try:
+        return torch.from_numpy(np.loadtxt(path, dtype=np.float32).reshape(-1)[:8].copy())
+    except Exception:
+        return None
+
+
+class PointCloudDataset(LabelledPlyDataset, Dataset):
     def __init__(self, samples, num_points, uniform_set, label_map=None):
-        self.samples = list(samples)
-        self.num_points = num_points
+        super().__init__(samples, num_points, label_map)
         self.uniform_set = set(uniform_set)
-        self.label2id = label_map or {}
-        if not self.label2id:
-            for _, _, lbl in self.samples:
-                if lbl not in self.label2id:
-                    self.label2id[lbl] = len(self.label2id)
 
-    def __len__(self):
-        return len(self.samples)
-
-    def __getitem__(self, idx):
-        ply_p, prob_p, lbl = self.samples[idx]
-        xyz = torch.from_numpy(np.ascontiguousarray(sample_pts(read_ply(ply_p), self.num_points), dtype=np.float32))
-        uniform = torch.full((8,), 0.125, dtype=torch.float32)
-        if (lbl in self.uniform_set) or (not os.path.exists(prob_p)):
-            prob = uniform
-        else:
-            try:
-                arr = np.loadtxt(prob_p, dtype=np.float32).flatten()
-                prob = torch.tensor(arr[:8], dtype=torch.float32)
-            except Exception:
-                prob = uniform
-        return xyz, prob, self.label2id[lbl]
+    def ground_truth(self, sample):
+        prob = None if sample[-1] in self.uniform_set else parse_8dir_probs(sample[1])
+        return (prob if prob is not None else torch.full((8,), 0.125, dtype=torch.float32),)

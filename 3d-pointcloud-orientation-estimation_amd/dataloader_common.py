@@ -46,10 +46,24 @@ def read_ply(p):
     """ASCII PLY -> (n,3) float32 array of the first three vertex properties (x y z)."""
     c = _cache_path(p)
     if c and os.path.exists(c) and os.path.getmtime(c) >= os.path.getmtime(p):
-        return np.load(c, mmap_mode="r")
+        try:
+            return np.load(c, mmap_mode="r")
+        except Exception:      # a damaged or foreign file is a cache miss: parse the source again and replace it
+            pass
     pts = _parse_ascii_ply(p)
     if c:
-        np.save(c, pts)
+        # several DataLoader workers (and ranks) may want the same file at once: each writes its own temporary and
+        # renames it into place -- a reader sees either no cache file or a complete one, never a partial write
+        tmp = f"{c}.tmp{os.getpid()}"
+        try:
+            with open(tmp, "wb") as f:
+                np.save(f, pts)
+            os.replace(tmp, c)
+        except OSError:
+            try:
+                os.remove(tmp)
+            except OSError:
+                pass
     return pts
 
 
@@ -61,6 +75,42 @@ def sample_pts(arr, num=10_000):
         return np.asarray(arr)
     idx = np.random.choice(n, num, replace=n < num)
     return np.asarray(arr)[idx]
+
+
+class LabelledPlyDataset:
+    """What the reference's three dataset classes share (dataloader_single_peak_vonMises.py:24-52,
+    dataloader_multi_peak_vonMises.py:29-86, dataloader_8dir_sampled.py:27-57): a list of sample tuples whose first entry
+    is the PLY path and whose last entry is the class name, a class-name -> index map (given, or numbered in order of
+    first appearance / sorted, as each reference class does), and `num_points` randomly drawn points per item.
+    Subclasses supply `ground_truth(sample)` -- the columns between the cloud and the label."""
+
+    sorted_labels = False          # how a missing label_map is built: order of first appearance, or sorted names
+
+    def __init__(self, samples, num_points, label_map=None):
+        self.samples = list(samples)
+        self.num_points = num_points
+        names = [s[-1] for s in self.samples]
+        if not label_map:
+            names = sorted(set(names)) if self.sorted_labels else list(dict.fromkeys(names))
+            label_map = {n: i for i, n in enumerate(names)}
+        self.label2id = label_map
+
+    def __len__(self):
+        return len(self.samples)
+
+    def cloud(self, ply_path):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(sample_pts(read_ply(ply_path), self.num_points), dtype=np.float32))
+
+    def ground_truth(self, sample):
+        raise NotImplementedError
+
+    def label(self, sample):
+        return self.label2id[sample[-1]]
+
+    def __getitem__(self, idx):
+        sample = self.samples[idx]
+        return (self.cloud(sample[0]), *self.ground_truth(sample), self.label(sample))
 
 
 class DeviceCloudBank:

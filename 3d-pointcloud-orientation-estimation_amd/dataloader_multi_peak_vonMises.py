@@ -12,15 +12,16 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
-from dataloader_common import read_ply, sample_pts  # noqa: F401
+from dataloader_common import LabelledPlyDataset, read_ply, sample_pts  # noqa: F401
 
 
-class PointCloudDatasetMvM(Dataset):
+class PointCloudDatasetMvM(LabelledPlyDataset, Dataset):
+    sorted_labels = True           # reference line 33: categories numbered in sorted order when no map is given
+
     def __init__(self, samples, num_points, max_K=4, label_map=None):
-        self.samples = list(samples)
-        self.num_points = num_points
+        super().__init__(samples, num_points, label_map)
         self.max_K = max_K
-        self.label_map = label_map or {cat: i for i, cat in enumerate(sorted(set(s[2] for s in samples)))}
+        self.label_map = self.label2id      # the reference's attribute name in this class
 
     @staticmethod
     def _read_mvM(gt_path, max_K=4):
@@ -38,15 +39,16 @@ class PointCloudDatasetMvM(Dataset):
             table[:len(peaks)] = np.asarray(peaks, dtype=np.float64)
         return torch.from_numpy(table), int(head[1])
 
-    def __len__(self):
-        return len(self.samples)
+    def cloud(self, ply_path):
+        if not os.path.exists(ply_path):
+            raise FileNotFoundError(f"PLY not found: {ply_path}")
+        return super().cloud(ply_path)
 
-    def __getitem__(self, idx):
-        ply_p, gt_txt, category = self.samples[idx]
-        if not os.path.exists(ply_p):
-            raise FileNotFoundError(f"PLY not found: {ply_p}")
-        xyz = torch.from_numpy(np.ascontiguousarray(sample_pts(read_ply(ply_p), self.num_points), dtype=np.float32))
+    def ground_truth(self, sample):
+        ply_p, gt_txt = sample[0], sample[1]
         if not os.path.exists(gt_txt):
             raise FileNotFoundError(f"GT txt not found: {gt_txt}, for ply: {ply_p}")
-        vm_params, K = self._read_mvM(gt_txt, self.max_K)
-        return xyz, vm_params, K, torch.tensor(self.label_map[category], dtype=torch.long)
+        return self._read_mvM(gt_txt, self.max_K)
+
+    def label(self, sample):
+        return torch.tensor(self.label2id[sample[-1]], dtype=torch.long)

@@ -9,8 +9,8 @@ from .pointnet_pp_8dir import BackboneBNHead, PointNetSetAbstraction  # noqa: F4
 class PointNetPPXYZ(BackboneBNHead):
     """forward(x (B,N,3)) -> (v1, v2), each (B,3), L2-normalised head_x / head_y outputs (lines 47-90)."""
 
-    def __init__(self):
-        super().__init__()
+    def __init__(self, sampler=None, grouper=None):
+        super().__init__(sampler, grouper)
         self.head_x = nn.Linear(256, 3)
         self.head_y = nn.Linear(256, 3)
 

@@ -9,8 +9,8 @@ from .pointnet_pp_8dir import BackboneBNHead, PointNetSetAbstraction  # noqa: F4
 class PointNetPPXYZ_Schedmit(BackboneBNHead):
     """forward(x (B,N,3)) -> (v2, v3), each (B,3), L2-normalised head_y / head_z outputs (lines 47-90)."""
 
-    def __init__(self):
-        super().__init__()
+    def __init__(self, sampler=None, grouper=None):
+        super().__init__(sampler, grouper)
         self.head_y = nn.Linear(256, 3)
         self.head_z = nn.Linear(256, 3)
 

@@ -9,8 +9,8 @@ from .pointnet_pp_8dir import BackboneBNHead, PointNetSetAbstraction  # noqa: F4
 class PointNetPP(BackboneBNHead):
     """forward(x (B,N,3)) -> (B,3) raw direction vector (models/pointnet_pp.py:44-68)."""
 
-    def __init__(self):
-        super().__init__()
+    def __init__(self, sampler=None, grouper=None):
+        super().__init__(sampler, grouper)
         self.fc3 = nn.Linear(256, 3)
 
     def forward(self, x, centres=None, drop_mask=None):

@@ -23,17 +23,25 @@ class PointNetSetAbstraction(nn.Module):
                'fps'                -- true farthest point sampling (PointNet++Demo.py:8-29).
       grouper  'knn' (default, what the reference calls query_ball_point) or ('ball', radius)
                for the radius query of PointNet++Demo.py:49-70.
-    Both can also be set process-wide with PNPP_SAMPLER / PNPP_GROUPER.
+    Both are per-instance constructor keywords (every model class passes its own `sampler=` / `grouper=` down to its
+    levels); the class attributes -- PNPP_SAMPLER / PNPP_GROUPER in the environment -- are only the default for
+    instances built without them, so two models in one process can differ.
     """
 
     sampler = os.environ.get("PNPP_SAMPLER", "randperm")
     grouper = os.environ.get("PNPP_GROUPER", "knn")
 
-    def __init__(self, npoint, nsample, in_channel, mlp_channels, group_all=False):
+    def __init__(self, npoint, nsample, in_channel, mlp_channels, group_all=False, sampler=None, grouper=None):
         super().__init__()
         self.npoint = npoint
         self.nsample = nsample
         self.group_all = group_all
+        if sampler is not None:
+            if sampler not in ("randperm", "device", "fps"):
+                raise ValueError(f"unknown sampler '{sampler}'")
+            self.sampler = sampler
+        if grouper is not None:
+            self.grouper = grouper
 
         last_ch = in_channel + 3
         self.convs = nn.ModuleList()
@@ -91,10 +99,11 @@ class BackboneBNHead(nn.Module):
     files, e.g. models/pointnet_pp_8dir.py:61-73).  Subclasses add their output layers AFTER super().__init__(), so
     parameter creation order -- and with it the seeded default initialisation -- matches the reference."""
 
-    def __init__(self):
+    def __init__(self, sampler=None, grouper=None):
         super().__init__()
-        self.sa1 = PointNetSetAbstraction(128, 32, 0, [64, 64, 128])
-        self.sa2 = PointNetSetAbstraction(32, 32, 128, [128, 128, 256])
+        kw = dict(sampler=sampler, grouper=grouper)
+        self.sa1 = PointNetSetAbstraction(128, 32, 0, [64, 64, 128], **kw)
+        self.sa2 = PointNetSetAbstraction(32, 32, 128, [128, 128, 256], **kw)
         self.sa3 = PointNetSetAbstraction(None, None, 256, [256, 512, 1024], group_all=True)
 
         self.fc1 = nn.Linear(1024, 512)
@@ -123,8 +132,8 @@ class BackboneBNHead(nn.Module):
 class PointNetPP8Dir(BackboneBNHead):
     """PointNet++ backbone + 8-way direction head, raw logits out (models/pointnet_pp_8dir.py:58-85)."""
 
-    def __init__(self):
-        super().__init__()
+    def __init__(self, sampler=None, grouper=None):
+        super().__init__(sampler, grouper)
         self.fc3 = nn.Linear(256, 8)
 
     def forward(self, xyz, centres=None, drop_mask=None):

@@ -9,8 +9,8 @@ from .pointnet_pp_8dir import DIRS_8, BackboneBNHead, PointNetSetAbstraction  # 
 class PointNetPPFwd(BackboneBNHead):
     """forward(xyz (B,N,3)) -> (B,3) unit vector: F.normalize(fc3(x), dim=1) (models/pointnet_pp_Fwd.py:77-98)."""
 
-    def __init__(self):
-        super().__init__()
+    def __init__(self, sampler=None, grouper=None):
+        super().__init__(sampler, grouper)
         self.fc3 = nn.Linear(256, 3)
 
     def forward(self, xyz, centres=None, drop_mask=None):

@@ -30,11 +30,13 @@ def _as_points_last(xyz: torch.Tensor) -> torch.Tensor:
 class PointNetPPMvM(nn.Module):
     """forward(xyz) -> mu (B,K) in [-pi,pi], kappa (B,K) >= 0, weight (B,K) summing to 1."""
 
-    def __init__(self, max_K: int = 4, kappa_max: float = 80.0, p_drop: float = 0.4, temp: float = 0.7):
+    def __init__(self, max_K: int = 4, kappa_max: float = 80.0, p_drop: float = 0.4, temp: float = 0.7, sampler=None,
+                 grouper=None):
         super().__init__()
         self.max_K, self.kappa_max, self.temp = max_K, float(kappa_max), float(temp)
         for i, (npoint, nsample, cin, mlp, whole) in enumerate(_BACKBONE, start=1):
-            setattr(self, f"sa{i}", PointNetSetAbstraction(npoint, nsample, cin, list(mlp), group_all=whole))
+            setattr(self, f"sa{i}", PointNetSetAbstraction(npoint, nsample, cin, list(mlp), group_all=whole,
+                                                           **({} if whole else dict(sampler=sampler, grouper=grouper))))
         widths = (1024, 512, 256)
         for i in (1, 2):                                   # fc1, ln1, fc2, ln2 (reference lines 57-62)
             setattr(self, f"fc{i}", nn.Linear(widths[i - 1], widths[i]))

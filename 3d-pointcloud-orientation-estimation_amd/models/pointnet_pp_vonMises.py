@@ -9,8 +9,8 @@ from .pointnet_pp_8dir import BackboneBNHead, PointNetSetAbstraction  # noqa: F4
 class PointNetPPVonMises(BackboneBNHead):
     """forward(xyz (B,N,3)) -> (mu (B,) in [-pi, pi], kappa (B,) >= 0)."""
 
-    def __init__(self):
-        super().__init__()
+    def __init__(self, sampler=None, grouper=None):
+        super().__init__(sampler, grouper)
         self.fc3 = nn.Linear(256, 2)
 
     def features(self, xyz, centres=None, drop_mask=None):

@@ -77,6 +77,7 @@ SIGNATURES = {
     "pnpp_sa_forward": (_i, [C.POINTER(SaDesc), C.POINTER(SaFwdArgs), _fp]),
     "pnpp_sa_backward": (_i, [C.POINTER(SaDesc), C.POINTER(SaBwdArgs), _fp]),
     "pnpp_sa_saved_neighbours": (_fp, [C.POINTER(SaDesc), _fp]),
+    "pnpp_sa_saved_argmax": (_fp, [C.POINTER(SaDesc), _fp]),
     "pnpp_fc_saved_bytes": (_sz, [C.POINTER(FcDesc)]),
     "pnpp_fc_scratch_bytes": (_sz, [C.POINTER(FcDesc)]),
     "pnpp_fc_forward": (_i, [C.POINTER(FcDesc), C.POINTER(FcFwdArgs), _fp]),
@@ -110,6 +111,8 @@ SIGNATURES = {
     "pnpp_adam_step": (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _f, _f, _f, _f, _fp]),
     "pnpp_adam_step_zero": (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _f, _f, _f, _f, _fp]),
     "pnpp_adam_step_dev": (_i, [_fp, _fp, _fp, _fp, _sz, _fp, _f, _f, _f, _f, _f, _i, _fp]),
+    "pnpp_adam_step_clip": (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _f, _f, _f, _f, _fp, _f, _i, _fp]),
+    "pnpp_adam_step_dev_clip": (_i, [_fp, _fp, _fp, _fp, _sz, _fp, _f, _f, _f, _f, _f, _fp, _f, _i, _fp]),
     "pnpp_sumsq": (_i, [_fp, _sz, _fp, _fp, _sz, _fp]),
 }
 

@@ -57,6 +57,23 @@ def _nbt(bn) -> Optional[torch.Tensor]:
     return t
 
 
+def grad_sink(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """The slice of an optimiser's flat gradient buffer that the backward kernels may OVERWRITE with p's gradient
+    (FlatAdam(fused_grads=True)), or None when the gradient has to go through autograd's accumulation instead.
+
+    Overwriting is only right for the first use of a parameter between two zero_grad()/step() calls.  A second use --
+    gradient accumulation over micro-batches, two forward passes summed into one loss, shared weights -- gets None: its
+    gradient is then returned to autograd, which ADDS it to p.grad (the same memory), so nothing is lost.  The claim is
+    taken when the forward pass records the destination; FlatAdam.zero_grad()/step() release it."""
+    if p is None or not torch.is_grad_enabled():
+        return None
+    sink = getattr(p, "_pnpp_grad_sink", None)
+    if sink is None or getattr(p, "_pnpp_sink_claimed", False):
+        return None
+    p._pnpp_sink_claimed = True
+    return sink
+
+
 _dropout_counters = {}
 
 
@@ -227,6 +244,11 @@ def _ptr_array(tensors: Sequence[Optional[torch.Tensor]]):
     return arr
 
 
+# set to a list to receive, per set-abstraction forward call, {"neighbours": (B,S,K) int32 | None, "argmax": (B,S,C) int32}
+# (views into the call's saved workspace) -- used by the parity tests to hand the fp64 oracle the same max-pool routing
+sa_tap: Optional[list] = None
+
+
 class _SetAbstraction(torch.autograd.Function):
     """PointNetSetAbstraction.forward / backward as two C calls (models/pointnet_pp_8dir.py:21-43)."""
 
@@ -281,6 +303,10 @@ class _SetAbstraction(torch.autograd.Function):
         else:  # view of the neighbour indices kept in the saved workspace
             off = lib.pnpp_sa_saved_neighbours(C.byref(desc), saved.data_ptr()) - saved.data_ptr()
             nbr = saved[off:off + 4 * B * S * Kk].view(torch.int32).view(B, S, Kk)
+        if sa_tap is not None:   # diagnostics: views of what backward will route by (neighbour rows, max-pool positions)
+            aoff = lib.pnpp_sa_saved_argmax(C.byref(desc), saved.data_ptr()) - saved.data_ptr()
+            arg = saved[aoff:aoff + 4 * B * S * channels[-1]].view(torch.int32).view(B, S, channels[-1])
+            sa_tap.append({"neighbours": None if group_all else nbr, "argmax": arg})
         ctx.mark_non_differentiable(new_xyz, nbr)
         ctx.set_materialize_grads(False)  # no zero tensors (= fill launches) for the two outputs that carry no gradient
         return new_xyz, out, nbr
@@ -335,7 +361,7 @@ def set_abstraction(xyz, points, centre_idx, nsample, group_all, training, convs
         running += [bn.running_mean, bn.running_var]
     eps = bns[0].eps
     momentum = bns[0].momentum if bns[0].momentum is not None else 0.1
-    sinks = [getattr(p, "_pnpp_grad_sink", None) for p in params]
+    sinks = [grad_sink(p) for p in params]
     nbt = [_nbt(bn) for bn in bns] if training else None   # bumped by the statistics kernels themselves
     cfg = (nsample, bool(group_all), bool(training), eps, momentum, sinks if any(s is not None for s in sinks) else None, nbt)
     new_xyz, out, nbr = _SetAbstraction.apply(xyz, points, centre_idx, neighbour_idx, cfg, running, *params)
@@ -442,7 +468,7 @@ def fc_block(x, linear, norm=None, relu=False, dropout=None, training=True, mask
             p = dropout.p if dropout is not None else 0.5
             drop_scale = 1.0 / (1.0 - p)
             mask = mask.to(device=x.device, dtype=torch.uint8)
-    sinks = tuple(getattr(p, "_pnpp_grad_sink", None) if p is not None else None for p in (linear.weight, linear.bias, nw, nb))
+    sinks = tuple(grad_sink(p) for p in (linear.weight, linear.bias, nw, nb))
     nbt = _nbt(norm) if (training and kind == L.NORM_BATCH) else None   # bumped by the statistics kernel itself
     cfg = (kind, relu, training, eps, momentum, drop_scale, sinks if any(s is not None for s in sinks) else None, nbt, draw)
     return _FcBlock.apply(x, linear.weight, linear.bias, nw, nb, rm, rv, mask, cfg)
@@ -579,7 +605,7 @@ def vm_fc_head_kl_loss_backward(x, linear, mu_gt, kappa_gt) -> torch.Tensor:
     if w.shape != (2, K) or b.numel() != 2 or mu_gt.numel() != B or kappa_gt.numel() != B:
         raise ValueError("vm_fc_head_kl_loss_backward: linear must map K -> 2 and the targets must be (B,)")
     loss = torch.empty((), device=x32.device, dtype=torch.float32)
-    sinks = [getattr(p, "_pnpp_grad_sink", None) for p in (linear.weight, linear.bias)]
+    sinks = [grad_sink(p) for p in (linear.weight, linear.bias)]
     dw = sinks[0] if sinks[0] is not None else torch.empty_like(w)
     db = sinks[1] if sinks[1] is not None else torch.empty_like(b)
     dx = torch.empty_like(x32) if x.requires_grad else None
@@ -587,7 +613,10 @@ def vm_fc_head_kl_loss_backward(x, linear, mu_gt, kappa_gt) -> torch.Tensor:
                                             loss.data_ptr(), dw.data_ptr(), db.data_ptr(), _p(dx), _stream()))
     for p, g, sink in ((linear.weight, dw, sinks[0]), (linear.bias, db, sinks[1])):
         if sink is None and p.requires_grad:                     # plain autograd semantics: accumulate into .grad
-            p.grad = g.view_as(p) if p.grad is None else p.grad + g.view_as(p)
+            if p.grad is None:
+                p.grad = g.view_as(p)
+            else:
+                p.grad.add_(g.view_as(p))                        # in place: .grad may be a view of a flat buffer
     if dx is not None:
         torch.autograd.backward([x], [dx])
     return loss

@@ -21,8 +21,10 @@ class FlatAdam:
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fused_grads=True):
         """fused_grads: register every parameter's slice of the flat gradient buffer as the destination the
-        backward kernels write to directly (valid when each parameter is used once per step, as in every
-        reference model); autograd then has no per-parameter accumulation kernels to launch."""
+        backward kernels write to directly; autograd then has no per-parameter accumulation kernels to launch.  The
+        first use of a parameter after zero_grad()/step() overwrites its slice; any further use in the same window
+        (micro-batch accumulation, two passes summed into one loss, shared weights) is detected when its forward pass
+        asks for the destination (ops.grad_sink) and goes through autograd's accumulation into the same memory."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("optimizer got an empty parameter list")
@@ -50,6 +52,8 @@ class FlatAdam:
         self.step_count = 0
         self._step_state = torch.zeros(2, device=dev, dtype=torch.int64)   # step_dev(): [steps taken, ticket]
         self._scratch = torch.empty(1024 * 8 + 8, device=dev, dtype=torch.uint8)
+        self._ss = torch.zeros(1, device=dev, dtype=torch.float64)          # sum of squares of flat_g (clip_grad_norm_)
+        self._pending_clip: Optional[float] = None
 
     @property
     def numel(self) -> int:
@@ -70,29 +74,46 @@ class FlatAdam:
         for p, g in zip(self.params, self._views):
             if p.grad is not g:
                 p.grad = g
+        self._release_sinks()
+
+    def _release_sinks(self) -> None:
+        """A new accumulation window: the first backward write of every parameter may overwrite again (ops.grad_sink)."""
+        for p in self.params:
+            p._pnpp_sink_claimed = False
+
+    def _sumsq(self) -> torch.Tensor:
+        """Sum of squares of the flat gradient buffer into a persistent device word (float64); one stream-ordered launch pair."""
+        L.check(L.lib().pnpp_sumsq(self.flat_g.data_ptr(), self.flat_g.numel(), self._ss.data_ptr(), self._scratch.data_ptr(),
+                                   self._scratch.numel(), _stream()))
+        return self._ss
 
     def grad_norm(self) -> torch.Tensor:
         """L2 norm of the whole gradient as a 0-dim float64 tensor on the device (no host sync)."""
-        out = torch.empty(1, device=self.flat_g.device, dtype=torch.float64)
-        L.check(L.lib().pnpp_sumsq(self.flat_g.data_ptr(), self.flat_g.numel(), out.data_ptr(), self._scratch.data_ptr(),
-                                   self._scratch.numel(), _stream()))
-        return out.sqrt_()[0]
+        return self._sumsq().clone().sqrt_()[0]
 
-    def clip_grad_norm_(self, max_norm: float) -> float:
-        """torch.nn.utils.clip_grad_norm_ semantics; the scale is folded into the next step()."""
-        norm = float(self.grad_norm())
-        self._pending_scale = min(1.0, max_norm / (norm + 1e-6))
-        return norm
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """torch.nn.utils.clip_grad_norm_(parameters, max_norm) semantics (train_multi_peaks_vonMises_KL.py:235) with no
+        host round trip: the sum of squares is reduced on the device now and the NEXT step()/step_dev() reads it there and
+        folds min(1, max_norm / (norm + 1e-6)) into its gradient scale (the gradient buffer itself is left untouched --
+        the update consumes it once).  Under data parallelism call it after the all-reduce: the norm that is clipped is
+        that of grad_scale * flat_g, i.e. of the mean gradient.  Returns the buffer's own L2 norm as a 0-dim float64 device
+        tensor (multiply by grad_scale for the mean gradient's); reading it is the caller's sync, not this method's."""
+        self._sumsq()
+        self._pending_clip = float(max_norm)
+        return self._ss.sqrt()[0]
 
     def step(self, grad_scale: float = 1.0, zero_grad: bool = False) -> None:
         """zero_grad=True clears the flat gradient buffer in the same launch (the next iteration's zero_grad())."""
         self.step_count += 1
-        scale = grad_scale * getattr(self, "_pending_scale", 1.0)
-        self._pending_scale = 1.0
-        fn = L.lib().pnpp_adam_step_zero if zero_grad else L.lib().pnpp_adam_step
-        L.check(fn(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
-                                       self.exp_avg_sq.data_ptr(), self.flat_p.numel(), self.step_count, self.lr,
-                                       self.betas[0], self.betas[1], self.eps, float(scale), _stream()))
+        self._release_sinks()
+        clip, self._pending_clip = self._pending_clip, None
+        args = (self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                self.flat_p.numel(), self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, float(grad_scale))
+        if clip is not None:
+            L.check(L.lib().pnpp_adam_step_clip(*args, self._ss.data_ptr(), clip, int(bool(zero_grad)), _stream()))
+        else:
+            fn = L.lib().pnpp_adam_step_zero if zero_grad else L.lib().pnpp_adam_step
+            L.check(fn(*args, _stream()))
 
     def seed_dev_steps(self) -> None:
         """Copies the host step count into the device word step_dev() reads, if they differ (not capturable: call it
@@ -108,8 +129,12 @@ class FlatAdam:
         callers that replay a captured step_dev bump `step_count` themselves."""
         self.seed_dev_steps()
         self.step_count += 1
+        self._release_sinks()
         self._dev_steps = self.step_count
-        L.check(L.lib().pnpp_adam_step_dev(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
-                                           self.exp_avg_sq.data_ptr(), self.flat_p.numel(), self._step_state.data_ptr(), self.lr,
-                                           self.betas[0], self.betas[1], self.eps, float(grad_scale), int(bool(zero_grad)),
-                                           _stream()))
+        clip, self._pending_clip = self._pending_clip, None
+        head = (self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                self.flat_p.numel(), self._step_state.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps, float(grad_scale))
+        if clip is not None:
+            L.check(L.lib().pnpp_adam_step_dev_clip(*head, self._ss.data_ptr(), clip, int(bool(zero_grad)), _stream()))
+        else:
+            L.check(L.lib().pnpp_adam_step_dev(*head, int(bool(zero_grad)), _stream()))

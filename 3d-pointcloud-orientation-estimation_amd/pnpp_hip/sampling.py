@@ -20,6 +20,18 @@ def reset(calls: int = 0) -> None:
         c.copy_(torch.tensor([int(calls), 0], dtype=torch.int64))   # [call counter, ticket word of the kernel]
 
 
+def snapshot():
+    """Values of every device-side random-stream counter of this process (centre sampler, in-kernel dropout): taken before
+    something that draws without being part of the run (graph warm-up / capture passes) ..."""
+    return [(c, c.clone()) for c in list(_state["counters"].values()) + list(ops._dropout_counters.values())]
+
+
+def restore(snap) -> None:
+    """... and put back afterwards, so that a run stays a function of its seed whether or not it was captured."""
+    for c, v in snap:
+        c.copy_(v)
+
+
 def _counter(device) -> torch.Tensor:
     device = torch.device(device)
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())

@@ -19,7 +19,7 @@ from .ops import _f32, _scratch, _stream
 
 class _LinearSmallK(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2d, w, b):
+    def forward(ctx, x2d, w, b, sinks):
         x2d, w = _f32(x2d, "x"), _f32(w, "weight")
         b = _f32(b, "bias") if b is not None else None
         M, K = x2d.shape
@@ -29,7 +29,7 @@ class _LinearSmallK(torch.autograd.Function):
                                            y.data_ptr(), _stream()))
         ctx.save_for_backward(x2d)
         ctx.dims, ctx.has_bias = (M, K, N), b is not None
-        ctx.sinks = (getattr(w, "_pnpp_grad_sink", None), getattr(b, "_pnpp_grad_sink", None) if b is not None else None)
+        ctx.sinks = sinks
         return y
 
     @staticmethod
@@ -44,12 +44,13 @@ class _LinearSmallK(torch.autograd.Function):
         scratch = _scratch(lib.pnpp_linear_smallk_bwd_scratch_bytes(M, N), dy.device)
         L.check(lib.pnpp_linear_smallk_bwd(x2d.data_ptr(), dy.data_ptr(), M, K, N, dw.data_ptr(),
                                            None if db is None else db.data_ptr(), scratch.data_ptr(), _stream()))
-        return None, (None if sw is not None else dw), (None if (sb is not None or db is None) else db)
+        return None, (None if sw is not None else dw), (None if (sb is not None or db is None) else db), None
 
 
 def linear_smallk(x2d: torch.Tensor, lin) -> torch.Tensor:
     """nn.Linear with at most 8 inputs (input_proj): y = x W^T + b.  The input is data: it gets no gradient."""
-    return _LinearSmallK.apply(x2d, lin.weight, lin.bias)
+    # the gradient destinations are claimed here: inside Function.forward autograd is switched off and ops.grad_sink declines
+    return _LinearSmallK.apply(x2d, lin.weight, lin.bias, (ops.grad_sink(lin.weight), ops.grad_sink(lin.bias)))
 
 
 _drop_state = {"calls": 0}
@@ -116,7 +117,7 @@ def attention(qkv: torch.Tensor, num_heads: int, want_lse: bool = False, p: floa
 
 class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2d, r2d, w, b, eps):
+    def forward(ctx, x2d, r2d, w, b, eps, sinks):
         x2d, w, b = _f32(x2d, "x"), _f32(w, "weight"), _f32(b, "bias")
         r2d = _f32(r2d, "r") if r2d is not None else None
         M, E = x2d.shape
@@ -125,7 +126,7 @@ class _AddLayerNorm(torch.autograd.Function):
                                            M, E, float(eps), y.data_ptr(), _stream()))
         ctx.save_for_backward(x2d, r2d if r2d is not None else x2d.new_empty(0), w)
         ctx.has_r, ctx.eps = r2d is not None, float(eps)
-        ctx.sinks = (getattr(w, "_pnpp_grad_sink", None), getattr(b, "_pnpp_grad_sink", None))
+        ctx.sinks = sinks
         return y
 
     @staticmethod
@@ -145,12 +146,12 @@ class _AddLayerNorm(torch.autograd.Function):
             sw.copy_(dwb[0])
         if sb is not None:
             sb.copy_(dwb[1])
-        return du, (du if ctx.has_r else None), (None if sw is not None else dwb[0]), (None if sb is not None else dwb[1]), None
+        return du, (du if ctx.has_r else None), (None if sw is not None else dwb[0]), (None if sb is not None else dwb[1]), None, None
 
 
 def add_layernorm(x2d: torch.Tensor, r2d, norm: torch.nn.LayerNorm) -> torch.Tensor:
     """LayerNorm(x + r) over the last dimension (the post-norm residual blocks of nn.TransformerEncoderLayer)."""
-    return _AddLayerNorm.apply(x2d, r2d, norm.weight, norm.bias, norm.eps)
+    return _AddLayerNorm.apply(x2d, r2d, norm.weight, norm.bias, norm.eps, (ops.grad_sink(norm.weight), ops.grad_sink(norm.bias)))
 
 
 class _MeanPoints(torch.autograd.Function):

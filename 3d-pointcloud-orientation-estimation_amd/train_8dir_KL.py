@@ -2,7 +2,9 @@
 # -*- coding: utf-8 -*-
 """train_8dir_KL.py -- drop-in for the reference script of the same name: PointNetPP8Dir trained with the
 soft-label cross entropy kl_loss_per_sample_from_logits (reference lines 60-68), here one fused HIP launch.
-Outputs RES/8dir_best.pth and RES/summary.txt."""
+Outputs, as the reference writes them (lines 121-149): RES/8dir_KLdiv_0926.pth (best-validation weights),
+FIGS/overall_loss.png, FIGS/<label>_loss.png, RES/summary.txt with one "<label>\t<test loss>" line per label and a final
+"Overall\t<test loss>" line."""
 import argparse
 import os
 import random
@@ -16,7 +18,9 @@ from models.pointnet_pp_8dir import DIRS_8, PointNetPP8Dir
 from pnpp_hip import sampling, dist as pdist, ops, trainer
 
 ROOT = trainer.env_path("PNPP_ROOT", "/home/pablo/ForwardNet/data/2d_1to8_sampled")
-RES = trainer.env_path("PNPP_RES", "/home/pablo/ForwardNet/results/8dir_KLdiv")
+RES = trainer.env_path("PNPP_RES", "/home/pablo/ForwardNet/results/8dir_KLdiv_0926")
+FIGS = RES / "figs"
+CKPT_NAME = "8dir_KLdiv_0926.pth"            # the reference's file name (line 122)
 NUM_POINTS = int(os.environ.get("PNPP_NUM_POINTS", 10_000))
 BATCH = int(os.environ.get("PNPP_BATCH", 16))
 EPOCHS = int(os.environ.get("PNPP_EPOCHS", 200))
@@ -31,8 +35,22 @@ def kl_loss_per_sample_from_logits(logits, p_target):
     return ops.soft_ce(logits, p_target)
 
 
-def _loss(model, batch):
-    return kl_loss_per_sample_from_logits(model(batch[0]), batch[1])
+def plot_curve(xs, ys_dict, title, path):
+    """Reference lines 30-37."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    path.parent.mkdir(parents=True, exist_ok=True)
+    plt.figure()
+    for k, (tr, va) in ys_dict.items():
+        plt.plot(xs, tr, label=f"{k}-Tr")
+        plt.plot(xs, va, ls="--", label=f"{k}-Val")
+    plt.xlabel("Epoch"), plt.ylabel("KL (nats)"), plt.title(title)
+    plt.grid(True), plt.legend(), plt.tight_layout(), plt.savefig(path), plt.close()
+
+
+_loss = (lambda model, batch: model(batch[0]),                                   # forward
+         lambda logits, batch: kl_loss_per_sample_from_logits(logits, batch[1]))  # criterion
 
 
 def _dataset_loaders(rank, world):
@@ -48,7 +66,7 @@ def _dataset_loaders(rank, world):
     lo, hi = pdist.shard_bounds(n_tr, rank, world)
     parts = {"train": samples[:n_tr][lo:hi], "val": samples[n_tr:n_tr + n_va], "test": samples[n_tr + n_va:]}
     print(f"Samples  train:{n_tr}  val:{n_va}  test:{n_total - n_tr - n_va}")
-    return {k: DataLoader(PointCloudDataset(v, NUM_POINTS, UNIFORM_SET, label_map), batch_size=BATCH, shuffle=k == "train",
+    return labels, {k: DataLoader(PointCloudDataset(v, NUM_POINTS, UNIFORM_SET, label_map), batch_size=BATCH, shuffle=k == "train",
                           num_workers=4, pin_memory=True) for k, v in parts.items()}
 
 
@@ -59,7 +77,7 @@ def _synthetic_loaders(n, rank):
         m = max(BATCH, int(n * frac))
         xyz, _, _, fwd = synthetic.rotated_clouds(m, NUM_POINTS, seed=SEED + 1000 * i + rank)
         out[name] = trainer.SyntheticLoader([xyz, synthetic.dir8_soft_labels(fwd, DIRS_8)], BATCH, name == "train", device)
-    return out
+    return ["synthetic"], out
 
 
 def main(argv=None):
@@ -70,21 +88,29 @@ def main(argv=None):
     rank, _, world = pdist.init_from_env()
     torch.manual_seed(SEED), np.random.seed(SEED), random.seed(SEED)
     sampling.reset(0)   # the device-side centre sampler restarts its stream too: a run is a function of SEED
-    RES.mkdir(parents=True, exist_ok=True)
-    from models.pointnet_pp_8dir import PointNetSetAbstraction
-    PointNetSetAbstraction.sampler = args.sampler
+    RES.mkdir(parents=True, exist_ok=True), FIGS.mkdir(parents=True, exist_ok=True)
     dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else device
-    loaders = _synthetic_loaders(args.synthetic, rank) if args.synthetic else _dataset_loaders(rank, world)
-    model = PointNetPP8Dir().to(dev)
-    hist, best_state, best_ep = trainer.fit(model, _loss, loaders, EPOCHS, LR, dev, label="8-dir soft CE")
+    labels, loaders = _synthetic_loaders(args.synthetic, rank) if args.synthetic else _dataset_loaders(rank, world)
+    model = PointNetPP8Dir(sampler=args.sampler).to(dev)
+    hist, best_state, best_ep = trainer.fit(model, _loss, loaders, EPOCHS, LR, dev, label="8-dir soft CE", label_index=2,
+                                            n_labels=len(labels))
     model.load_state_dict(best_state)
-    test = trainer.evaluate(model, _loss, loaders["test"], dev)
+    overall, per_label = trainer.evaluate(model, _loss, loaders["test"], dev, label_index=2, n_labels=len(labels))
     if rank == 0:
-        torch.save(best_state, RES / "8dir_best.pth")
-        with open(RES / "summary.txt", "w", encoding="utf-8") as f:
-            f.write(f"best val epoch: {best_ep}\noverall test soft-CE: {test:.6f}\n")
-        print(f"Test soft-CE = {test:.6f}")
-    return hist, test
+        torch.save(best_state, RES / CKPT_NAME)
+        try:
+            xs = range(1, EPOCHS + 1)
+            plot_curve(xs, {"overall": (hist["train"], hist["val"])}, "Overall Loss (KL)", FIGS / "overall_loss.png")
+            for i, l in enumerate(labels):
+                plot_curve(xs, {l: (hist["labels"][i]["train"], hist["labels"][i]["val"])}, f"{l} Loss (KL)", FIGS / f"{l}_loss.png")
+        except Exception as e:  # plotting is optional (matplotlib may be absent)
+            print(f"[plot skipped: {e}]")
+        with open(RES / "summary.txt", "w") as f:            # reference lines 147-149
+            for l, v in zip(labels, per_label):
+                f.write(f"{l}\t{v:.6f}\n")
+            f.write(f"Overall\t{overall:.6f}\n")
+        print(f"Test soft-CE = {overall:.6f}  (best val epoch {best_ep}; steps: {hist['steps']})")
+    return hist, overall
 
 
 if __name__ == "__main__":

@@ -3,8 +3,9 @@
 """train_multi_peaks_vonMises_KL.py -- drop-in for the reference script of the same name.
 
 Keeps kl_von_mises(mu_p, kappa_p, mu_q, kappa_q), match_loss(mu_pred, kappa_pred, w_pred, vm_gt, _, K_gt),
-write_summary_txt and main(); outputs RES/mvM_best.pth and RES/results.txt in the reference's format
-(lines 127-146).  match_loss is one HIP launch for the whole batch: K x K clamped/wrapped KL cost, optimal
+plot_curve / plot_label_curve / plot_total_curve, write_summary_txt and main(); outputs RES/mvM_best.pth, RES/results.txt in
+the reference's format (lines 127-146, per-category rows filled from the per-label epoch means), FIGS/loss_<category>.png,
+FIGS/loss_total.png and FIGS/loss_overview.png (lines 292-299).  match_loss is one HIP launch for the whole batch: K x K clamped/wrapped KL cost, optimal
 assignment and the weighted mean, value and gradients, with no per-sample host round trip (the reference crosses
 to the host for scipy's linear_sum_assignment once per sample, lines 74-75).
 """
@@ -79,10 +80,50 @@ def write_summary_txt(path_txt: Path, categories, hist, test_kl=None, best_val_e
             f.write(f"[{cat}] Train={_fmt(tr)} Val={_fmt(va)}\n")
 
 
-def _loss(model, batch):
-    xyz, vm_gt, K = batch[0], batch[1], batch[2]
-    mu_pred, kappa_pred, w_pred = model(xyz)
-    return match_loss(mu_pred, kappa_pred, w_pred, vm_gt, vm_gt, K)
+def _plt():
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    return plt
+
+
+def plot_curve(xs, ys_dict, title, path):
+    """Reference lines 86-99: every curve of ys_dict in one figure."""
+    plt = _plt()
+    plt.figure(figsize=(12, 8))
+    for k in sorted(ys_dict.keys()):
+        tr, va = ys_dict[k]
+        plt.plot(xs, tr, label=f"{k}-Train")
+        plt.plot(xs, va, "--", label=f"{k}-Val")
+    plt.xlabel("Epoch"), plt.ylabel("KL Loss"), plt.title(title), plt.grid(True), plt.legend()
+    plt.tight_layout(), plt.savefig(path), plt.close()
+
+
+def plot_label_curve(xs, train_vals, val_vals, label_name, out_path):
+    """Reference lines 101-112."""
+    plot_pair(xs, train_vals, val_vals, ("Train", "Val"), f"{label_name} - KL Loss", out_path)
+
+
+def plot_total_curve(xs, total_train, total_val, out_path):
+    """Reference lines 114-125."""
+    plot_pair(xs, total_train, total_val, ("Total-Train", "Total-Val"), "Overall KL Loss (Total)", out_path)
+
+
+def plot_pair(xs, tr, va, names, title, out_path):
+    plt = _plt()
+    plt.figure(figsize=(10, 6))
+    plt.plot(xs, tr, label=names[0])
+    plt.plot(xs, va, "--", label=names[1])
+    plt.xlabel("Epoch"), plt.ylabel("KL Loss"), plt.title(title), plt.grid(True), plt.legend()
+    plt.tight_layout(), plt.savefig(out_path), plt.close()
+
+
+def _criterion(out, batch):
+    mu_pred, kappa_pred, w_pred = out
+    return match_loss(mu_pred, kappa_pred, w_pred, batch[1], batch[1], batch[2])
+
+
+_loss = (lambda model, batch: model(batch[0]), _criterion)    # (forward, criterion): the reference times them separately
 
 
 def _dataset_loaders(rank, world):
@@ -131,20 +172,27 @@ def main(argv=None):
     torch.manual_seed(SEED), np.random.seed(SEED), random.seed(SEED)
     sampling.reset(0)   # the device-side centre sampler restarts its stream too: a run is a function of SEED
     RES.mkdir(parents=True, exist_ok=True), FIGS.mkdir(parents=True, exist_ok=True)
-    from models.pointnet_pp_8dir import PointNetSetAbstraction
-    PointNetSetAbstraction.sampler = args.sampler
     dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else device
     categories, loaders = _synthetic_loaders(args.synthetic, rank) if args.synthetic else _dataset_loaders(rank, world)
-    model = PointNetPPMvM().to(dev)
-    h, best_state, best_ep = trainer.fit(model, _loss, loaders, EPOCHS, LR, dev, clip_norm=1.0, label="multi-peak vM KL")
-    hist = {"total": h}
-    for cat in categories:      # per-category curves need labels in the batch; the total curve is what is tracked here
-        hist[cat] = {"train": [], "val": []}
+    model = PointNetPPMvM(sampler=args.sampler).to(dev)
+    h, best_state, best_ep = trainer.fit(model, _loss, loaders, EPOCHS, LR, dev, clip_norm=1.0, label="multi-peak vM KL",
+                                         label_index=3, n_labels=len(categories))
+    hist = {"total": {"train": h["train"], "val": h["val"]}}
+    for i, cat in enumerate(categories):
+        hist[cat] = h["labels"][i]
     model.load_state_dict(best_state)
     test_kl = trainer.evaluate(model, _loss, loaders["test"], dev)
     if rank == 0:
         torch.save(best_state, RES / "mvM_best.pth")
-        print(f"Test KL = {test_kl:.6f}")
+        try:
+            xs = list(range(1, EPOCHS + 1))
+            for cat in categories:
+                plot_label_curve(xs, hist[cat]["train"], hist[cat]["val"], cat, FIGS / f"loss_{_sanitize(cat)}.png")
+            plot_total_curve(xs, hist["total"]["train"], hist["total"]["val"], FIGS / "loss_total.png")
+            plot_curve(xs, {k: (v["train"], v["val"]) for k, v in hist.items()}, "Multi-Peak von Mises KL Loss", FIGS / "loss_overview.png")
+        except Exception as e:  # plotting is optional (matplotlib may be absent)
+            print(f"[plot skipped: {e}]")
+        print(f"Test KL = {test_kl:.6f}  (steps: {h['steps']})")
         write_summary_txt(RES / "results.txt", categories, hist, test_kl=test_kl, best_val_epoch=best_ep)
     return hist, test_kl
 

@@ -57,9 +57,10 @@ def plot_curve(xs, ys_dict, title, path):
 
 
 def _loss(model, batch):
+    """model.features = the raw fc3 output; head (tanh * pi, softplus), KL and their gradient are one launch
+    (models/pointnet_pp_vonMises.py:36-37 + kl_von_mises): what `kl_von_mises(*model(xyz), mu_gt, kappa_gt)` computes."""
     xyz, vm_gt = batch[0], batch[1]
-    mu_pred, kappa_pred = model(xyz)
-    return kl_von_mises(mu_pred, kappa_pred, vm_gt[:, 0].contiguous(), vm_gt[:, 1].contiguous())
+    return ops.vm_head_kl_loss(model.features(xyz), vm_gt[:, 0].contiguous(), vm_gt[:, 1].contiguous(), reduction="none")
 
 
 def _dataset_loaders(rank, world):
@@ -100,11 +101,9 @@ def main(argv=None):
     torch.manual_seed(SEED), np.random.seed(SEED), random.seed(SEED)
     sampling.reset(0)   # the device-side centre sampler restarts its stream too: a run is a function of SEED
     RES.mkdir(parents=True, exist_ok=True), FIGS.mkdir(parents=True, exist_ok=True)
-    from models.pointnet_pp_8dir import PointNetSetAbstraction
-    PointNetSetAbstraction.sampler = args.sampler
     dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else device
     loaders = _synthetic_loaders(args.synthetic, rank) if args.synthetic else _dataset_loaders(rank, world)
-    model = PointNetPPVonMises().to(dev)
+    model = PointNetPPVonMises(sampler=args.sampler).to(dev)
     hist, best_state, _ = trainer.fit(model, _loss, loaders, EPOCHS, LR, dev, label="von Mises KL")
     if rank == 0:
         torch.save(best_state, RES / "vonMises_best.pth")
@@ -116,6 +115,7 @@ def main(argv=None):
     test_kl = trainer.evaluate(model, _loss, loaders["test"], dev)
     if rank == 0:
         print(f"Test KL = {test_kl:.6f}")
+        print(f"[steps: {hist['steps']}]")
     return hist, test_kl
 
 

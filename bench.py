@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks: the parent -- before
+it has made a single GPU call -- runs `python -m torch.distributed.run ... bench.py <same arguments>` as a child process
+and exits with its code (never an exec of a process that has touched the GPU).  Under torchrun it is a plain rank.
+
 One step = zero_grad + forward (device-side centre sampling, kNN grouping, fused MLP, head) + single-peak
 von-Mises KL + backward + [one flat-gradient all-reduce when N > 1] + fused Adam, on a batch of B=32 synthetic
 clouds per GPU that is already resident in HBM.  float32 end to end (exact-f32 MFMA), weak scaling.
@@ -33,10 +37,12 @@ import torch  # noqa: E402
 N_POINTS = 1024
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32x32x2_f32)
+FLOPS_PER_CLOUD = 0.8542e9     # 3 x 2 x 142,369,280 MAC, forward + backward, independent of N
+BYTES_PER_CLOUD = 34.6e6       # 5 E + 3 G float32 words + xyz / indices
 
 
 def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=True):
-    """Returns (step, launch_mode).  zero_grad + forward + loss + backward are replayed from one hipGraph when
+    """Returns (step, launch_mode, step_without_collective).  zero_grad + forward + loss + backward are replayed from one hipGraph when
     capture succeeds (falls back to eager launches otherwise); the all-reduce and the fused Adam follow eagerly."""
     from pnpp_hip import ops, dist as pdist
 
@@ -82,29 +88,32 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
             print(f"[bench] hipGraph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr)
             graphed = None
 
-    def step():
-        if split is not None:
-            loss = split(xyz, mu_gt, kappa_gt, all_reduce=lambda t: pdist.all_reduce_flat_grad(t, async_op=True))
-            opt.step(grad_scale=1.0 / world)
-            return loss
-        if graphed is not None:
-            loss = graphed(xyz, mu_gt, kappa_gt)
-            if graphed.fused_optimizer:
+    def make_step(coll):
+        def step():
+            if split is not None:
+                loss = split(xyz, mu_gt, kappa_gt,
+                             all_reduce=(lambda t: pdist.all_reduce_flat_grad(t, async_op=True)) if coll else None)
+                opt.step(grad_scale=1.0 / world)
                 return loss
-        else:
-            opt.zero_grad()
-            loss = loss_fn(xyz, mu_gt, kappa_gt)
-            if loss.requires_grad:
-                loss.backward()
-        if collective:   # the instrumented roofline pass runs on rank 0 alone: it must not enter a collective
-            pdist.all_reduce_flat_grad(opt.flat_g)
-        opt.step(grad_scale=1.0 / world, zero_grad=graphed is not None)
-        return loss
+            if graphed is not None:
+                loss = graphed(xyz, mu_gt, kappa_gt)
+                if graphed.fused_optimizer:
+                    return loss
+            else:
+                opt.zero_grad()
+                loss = loss_fn(xyz, mu_gt, kappa_gt)
+                if loss.requires_grad:
+                    loss.backward()
+            if coll:   # the instrumented roofline pass runs on rank 0 alone: it must not enter a collective
+                pdist.all_reduce_flat_grad(opt.flat_g)
+            opt.step(grad_scale=1.0 / world, zero_grad=graphed is not None)
+            return loss
+        return step
 
     mode = ("two hipGraphs (fwd + sa3/head bwd | sa2/sa1 bwd) with the bucketed all-reduce overlapped + eager Adam" if split is not None
             else "hipGraph(fwd+loss+bwd+Adam, gradients cleared by the update)" if graphed is not None and graphed.fused_optimizer
             else "hipGraph(fwd+loss+bwd) + eager all-reduce/Adam (the update clears the gradients)" if graphed is not None else "eager")
-    return step, mode
+    return make_step(collective), mode, make_step(False)   # the last one: same launches, no collective (rank-local)
 
 
 def kernel_cost(tag: str):
@@ -137,6 +146,17 @@ def kernel_cost(tag: str):
     return None
 
 
+def csrc_sha() -> str:
+    """sha256 over the kernel sources (what a PMC measurement is valid for)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def roofline_leg(step, nsteps=5):
     """Instrumented pass: HIP events around every launch, aggregated per (kernel, shape) tag."""
     from pnpp_hip import _lib
@@ -155,7 +175,7 @@ def roofline_leg(step, nsteps=5):
         tag, cnt, ms = line.split("\t")
         rows.append((tag, int(cnt), float(ms)))
     if ntag <= 0 or not rows:
-        return None, []
+        return None, [], None
     rows.sort(key=lambda r: -r[2])
     total = sum(r[2] for r in rows)
     table = [{"kernel": t, "launches": c, "avg_us": 1e3 * ms / c, "share": ms / total} for t, c, ms in rows[:12]]
@@ -190,11 +210,18 @@ def roofline_leg(step, nsteps=5):
             key = key[:g.start()] + f"grid={int(g.group(1)) * int(g.group(2))}"
         if os.path.exists(pmc):
             try:
-                roof["traffic"] = json.load(open(pmc)).get(key, {}).get("hbm_bytes_per_launch")
+                doc = json.load(open(pmc))
+                meta = doc.get("_measured_at", {})
+                # the counters belong to the kernel sources they were taken with: a later edit of csrc/ voids them
+                if meta.get("csrc_sha256") == csrc_sha():
+                    roof["traffic"] = doc.get(key, {}).get("hbm_bytes_per_launch")
+                    roof["traffic_measured_at"] = meta.get("git")
+                else:
+                    roof["traffic_stale"] = f"profiles/pmc_traffic.json was taken at {meta.get('git')} with other kernel sources"
             except Exception:
                 pass
-        return roof, table
-    return None, table
+        return roof, table, total / nsteps
+    return None, table, total / nsteps
 
 
 def cpu_baseline(B, budget_s=20.0):
@@ -221,18 +248,93 @@ def cpu_baseline(B, budget_s=20.0):
         opt.step()
         return float(loss.detach())
 
-    step()
-    t0 = time.perf_counter()
-    times = []
-    while time.perf_counter() - t0 < budget_s and len(times) < 40:
-        t = time.perf_counter()
+    def median_step(budget, cap):
         step()
-        times.append(time.perf_counter() - t)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": B / med, "unit": "clouds/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} steps of batch {B} x {N_POINTS} points, median step {med * 1e3:.1f} ms, "
-                      f"fwd+loss+bwd+Adam, oracle/restatement.py float32"}
+        t0 = time.perf_counter()
+        times = []
+        while time.perf_counter() - t0 < budget and len(times) < cap:
+            t = time.perf_counter()
+            step()
+            times.append(time.perf_counter() - t)
+        times.sort()
+        return times[len(times) // 2], len(times)
+
+    med, n = median_step(budget_s, 40)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)                               # also the single-thread figure
+    med1, n1 = median_step(min(budget_s, 8.0), 3)
+    torch.set_num_threads(threads)
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": B / med, "unit": "clouds/s", "cores": threads, "kind": "port",
+            "sample": f"{n} steps of batch {B} x {N_POINTS} points, median step {med * 1e3:.1f} ms, "
+                      f"fwd+loss+bwd+Adam, oracle/restatement.py float32",
+            "one_thread": {"value": B / med1, "cores": 1, "sample": f"{n1} steps, median {med1 * 1e3:.0f} ms"},
+            "cpu_model": cpu_model, "host_cpus": os.cpu_count(), "torch": torch.__version__}
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks ourselves.  Runs in a parent that has made
+    NO GPU call (importing torch makes none); the ranks are fresh child processes, the parent only waits for them."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rehearse(args):
+    """Launcher / rendezvous / collective plumbing WITHOUT kernels (`--rehearse`, CPU + gloo): what tests/ can run in a
+    container that has no GPU.  The line it prints is marked as a rehearsal and carries no throughput."""
+    import torch.distributed as tdist
+    from pnpp_hip import dist as pdist
+    rank, _, world = pdist.init_from_env(backend="gloo")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    flat_g = torch.ones(1_465_922)                          # the flat gradient of PointNetPPVonMises
+    seen = torch.ones(1)
+    if world > 1:
+        tdist.all_reduce(seen)
+        tdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pdist.all_reduce_flat_grad(flat_g)
+        flat_g.mul_(1.0 / world)
+    if world > 1:
+        tdist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        tdist.all_reduce(el, op=tdist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "REHEARSAL of the launcher and the flat-gradient all-reduce (gloo, no kernels, not a measurement)",
+                          "value": None, "unit": "clouds/s", "n_gpus": world, "n_ranks_seen": int(seen.item()),
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(el) / max(args.steps, 1),
+                          "rehearsal": True, "allreduce_ok": bool(torch.all(flat_g == 1.0))}))
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+def timed(step, n, fence):
+    fence()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(n):
+        loss = step()
+    fence()
+    return time.perf_counter() - t0, loss
 
 
 def main():
@@ -244,10 +346,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="CPU/gloo rehearsal of the launcher and the collective plumbing only (no kernels, no throughput)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # no launcher around us: become one (no GPU call made so far)
+        sys.exit(self_launch(args))
+    if args.rehearse:
+        return rehearse(args)
+
     from pnpp_hip import _lib, dist as pdist, optim
-    from models.pointnet_pp_8dir import PointNetSetAbstraction
     from models.pointnet_pp_vonMises import PointNetPPVonMises
     import synthetic
     import torch.distributed as tdist
@@ -259,16 +367,18 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     torch.manual_seed(42)                                  # train_single_peak_vonMises_KL.py:19-20
-    PointNetSetAbstraction.sampler = "device"              # centre sampling on the GPU (same distribution as randperm)
-    model = PointNetPPVonMises().to(dev).train()
+    model = PointNetPPVonMises(sampler="device").to(dev).train()   # centre sampling on the GPU (same distribution as randperm)
     opt = optim.FlatAdam(model.parameters(), lr=1e-3)
     pdist.broadcast_flat(opt.flat_p)
     B = args.batch
     xyz, mu_gt, kappa_gt, _ = synthetic.rotated_clouds(B, N_POINTS, seed=1234 + rank)
     xyz, mu_gt, kappa_gt = xyz.to(dev), mu_gt.to(dev), kappa_gt.to(dev)
-    step, launch_mode = build_step(model, opt, xyz, mu_gt, kappa_gt, world, not args.no_graph)
-    eager_step, _ = build_step(model, opt, xyz, mu_gt, kappa_gt, world, False, collective=False)   # rank-local, for the roofline pass
+    step, launch_mode, step_local = build_step(model, opt, xyz, mu_gt, kappa_gt, world, not args.no_graph)
+    eager_step, _, _ = build_step(model, opt, xyz, mu_gt, kappa_gt, world, False, collective=False)   # rank-local, for the roofline pass
 
+    seen = torch.ones(1, device=dev)
+    if world > 1:
+        tdist.all_reduce(seen)                             # every rank really is in the job
     for _ in range(args.warmup):
         step()
 
@@ -278,20 +388,26 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    el, loss = timed(step, args.steps, fence)
+    elapsed = torch.tensor([el], device=dev, dtype=torch.float64)
     if world > 1:
         tdist.all_reduce(elapsed, op=tdist.ReduceOp.MAX)
     elapsed = float(elapsed)
     final_loss = float(loss.detach())
 
-    roof, table = (None, [])
+    exposed_us = None
+    if world > 1:   # the same captured step without the collective: what the all-reduce costs beyond what backward hides
+        for _ in range(min(args.warmup, 5)):
+            step_local()
+        el2, _ = timed(step_local, args.steps, fence)
+        e2 = torch.tensor([el2], device=dev, dtype=torch.float64)
+        tdist.all_reduce(e2, op=tdist.ReduceOp.MAX)
+        exposed_us = 1e6 * (elapsed - float(e2)) / args.steps
+        pdist.broadcast_flat(opt.flat_p)                   # replicas drifted apart in the local-only steps: not used after this
+
+    roof, table, kernel_ms = (None, [], None)
     if not args.no_roofline and rank == 0:
-        roof, table = roofline_leg(eager_step)     # per-launch events need individual launches, not a graph replay
+        roof, table, kernel_ms = roofline_leg(eager_step)  # per-launch events need individual launches, not a graph replay
     cpu = None
     if world > 1:
         tdist.barrier()
@@ -299,15 +415,21 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(B)
         ms = 1e3 * elapsed / args.steps
+        per_gpu = B * args.steps / elapsed
         out = {
-            "metric": "clouds/sec fwd+bwd, pointnet_pp_vonMises N=1024", "value": world * B * args.steps / elapsed,
+            "metric": "clouds/sec fwd+bwd, pointnet_pp_vonMises N=1024", "value": world * per_gpu,
             "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: models/pointnet_pp_vonMises.py single-peak KL, N=1024, batch=32 per GPU, "
                                    "fwd+loss+bwd+allreduce+Adam, random-init weights (seed 42), device-side centre sampling",
                        "per_gpu_batch": B, "global_batch": B * world, "points": N_POINTS,
                        "parallelism": f"dp{world}" if world > 1 else "single", "launch": launch_mode},
-            "final_loss": final_loss, "roofline": roof, "cpu_baseline": cpu, "top_kernels": table,
+            "final_loss": final_loss, "n_ranks_seen": int(seen.item()), "allreduce_exposed_us": exposed_us,
+            # whole step against both roofs: algorithmic FLOPs / bytes per cloud x clouds/s per GPU
+            "mfma_fraction": per_gpu * FLOPS_PER_CLOUD / (MFMA_F32_PEAK_TFLOPS * 1e12),
+            "hbm_fraction": per_gpu * BYTES_PER_CLOUD / (HBM_PEAK_GBS * 1e9),
+            "kernel_ms_per_step": kernel_ms,
+            "roofline": roof, "cpu_baseline": cpu, "top_kernels": table,
         }
         print(json.dumps(out))
     if world > 1:

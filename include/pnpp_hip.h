@@ -161,6 +161,9 @@ int pnpp_sa_forward(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, void *stre
 int pnpp_sa_backward(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, void *stream);
 /* read-only view of the neighbour indices kept in `saved` ((B,S,K) int32; NULL when group_all) */
 const int32_t *pnpp_sa_saved_neighbours(const pnpp_sa_desc *d, const void *saved);
+/* read-only view of the max-pool routing kept in `saved`: (B*S, C_last) int32, the position 0..K-1 inside its group of the
+ * row that torch.max(x, 3) selected (pointnet_pp_8dir.py:42; first maximum on ties) */
+const int32_t *pnpp_sa_saved_argmax(const pnpp_sa_desc *d, const void *saved);
 
 /* ------------------------------------------------------------------------------------------
  * Fully connected block: y = act(norm(x W^T + b)) with norm in {BatchNorm1d, LayerNorm, none},
@@ -332,6 +335,16 @@ int pnpp_adam_step_zero(float *param, float *grad, float *exp_avg, float *exp_av
  * consumed -- the opt.zero_grad() of the next iteration (train_single_peak_vonMises_KL.py:80), folded in. */
 int pnpp_adam_step_dev(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, uint64_t *step_state,
                        float lr, float beta1, float beta2, float eps, float grad_scale, int zero_grad, void *stream);
+/* torch.nn.utils.clip_grad_norm_(parameters, max_norm) (train_multi_peaks_vonMises_KL.py:235) folded into the update with
+ * no host round trip: grad_sumsq[0] (device memory, written by pnpp_sumsq on the same stream) is the sum of squares of the
+ * flat gradient buffer as it stands; the gradient is grad * grad_scale, its norm sqrt(grad_sumsq[0]) * grad_scale, and the
+ * update uses grad * grad_scale * min(1, max_norm / (norm + 1e-6)).  zero_grad != 0 clears each gradient once consumed. */
+int pnpp_adam_step_clip(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, int step, float lr,
+                        float beta1, float beta2, float eps, float grad_scale, const double *grad_sumsq, float max_norm,
+                        int zero_grad, void *stream);
+int pnpp_adam_step_dev_clip(float *param, float *grad, float *exp_avg, float *exp_avg_sq, size_t n, uint64_t *step_state,
+                            float lr, float beta1, float beta2, float eps, float grad_scale, const double *grad_sumsq,
+                            float max_norm, int zero_grad, void *stream);
 /* sum of squares of a flat buffer into out[0] (double), deterministic two-level reduction. */
 int pnpp_sumsq(const float *x, size_t n, double *out, void *scratch, size_t scratch_bytes, void *stream);
 

@@ -156,13 +156,19 @@ def sa_forward(xyz32: torch.Tensor, points: Optional[torch.Tensor], P: Dict[str,
                prefix: str, centre_idx: Optional[torch.Tensor], nsample: Optional[int],
                group_all: bool, training: bool = True, bn_state: Optional[BNState] = None,
                eps: float = 1e-5, momentum: float = 0.1, neighbour_idx: Optional[torch.Tensor] = None,
-               rel_in_compute_dtype: bool = False):
+               rel_in_compute_dtype: bool = False, argmax: Optional[torch.Tensor] = None, diag: Optional[dict] = None):
     """One PointNetSetAbstraction.forward (pointnet_pp_8dir.py:21-43).
 
     xyz32 is the float32 cloud (B,N,3); compute dtype is that of the parameters in P.
     centre_idx (B,S) int64 replaces the `torch.randperm` draw of line 28.
     Returns new_xyz (B,S,3) float32, features (B,S,Cout) and the neighbour indices used.
-    """
+
+    argmax (B,S,Cout) int64, optional: positions inside each neighbourhood (in the order of `neighbour_idx`) that the max
+    over nsample takes -- the routing of another evaluation of the same network.  max() is not smooth: where two rows of
+    a neighbourhood agree to float32 rounding, a float32 evaluation may legitimately route the pooled gradient through
+    the other row than float64 does.  With the routing injected the result is a smooth function of rounding again;
+    diag["route_gap"] collects max (true max - value at the injected position) / scale per call, which the caller bounds
+    (the injected routing must select a maximum up to float32 rounding)."""
     dt = P[f"{prefix}.convs.0.weight"].dtype
     B, N, _ = xyz32.shape
     if group_all:
@@ -196,16 +202,27 @@ def sa_forward(xyz32: torch.Tensor, points: Optional[torch.Tensor], P: Dict[str,
             y = _bn_eval(z, g_, b_, P[f"{prefix}.bns.{li}.running_mean"], P[f"{prefix}.bns.{li}.running_var"], eps)
         x = torch.relu(y)
         li += 1
-    return new_xyz32, x.max(dim=2).values, idx
+    if argmax is None:
+        return new_xyz32, x.max(dim=2).values, idx
+    pooled = torch.gather(x, 2, argmax.to(torch.int64).unsqueeze(2)).squeeze(2)
+    if diag is not None:
+        top = x.detach().max(dim=2).values
+        diag.setdefault("route_gap", []).append(float(((top - pooled.detach()) / top.abs().clamp_min(1.0)).max()))
+    return new_xyz32, pooled, idx
 
 
 def backbone_forward(xyz32, P, centres: Sequence[torch.Tensor], training=True, bn_state=None,
-                     cfg=((128, 32), (32, 32)), rel_in_compute_dtype=False):
-    """sa1 -> sa2 -> sa3(group_all), as in every pointnet_pp_* model (e.g. pointnet_pp_vonMises.py:28-31)."""
-    kw = dict(rel_in_compute_dtype=rel_in_compute_dtype)
-    l1_xyz, l1, _ = sa_forward(xyz32, None, P, "sa1", centres[0], cfg[0][1], False, training, bn_state, **kw)
-    l2_xyz, l2, _ = sa_forward(l1_xyz, l1, P, "sa2", centres[1], cfg[1][1], False, training, bn_state, **kw)
-    _, l3, _ = sa_forward(l2_xyz, l2, P, "sa3", None, None, True, training, bn_state, **kw)
+                     cfg=((128, 32), (32, 32)), rel_in_compute_dtype=False, routing=None, diag=None):
+    """sa1 -> sa2 -> sa3(group_all), as in every pointnet_pp_* model (e.g. pointnet_pp_vonMises.py:28-31).
+    routing: optional three dicts {"neighbours": (B,S,K) | None, "argmax": (B,S,C)} (see sa_forward)."""
+    kw = dict(rel_in_compute_dtype=rel_in_compute_dtype, diag=diag)
+    r = routing if routing is not None else [{"neighbours": None, "argmax": None}] * 3
+    nb = lambda i: None if r[i]["neighbours"] is None else r[i]["neighbours"].to(torch.int64)
+    l1_xyz, l1, _ = sa_forward(xyz32, None, P, "sa1", centres[0], cfg[0][1], False, training, bn_state,
+                               neighbour_idx=nb(0), argmax=r[0]["argmax"], **kw)
+    l2_xyz, l2, _ = sa_forward(l1_xyz, l1, P, "sa2", centres[1], cfg[1][1], False, training, bn_state,
+                               neighbour_idx=nb(1), argmax=r[1]["argmax"], **kw)
+    _, l3, _ = sa_forward(l2_xyz, l2, P, "sa3", None, None, True, training, bn_state, argmax=r[2]["argmax"], **kw)
     return l3.reshape(l3.shape[0], -1)
 
 

@@ -92,3 +92,35 @@ def test_synthetic_recipe_matches_oracle(oracle):
     from models.pointnet_pp_8dir import DIRS_8
     p8 = synthetic.dir8_soft_labels(a[3], DIRS_8)
     assert torch.allclose(p8.sum(1), torch.ones(5), atol=1e-6) and (p8 >= 0).all()
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts its own two ranks (a parent that never touches the
+    GPU runs torch.distributed.run as a child) and rank 0 prints one JSON line with n_gpus = n_ranks_seen = 2.  --rehearse
+    swaps the kernels for nothing and RCCL for gloo: launcher, rendezvous and flat all-reduce are what is covered here."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--rehearse"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["steps"] == 3 and out["allreduce_ok"] is True
+    assert out["rehearsal"] is True and out["value"] is None          # never mistaken for a measurement
+
+
+def test_bench_refuses_to_run_without_the_hip_path():
+    """Without --rehearse the product path must fail loudly on a box without a GPU: no CPU fallback."""
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    if torch.cuda.is_available():
+        pytest.skip("needs a GPU-less container")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not any(ln.startswith("{") for ln in r.stdout.splitlines())

@@ -38,6 +38,13 @@ def test_read_ply_and_sampling(cloud, tmp_path, monkeypatch):
     a = dc.read_ply(p)
     b = dc.read_ply(p)                                                                # second read is served by the cache
     assert np.array_equal(np.asarray(a), np.asarray(b)) and len(os.listdir(tmp_path / "cache")) == 1
+    # a damaged cache file (a writer that died, a foreign file) is a miss: the source is parsed again and the cache replaced
+    cfile = tmp_path / "cache" / os.listdir(tmp_path / "cache")[0]
+    cfile.write_bytes(b"\x93NUMPY garbage")
+    os.utime(cfile, (os.path.getmtime(p) + 10, os.path.getmtime(p) + 10))
+    c = dc.read_ply(p)
+    assert np.array_equal(np.asarray(c), np.asarray(a))
+    assert np.array_equal(np.load(cfile), np.asarray(a)) and os.listdir(tmp_path / "cache") == [cfile.name]   # no temporaries left
 
 
 def test_single_peak_dataset(cloud):
