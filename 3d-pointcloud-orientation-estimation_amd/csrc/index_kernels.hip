@@ -207,54 +207,94 @@ __global__ void __launch_bounds__(256) knn_kernel(const float *__restrict__ new_
 
 // ---------------------------------------------------------------------------------------------
 // farthest point sampling (PointNet++Demo.py:8-29): one workgroup per cloud.
-// xyz and the running min-distance live in LDS; one barrier per round (double-buffered wave maxima).
+//
+// The algorithm is a chain of npoint dependent rounds (distance update over all N points, arg-max, next centre), so its
+// time is npoint x (latency of one round); a round is short enough (< 1 us up to N ~ 16k) that handing the arg-max
+// between workgroups through memory (>= 1 us per hop) would lengthen it -- a cloud therefore stays on ONE CU and the
+// round is made short instead:
+//   * every thread keeps its PPT points (x, y, z, running minimum) in REGISTERS for the whole kernel: a round touches
+//     the LDS only for the T/64 per-wave winners, and N is bounded by the register file (T x PPT points), not by 16 bytes
+//     of LDS per point; points beyond T x PPT (N > 16384) live in the LDS as before (the "tail", up to 160 KiB / 16 B more);
+//   * the winner's coordinates travel with its key: the lane that owns a wave's maximum writes (key, x, y, z) to its
+//     wave's slot, so the next centre needs no lookup by index (one barrier per round, slots double-buffered);
+//   * ties: key = (distance bits << 32) | ~index, i.e. the FIRST maximum, as torch.max(distance, -1)[1] (line 28).
+// Distances are the reference's exact float32 sequence ((dx^2 + dy^2) + dz^2, no FMA) -> indices are bit-exact.
 // ---------------------------------------------------------------------------------------------
-template <int T>
+template <int T, int PPT>
 __global__ void __launch_bounds__(T) fps_kernel(const float *__restrict__ xyz, int N, int npoint,
-                                                const int32_t *__restrict__ start, int32_t *__restrict__ out) {
+                                                const int32_t *__restrict__ start, int32_t *__restrict__ out, int ntail) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *sx = lds, *sy = lds + N, *sz = lds + 2 * N, *sd = lds + 3 * N;
-    __shared__ unsigned long long wmax[2][T / 64];
+    constexpr int NW = T / 64;
+    // one LDS object (a second __shared__ array beside a dynamic one can cost a vmcnt(0) per read, guide 5.4 item 4a):
+    // [2][NW] keys (u64) | [2][NW][4] winner coordinates | tail: x[ntail] y[ntail] z[ntail] d[ntail]
+    unsigned long long *wkey = reinterpret_cast<unsigned long long *>(lds);
+    float *wxyz = lds + 2 * 2 * NW;
+    float *sx = wxyz + 2 * NW * 4, *sy = sx + ntail, *sz = sy + ntail, *sd = sz + ntail;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *cloud = xyz + (size_t)b * N * 3;
-    for (int i = tid; i < N * 3; i += T) {
-        float v = cloud[i];
-        int p = i / 3, c = i - p * 3;
-        (c == 0 ? sx : c == 1 ? sy : sz)[p] = v;
+    float px[PPT], py[PPT], pz[PPT], pd[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = tid + j * T, pc = p < N ? p : N - 1;
+        px[j] = cloud[pc * 3 + 0], py[j] = cloud[pc * 3 + 1], pz[j] = cloud[pc * 3 + 2];
+        pd[j] = p < N ? 1e10f : -1.f;   // a slot past the cloud: min(d, -1) = -1 never beats a real (non-negative) distance
     }
-    for (int p = tid; p < N; p += T) sd[p] = 1e10f;
-    __syncthreads();
-
+    for (int q = tid; q < ntail; q += T) {
+        const int p = T * PPT + q;
+        sx[q] = cloud[p * 3 + 0], sy[q] = cloud[p * 3 + 1], sz[q] = cloud[p * 3 + 2], sd[q] = 1e10f;
+    }
     int far = start[b];
+    float cx = cloud[far * 3 + 0], cy = cloud[far * 3 + 1], cz = cloud[far * 3 + 2];
+    if (ntail) __syncthreads();
+
     for (int it = 0; it < npoint; ++it) {
         if (tid == 0) out[(size_t)b * npoint + it] = far;
-        const float cx = sx[far], cy = sy[far], cz = sz[far];
-        unsigned long long bestk = 0;  // (dist bits << 32) | (~n): larger distance first, then lower index
-        for (int p = tid; p < N; p += T) {
-            float d = direct_dist_exact(sx[p], sy[p], sz[p], cx, cy, cz);
-            float cur = sd[p];
-            if (d < cur) {
-                cur = d;
-                sd[p] = d;
-            }
-            unsigned long long kk = ((unsigned long long)f32_sortable(cur) << 32) | (unsigned)(0xffffffffu - (unsigned)p);
-            bestk = kk > bestk ? kk : bestk;
+        // inside a thread the points are visited in ascending index, so a strict float compare keeps the FIRST maximum;
+        // distances are non-negative, so their bit patterns order like unsigned integers -- the 64-bit key
+        // (distance bits << 32) | ~index is only built once per thread, for the cross-lane reduction
+        float bv = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
+        int bp = 0;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const float cur = fminf(direct_dist_exact(px[j], py[j], pz[j], cx, cy, cz), pd[j]);   // NaN distance: keeps pd, like dist < distance
+            pd[j] = cur;
+            const bool w = cur > bv;
+            bv = w ? cur : bv, bp = w ? tid + j * T : bp, bx = w ? px[j] : bx, by = w ? py[j] : by, bz = w ? pz[j] : bz;
         }
+        for (int q = tid; q < ntail; q += T) {
+            const float x = sx[q], y = sy[q], z = sz[q];
+            const float cur = fminf(direct_dist_exact(x, y, z, cx, cy, cz), sd[q]);
+            sd[q] = cur;
+            const bool w = cur > bv;
+            bv = w ? cur : bv, bp = w ? T * PPT + q : bp, bx = w ? x : bx, by = w ? y : by, bz = w ? z : bz;
+        }
+        // a thread without a valid point (bv < 0) contributes key 0, below every real key (~index is never 0)
+        const unsigned long long bestk =
+            bv < 0.f ? 0ull : ((unsigned long long)__float_as_uint(bv) << 32) | (unsigned)(0xffffffffu - (unsigned)bp);
+        unsigned long long wk = bestk;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
-            unsigned long long o = shfl_xor_u64(bestk, m);
-            bestk = o > bestk ? o : bestk;
+            const unsigned long long o = shfl_xor_u64(wk, m);
+            wk = o > wk ? o : wk;
         }
-        if (lane == 0) wmax[it & 1][wave] = bestk;
+        if (bestk == wk && (wk != 0ull || lane == 0)) {   // keys carry the point index: exactly one lane of the wave holds the maximum
+            wkey[(it & 1) * NW + wave] = wk;
+            float *w4 = wxyz + ((it & 1) * NW + wave) * 4;
+            w4[0] = bx, w4[1] = by, w4[2] = bz;
+        }
         __syncthreads();
         unsigned long long g = 0;
+        int gw = 0;
 #pragma unroll
-        for (int w = 0; w < T / 64; ++w) {
-            unsigned long long o = wmax[it & 1][w];
-            g = o > g ? o : g;
+        for (int w = 0; w < NW; ++w) {
+            const unsigned long long o = wkey[(it & 1) * NW + w];
+            const bool win = o > g;
+            g = win ? o : g, gw = win ? w : gw;
         }
         far = (int)(0xffffffffu - (unsigned)(g & 0xffffffffu));
+        const float *w4 = wxyz + ((it & 1) * NW + gw) * 4;
+        cx = w4[0], cy = w4[1], cz = w4[2];
     }
 }
 
@@ -627,18 +667,24 @@ extern "C" int pnpp_knn(const float *new_xyz, const float *xyz, int B, int S, in
 extern "C" int pnpp_fps(const float *xyz, int B, int N, int npoint, const int32_t *start, int32_t *out, void *stream) {
     PNPP_REQUIRE(xyz && start && out, PNPP_ERR_ARG, "fps: null pointer");
     PNPP_REQUIRE(B > 0 && N > 0 && npoint > 0, PNPP_ERR_ARG, "fps: non-positive size");
-    const size_t lds = (size_t)N * 4 * sizeof(float);
-    PNPP_REQUIRE(lds <= 160 * 1024 - 1024, PNPP_ERR_ARG, "fps: N=%d does not fit the 160 KiB LDS of one CU", N);
+    PNPP_REQUIRE(npoint <= N, PNPP_ERR_RANGE, "fps: npoint=%d > N=%d", npoint, N);
     hipStream_t st = as_stream(stream);
-    if (N <= 4096) {
-        auto kfn = fps_kernel<256>;
-        if (lds > 48 * 1024) hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kfn, dim3(B), dim3(256), lds, st, xyz, N, npoint, start, out);
-    } else {
-        auto kfn = fps_kernel<1024>;
-        hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kfn, dim3(B), dim3(1024), lds, st, xyz, N, npoint, start, out);
-    }
+    // points per thread live in registers; clouds beyond 1024 x 16 points keep the rest in the LDS (16 bytes per point)
+    constexpr int kRegPoints = 1024 * 16, kTailMax = (160 * 1024 - 2048) / 16;
+    PNPP_REQUIRE(N <= kRegPoints + kTailMax, PNPP_ERR_ARG, "fps: N=%d exceeds the %d points one CU can hold (registers + LDS)", N,
+                 kRegPoints + kTailMax);
+    const int ntail = N > kRegPoints ? N - kRegPoints : 0;
+    auto go = [&](auto kfn, int T) {
+        const size_t lds = ((size_t)2 * 2 * (T / 64) + (size_t)2 * (T / 64) * 4 + (size_t)4 * ntail) * sizeof(float);
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ProfScope ps(st, "fps_kernel<%d> B=%d N=%d npoint=%d", T, B, N, npoint);
+        hipLaunchKernelGGL(kfn, dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out, ntail);
+    };
+    if (N <= 1024) go(fps_kernel<256, 4>, 256);
+    else if (N <= 2048) go(fps_kernel<256, 8>, 256);
+    else if (N <= 4096) go(fps_kernel<512, 8>, 512);
+    else if (N <= 8192) go(fps_kernel<1024, 8>, 1024);
+    else go(fps_kernel<1024, 16>, 1024);
     PNPP_CHECK_LAUNCH("fps");
     return PNPP_OK;
 }
@@ -649,6 +695,7 @@ extern "C" int pnpp_ball_query(const float *new_xyz, const float *xyz, int B, in
     PNPP_REQUIRE(B > 0 && S > 0 && N > 0 && nsample > 0, PNPP_ERR_ARG, "ball_query: non-positive size");
     PNPP_REQUIRE(B <= 65535, PNPP_ERR_ARG, "ball_query: batch exceeds grid limit");
     const float r2 = (float)((double)radius * (double)radius);  // Demo.py:65: python float squared, compared in float32
+    ProfScope ps(as_stream(stream), "ball_query_kernel B=%d S=%d N=%d nsample=%d", B, S, N, nsample);
     hipLaunchKernelGGL(ball_query_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, as_stream(stream), new_xyz, xyz, S, N, r2,
                        nsample, idx);
     PNPP_CHECK_LAUNCH("ball_query");

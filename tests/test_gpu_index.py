@@ -80,13 +80,32 @@ def test_fps_matches_demo(ops, oracle, golden):
     assert np.array_equal(got, g["fpsr_idx"])
 
 
-@pytest.mark.parametrize("B,N,npoint", [(1, 1, 1), (2, 100, 100), (3, 4097, 40), (1, 10000, 64)])
+@pytest.mark.parametrize("B,N,npoint", [(1, 1, 1), (2, 100, 100), (32, 1024, 128), (2, 2048, 128), (3, 4097, 40), (1, 10000, 64),
+                                        (2, 16384, 128),      # the largest cloud held entirely in registers (1024 threads x 16)
+                                        (1, 20000, 48)])      # registers + the LDS tail
 def test_fps_sizes(ops, oracle, B, N, npoint):
     g = torch.Generator().manual_seed(N)
     xyz = torch.rand(B, N, 3, generator=g)
     start = torch.randint(0, N, (B,), generator=g)
     got = ops.farthest_point_sample(xyz.cuda(), npoint, start).cpu().numpy()
     assert np.array_equal(got, oracle.farthest_point_sample(xyz, npoint, start.numpy()).numpy())
+
+
+def test_fps_duplicates_take_the_first_maximum(ops, oracle):
+    """Duplicated points give exact distance ties: torch.max(distance, -1)[1] (PointNet++Demo.py:28) returns the first."""
+    g = torch.Generator().manual_seed(5)
+    base = torch.rand(1, 300, 3, generator=g)
+    xyz = torch.cat([base, base, base[:, :100]], 1)[:, torch.randperm(700, generator=g)]
+    start = torch.tensor([17])
+    got = ops.farthest_point_sample(xyz.cuda(), 64, start).cpu().numpy()
+    assert np.array_equal(got, oracle.farthest_point_sample(xyz, 64, start.numpy()).numpy())
+
+
+def test_fps_limits(ops):
+    with pytest.raises(ValueError):          # beyond registers + LDS of one CU
+        ops.farthest_point_sample(torch.rand(1, 30000, 3).cuda(), 8, torch.zeros(1, dtype=torch.long))
+    with pytest.raises(RuntimeError):        # npoint > N (PNPP_ERR_RANGE)
+        ops.farthest_point_sample(torch.rand(1, 10, 3).cuda(), 11, torch.zeros(1, dtype=torch.long))
 
 
 def test_ball_query_matches_demo(ops, oracle, golden):

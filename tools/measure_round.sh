@@ -1,0 +1,33 @@
+#!/bin/bash
+# One measurement pass on the GPU box (run through gpurun): writes raw rocprofv3 output under gpurun_out/<tag>/ and the
+# condensed summaries (the files that are committed) under gpurun_out/<tag>/profiles/.  Usage: tools/measure_round.sh <tag> <git-rev>
+# The profiled program comes directly after `--` (python3 bench.py ...): no env/bash wrapper, and counter passes are
+# separate runs with --pmc only (no trace domains beside them).
+set -e -o pipefail
+TAG=${1:-round2}
+export PNPP_GIT_REV=${2:-unknown}
+OUT=gpurun_out/$TAG
+P=$OUT/profiles
+mkdir -p $P
+export TMPDIR=/tmp
+BENCH="bench.py --steps 200 --warmup 20 --no-cpu-baseline"
+echo "[1/6] bench line"; python3 bench.py --steps 200 --warmup 20 > $P/${TAG}_bench.json 2> $OUT/bench.err
+PNPP_BENCH_DUMP=$P/${TAG}_kernel_table_events.txt python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline > /dev/null 2>> $OUT/bench.err
+echo "[2/6] kernel trace of the step"; rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $BENCH --no-roofline > $OUT/trace.log 2>&1
+python3 tools/summarize_rocprof.py stats $OUT/trace $P/${TAG}_kernel_stats.csv
+echo "[3/6] FETCH_SIZE of the step"; rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-graph > $OUT/fetch.log 2>&1
+echo "[4/6] WRITE_SIZE of the step"; rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-graph > $OUT/write.log 2>&1
+python3 tools/summarize_rocprof.py pmc $OUT/fetch $OUT/write $P/pmc_traffic.json $P/${TAG}_pmc_traffic.csv
+python3 tools/summarize_rocprof.py pmc-all $OUT/fetch $OUT/write $P/${TAG}_pmc_traffic_all_kernels.json $P/${TAG}_pmc_traffic_all_kernels.csv
+echo "[5/6] index kernels: events, trace, counters"
+python3 tools/bench_index_kernels.py --json $P/${TAG}_index_kernels.json > $P/${TAG}_index_kernels.txt 2> $OUT/idx.err
+rocprofv3 --kernel-trace --stats -d $OUT/idx_trace -o idx --output-format csv -- python3 tools/bench_index_kernels.py --reps 5 > $OUT/idx_trace.log 2>&1
+python3 tools/summarize_rocprof.py stats $OUT/idx_trace $P/${TAG}_index_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE -d $OUT/idx_fetch -o f --output-format csv -- python3 tools/bench_index_kernels.py --reps 3 > $OUT/idx_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/idx_write -o w --output-format csv -- python3 tools/bench_index_kernels.py --reps 3 > $OUT/idx_write.log 2>&1
+python3 tools/summarize_rocprof.py pmc-all $OUT/idx_fetch $OUT/idx_write $P/${TAG}_index_pmc_traffic.json $P/${TAG}_index_pmc_traffic.csv
+echo "[6/6] batch sweep"
+python3 tools/batch_sweep.py > $P/${TAG}_batch_sweep.json 2> $OUT/sweep.err
+# raw directories can be large: keep only the summaries for the merge back
+rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/idx_trace $OUT/idx_fetch $OUT/idx_write
+ls -la $P
