@@ -70,9 +70,15 @@ __device__ __forceinline__ void philox4(unsigned c0, unsigned c1, unsigned c2, u
 
 // one wave per pair of 32 x 32 tiles: lane = (tile half, row); 8 Philox calls give the row's 32 uniform words
 __global__ void __launch_bounds__(256)
-attention_dropout_mask_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_lo, unsigned str_hi, int N, unsigned thresh,
-                              unsigned *__restrict__ mask, unsigned *__restrict__ maskT) {
+attention_dropout_mask_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_lo, unsigned str_hi,
+                              unsigned long long *__restrict__ str_dev, int N, unsigned thresh, unsigned *__restrict__ mask,
+                              unsigned *__restrict__ maskT) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+    // stream id = (str_hi:str_lo) [+ the call counter in device memory: a captured step draws fresh masks on every replay];
+    // a call owns the eight Philox counter words 8 * id .. 8 * id + 7, so consecutive calls share none
+    unsigned long long sid = ((unsigned long long)str_hi << 32) | str_lo;
+    if (str_dev) sid += str_dev[0];
+    sid <<= 3;
     const int nw = N / 32;                                  // words per row
     const size_t wave_id = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const size_t tile = wave_id * 2 + lh;                   // (bh, query block, key block) flattened
@@ -84,7 +90,8 @@ attention_dropout_mask_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_l
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         unsigned r[4];
-        philox4((unsigned)(q * nw + kb), (unsigned)bh, str_lo + (unsigned)c, str_hi, seed_lo, seed_hi, r);
+        const unsigned long long sc = sid + (unsigned long long)c;
+        philox4((unsigned)(q * nw + kb), (unsigned)bh, (unsigned)sc, (unsigned)(sc >> 32), seed_lo, seed_hi, r);
 #pragma unroll
         for (int e = 0; e < 4; ++e) w |= (r[e] >= thresh ? 1u : 0u) << (4 * c + e);   // keep with probability 1 - p
     }
@@ -98,6 +105,16 @@ attention_dropout_mask_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_l
         if (l31 == j) wt = half;
     }
     maskT[(bh * N + kb * 32 + l31) * nw + qb] = wt;
+    if (str_dev) {   // post-increment: every workgroup has read str_dev[0] before it takes a ticket; the last one bumps the counter
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long t = atomicAdd(&str_dev[1], 1ull);
+            if (t == (unsigned long long)gridDim.x - 1ull) {
+                str_dev[1] = 0ull;
+                str_dev[0] += 1ull;
+            }
+        }
+    }
 }
 
 constexpr int ATT_DH = 16;
@@ -501,8 +518,8 @@ extern "C" int pnpp_linear_smallk(const float *x, const float *w, const float *b
     return PNPP_OK;
 }
 
-extern "C" int pnpp_attention_dropout_mask(uint64_t seed, uint64_t stream_id, int B, int N, int H, float p, uint32_t *mask,
-                                           uint32_t *maskT, void *stream) {
+static int attention_dropout_mask_impl(uint64_t seed, uint64_t stream_id, uint64_t *stream_id_dev, int B, int N, int H, float p,
+                                       uint32_t *mask, uint32_t *maskT, void *stream) {
     PNPP_REQUIRE(mask && maskT, PNPP_ERR_ARG, "attention_dropout_mask: null pointer");
     PNPP_REQUIRE(B > 0 && N > 0 && H > 0 && N % 128 == 0, PNPP_ERR_ARG, "attention_dropout_mask: bad size (N %% 128 == 0)");
     PNPP_REQUIRE(p >= 0.f && p < 1.f, PNPP_ERR_ARG, "attention_dropout_mask: p=%g outside [0, 1)", (double)p);
@@ -513,9 +530,21 @@ extern "C" int pnpp_attention_dropout_mask(uint64_t seed, uint64_t stream_id, in
     PNPP_REQUIRE(blocks <= 0x7fffffff, PNPP_ERR_ARG, "attention_dropout_mask: too many tiles");
     ProfScope ps(as_stream(stream), "attention_dropout_mask_kernel B=%d N=%d H=%d", B, N, H);
     hipLaunchKernelGGL(attention_dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (unsigned)seed,
-                       (unsigned)(seed >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32), N, thresh, mask, maskT);
+                       (unsigned)(seed >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32),
+                       reinterpret_cast<unsigned long long *>(stream_id_dev), N, thresh, mask, maskT);
     PNPP_CHECK_LAUNCH("attention_dropout_mask");
     return PNPP_OK;
+}
+
+extern "C" int pnpp_attention_dropout_mask(uint64_t seed, uint64_t stream_id, int B, int N, int H, float p, uint32_t *mask,
+                                           uint32_t *maskT, void *stream) {
+    return attention_dropout_mask_impl(seed, stream_id, nullptr, B, N, H, p, mask, maskT, stream);
+}
+
+extern "C" int pnpp_attention_dropout_mask_dev(uint64_t seed, uint64_t *stream_id_dev, uint64_t offset, int B, int N, int H, float p,
+                                               uint32_t *mask, uint32_t *maskT, void *stream) {
+    PNPP_REQUIRE(stream_id_dev, PNPP_ERR_ARG, "attention_dropout_mask_dev: null counter pointer");
+    return attention_dropout_mask_impl(seed, offset, stream_id_dev, B, N, H, p, mask, maskT, stream);
 }
 
 extern "C" int pnpp_attention_fwd(const float *qkv, int B, int N, int H, int head_dim, const uint32_t *mask, float p, float *out,

@@ -100,6 +100,7 @@ SIGNATURES = {
     "pnpp_linear_smallk": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
     "pnpp_attention_fwd": (_i, [_fp, _i, _i, _i, _i, _fp, _f, _fp, _fp, _fp]),
     "pnpp_attention_dropout_mask": (_i, [_u64, _u64, _i, _i, _i, _f, _fp, _fp, _fp]),
+    "pnpp_attention_dropout_mask_dev": (_i, [_u64, _fp, _u64, _i, _i, _i, _f, _fp, _fp, _fp]),
     "pnpp_add_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp, _fp]),
     "pnpp_mean_points": (_i, [_fp, _i, _i, _i, _fp, _fp]),
     "pnpp_linear_smallk_bwd_scratch_bytes": (_sz, [_i, _i]),

@@ -53,21 +53,37 @@ def linear_smallk(x2d: torch.Tensor, lin) -> torch.Tensor:
     return _LinearSmallK.apply(x2d, lin.weight, lin.bias, (ops.grad_sink(lin.weight), ops.grad_sink(lin.bias)))
 
 
-_drop_state = {"calls": 0}
+_att_counters = {}
+
+
+def _att_counter(device: torch.device) -> torch.Tensor:
+    """Device-side call counter of the attention-dropout draws: [calls so far, ticket word], bumped by the mask kernel
+    itself, so a step captured in a hipGraph draws fresh masks on every replay (a host-side counter would be frozen into
+    the capture and replay the same mask)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    c = _att_counters.get(key)
+    if c is None:
+        c = torch.zeros(2, dtype=torch.int64, device=device)
+        _att_counters[key] = c
+        ops._dropout_counters[("attention",) + key] = c      # pnpp_hip.sampling.snapshot()/restore() cover it too
+    return c
 
 
 def attention_dropout_mask(B: int, N: int, H: int, p: float, device, seed=None, stream_id=None):
     """Bit-packed keep masks (mask, maskT), each (B,H,N,N/32) int32, for dropout p on the attention weights.  The bits are
-    a pure function of (seed, stream_id); by default seed = torch.initial_seed() and stream_id counts the calls."""
+    a pure function of (seed, stream id); seed defaults to torch.initial_seed().  With an explicit `stream_id` that is the
+    id; by default it is 1 + the number of draws made so far on this device, counted in device memory."""
     if seed is None:
         seed = torch.initial_seed()
-    if stream_id is None:
-        _drop_state["calls"] += 1
-        stream_id = _drop_state["calls"]
+    device = torch.device(device)
     mask = torch.empty(B, H, N, N // 32, device=device, dtype=torch.int32)
     maskT = torch.empty_like(mask)
-    L.check(L.lib().pnpp_attention_dropout_mask(int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1), B, N, H, float(p),
-                                                mask.data_ptr(), maskT.data_ptr(), _stream()))
+    if stream_id is None:
+        L.check(L.lib().pnpp_attention_dropout_mask_dev(int(seed) & (2**64 - 1), _att_counter(device).data_ptr(), 1, B, N, H, float(p),
+                                                        mask.data_ptr(), maskT.data_ptr(), _stream()))
+    else:
+        L.check(L.lib().pnpp_attention_dropout_mask(int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1), B, N, H, float(p),
+                                                    mask.data_ptr(), maskT.data_ptr(), _stream()))
     return mask, maskT
 
 

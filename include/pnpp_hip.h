@@ -295,6 +295,11 @@ int pnpp_attention_fwd(const float *qkv, int B, int N, int H, int head_dim, cons
  * queries), read by the dK/dV kernel. */
 int pnpp_attention_dropout_mask(uint64_t seed, uint64_t stream_id, int B, int N, int H, float p, uint32_t *mask,
                                 uint32_t *maskT, void *stream);
+/* The same with the stream id kept in device memory (stream_id_dev[0] = calls so far, stream_id_dev[1] = ticket word, both
+ * zero-initialised by the caller): stream id = offset + stream_id_dev[0], read by the launch, which then adds 1 -- a
+ * train step captured in a hipGraph draws fresh masks on every replay (nn.Dropout semantics), reproducibly. */
+int pnpp_attention_dropout_mask_dev(uint64_t seed, uint64_t *stream_id_dev, uint64_t offset, int B, int N, int H, float p,
+                                    uint32_t *mask, uint32_t *maskT, void *stream);
 /* Post-norm residual block: y (M,E) = LayerNorm(x + r) * w + b over the last dimension (r may be NULL), E <= 128. */
 int pnpp_add_layernorm(const float *x, const float *r, const float *w, const float *b, int M, int E, float eps, float *y,
                        void *stream);

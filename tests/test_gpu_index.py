@@ -261,3 +261,32 @@ def test_paired_device_draw_equals_two_draws():
         b1, b2 = ops.sample_random_dev2(1234, c_b, 7, 5, 1000, 128, 128, 32)
         assert torch.equal(a1, b1) and torch.equal(a2, b2)
         assert torch.equal(c_a, c_b) and int(c_b[0]) == base + 2 and int(c_b[1]) == 0
+
+
+def test_device_samplers_bit_exact_vs_oracle(ops):
+    """The device-side centre sampler and the on-device point subsampler against their CPU restatement
+    (oracle/sampler.py, Philox4x32-10 pinned by the Random123 vectors in tests/test_oracle_sampler.py): the drawn INDICES
+    are bit-exact, hence the gathered rows equal numpy's gather of the same indices -- not just "a plausible subset"."""
+    from oracle import sampler as S
+    import dataloader_common as dc
+    seed = 0x1234_5678_9ABC_DEF1
+    for stream, B, N, npoint in ((1, 4, 1024, 128), ((3 << 40) + 17, 3, 128, 32), (5, 2, 10000, 128), (9, 2, 300, 300)):
+        got = ops.sample_random(seed, stream, B, N, npoint, "cuda").cpu().numpy()
+        assert np.array_equal(got, S.sample_random(seed, stream, B, N, npoint)), (stream, B, N, npoint)
+    # the graph-replayable form: stream id = offset + device counter, post-incremented by the kernel
+    cnt = torch.tensor([41, 0], dtype=torch.int64, device="cuda")
+    a = ops.sample_random_dev(seed, cnt, 7, 3, 1000, 64).cpu().numpy()
+    b = ops.sample_random_dev(seed, cnt, 7, 3, 1000, 64).cpu().numpy()
+    assert np.array_equal(a, S.sample_random(seed, 48, 3, 1000, 64)) and np.array_equal(b, S.sample_random(seed, 49, 3, 1000, 64))
+    # point subsampling: without replacement (L >= num), with replacement (L < num), empty cloud, L == num
+    rng = np.random.default_rng(0)
+    lens = [5000, 300, 1024, 0, 1, 16383]
+    clouds = [rng.standard_normal((n, 3)).astype(np.float32) for n in lens]
+    bank = dc.DeviceCloudBank(clouds, "cuda", seed=77)
+    ids = [0, 1, 2, 3, 4, 5, 0]
+    num = 1024
+    out = bank.sample(torch.tensor(ids), num).cpu().numpy()          # first draw of the bank: stream id 1
+    for slot, cid in enumerate(ids):
+        idx = S.subsample_indices(77, 1, slot, lens[cid], num)
+        want = clouds[cid][idx] if lens[cid] else np.zeros((num, 3), np.float32)
+        assert np.array_equal(out[slot], want), (slot, cid)

@@ -202,3 +202,36 @@ def test_point_transformer_trains_with_default_dropout():
     assert all(v == v for v in hist) and sum(hist[-5:]) / 5 < 0.7 * sum(hist[:5]) / 5, (hist[:5], hist[-5:])
     for n, prm in model.named_parameters():
         assert prm.grad is None or torch.isfinite(prm.grad).all(), n
+
+
+def test_attention_dropout_streams_are_disjoint_and_device_counted():
+    """Consecutive draws share no Philox counter word (an earlier layout made call k+1 a bit-shifted copy of call k), and the
+    default stream id lives in device memory: the kernel itself advances it, so a captured step draws fresh masks on replay."""
+    from pnpp_hip import transformer as T
+    B, N, H, p = 1, 256, 2, 0.5
+    m3, _ = T.attention_dropout_mask(B, N, H, p, "cuda", seed=11, stream_id=3)
+    m4, _ = T.attention_dropout_mask(B, N, H, p, "cuda", seed=11, stream_id=4)
+    a, b = m3.cpu().numpy().astype(np.uint32), m4.cpu().numpy().astype(np.uint32)
+    for sh in (0, 4, 8):   # call k+1 is no shifted copy of call k: agreement of the overlapping bits stays at chance level
+        agree = np.unpackbits((~((a >> sh) ^ b) & (0xFFFFFFFF >> sh)).view(np.uint8)).mean() * 32 / (32 - sh)
+        assert 0.47 < agree < 0.53, (sh, agree)
+    cnt = T._att_counter(torch.device("cuda"))
+    before = int(cnt[0])
+    d1, _ = T.attention_dropout_mask(B, N, H, p, "cuda", seed=11)
+    d2, _ = T.attention_dropout_mask(B, N, H, p, "cuda", seed=11)
+    assert int(cnt[0]) == before + 2 and int(cnt[1]) == 0 and not torch.equal(d1, d2)
+    e1, _ = T.attention_dropout_mask(B, N, H, p, "cuda", seed=11, stream_id=before + 1)   # default id = 1 + draws so far
+    assert torch.equal(d1, e1)
+    # captured: the replayed launch reads the counter at run time
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        T.attention_dropout_mask(B, N, H, p, "cuda", seed=11)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        gm, _ = T.attention_dropout_mask(B, N, H, p, "cuda", seed=11)
+    g.replay()
+    r1 = gm.clone()
+    g.replay()
+    assert not torch.equal(r1, gm)
