@@ -1426,6 +1426,7 @@ int launch_gemm(const AOperand &A, const BOperand &Bin, int M, int Nout, int Kd,
     if (B.rows <= 0 || B.rows > Kd) B.rows = Kd;
     {
         int rc = PNPP_OK;
+        if (try_launch_ws_bf16(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;   // only in the opt-in bf16-operand mode
         if (try_launch_ws(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;
     }
     const bool a_aligned = (A.mode == A_CONCAT || A.mode == A_GATHER) || (A.lda % 4 == 0 && ((uintptr_t)A.a & 15) == 0);

@@ -95,6 +95,13 @@ struct BOperand {
 int launch_gemm(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab,
                 hipStream_t st, int *dw_slabs = nullptr);
 
+// gemm_bf16_kernels.hip: the bf16-operand / float32-accumulate variant of the weights-stationary kernel (throughput mode,
+// off by default; pnpp_set_matmul_precision / PNPP_MATMUL=bf16).  Returns false when the shape stays on the float32 kernels.
+int matmul_precision();
+void set_matmul_precision(int bf16);
+bool try_launch_ws_bf16(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st,
+                        int *rc, int *dw_slabs);
+
 // dW[Nc x Kp] = dZ^T[Nc x M] * A2[M x Kp], split over `nsplit` row ranges into slab[nsplit][Nc][kp_pad].
 // dz is produced as in A_DZ (or read directly when dz.mode == A_PLAIN); A2 by its own AOperand.
 int launch_dw(const AOperand &dz, int Nc, const AOperand &a2, int Kp, int M, float *slab, int nsplit, int kp_pad,

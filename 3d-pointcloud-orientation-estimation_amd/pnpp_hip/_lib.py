@@ -109,6 +109,8 @@ SIGNATURES = {
     "pnpp_add_layernorm_bwd_scratch_bytes": (_sz, [_i, _i]),
     "pnpp_add_layernorm_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp, _fp, _fp, _fp]),
     "pnpp_mean_points_bwd": (_i, [_fp, _i, _i, _i, _fp, _fp]),
+    "pnpp_set_matmul_precision": (_i, [_i]),
+    "pnpp_get_matmul_precision": (_i, []),
     "pnpp_adam_step": (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _f, _f, _f, _f, _fp]),
     "pnpp_adam_step_zero": (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _f, _f, _f, _f, _fp]),
     "pnpp_adam_step_dev": (_i, [_fp, _fp, _fp, _fp, _sz, _fp, _f, _f, _f, _f, _f, _i, _fp]),

@@ -26,6 +26,7 @@ COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wno-unused-v
 SOURCES = {
     "index_kernels.hip": ["-ffp-contract=off"],
     "gemm_kernels.hip": [],
+    "gemm_bf16_kernels.hip": [],
     "loss_kernels.hip": [],
     "sa_api.hip": [],
     "fc_api.hip": [],

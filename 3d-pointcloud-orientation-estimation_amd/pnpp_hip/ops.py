@@ -100,6 +100,19 @@ def _scratch(nbytes: int, device: torch.device) -> torch.Tensor:
     return buf
 
 
+def set_matmul_precision(mode: str) -> None:
+    """'f32' (default: exact float32 MFMA, the reference's arithmetic) or 'bf16' (throughput mode: the grouped layers' large
+    GEMMs round their two operands to bfloat16 and accumulate in float32; everything else stays float32 / float64).
+    Process-wide; a hipGraph captured under one mode keeps it."""
+    if mode not in ("f32", "bf16"):
+        raise ValueError(f"matmul precision must be 'f32' or 'bf16', got {mode!r}")
+    L.check(L.lib().pnpp_set_matmul_precision(1 if mode == "bf16" else 0))
+
+
+def get_matmul_precision() -> str:
+    return "bf16" if L.lib().pnpp_get_matmul_precision() else "f32"
+
+
 # ------------------------------------------------------------------------------------------------
 # index primitives
 # ------------------------------------------------------------------------------------------------

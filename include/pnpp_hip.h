@@ -323,6 +323,15 @@ int pnpp_add_layernorm_bwd(const float *x, const float *r, const float *w, const
 int pnpp_mean_points_bwd(const float *dy, int B, int N, int E, float *dx, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Throughput mode of the grouped layers (BASELINE.json configs[1] names a bf16 mode; the reference itself is float32,
+ * models/pointnet_pp_8dir.py:40-42): bf16_operands != 0 makes the large 1x1-conv GEMMs of pnpp_sa_forward / pnpp_sa_backward
+ * round their two MFMA operands to bfloat16 (float32 accumulate; activations, statistics, transforms stay float32 / float64).
+ * Process-wide, default 0 (exact float32), initial value from the environment variable PNPP_MATMUL=bf16.
+ * ---------------------------------------------------------------------------------------- */
+int pnpp_set_matmul_precision(int bf16_operands);
+int pnpp_get_matmul_precision(void);
+
+/* ------------------------------------------------------------------------------------------
  * Step glue on one flat parameter / gradient buffer
  * (train_single_peak_vonMises_KL.py:80,85; train_multi_peaks_vonMises_KL.py:221,235-236)
  * ---------------------------------------------------------------------------------------- */
