@@ -20,8 +20,9 @@
 // lane holds in the accumulator layout -- registers 8s..8s+7 of lane-half lh -- are the tile rows (2s + lh) + 4j,
 // j = 0..7: exactly the rows ONE staging thread loaded (row slot rho = 2s + lh).  Consequences: the transposed image is
 // written with one 16-byte store per (column, 8 rows), and the second operand of the fused dW product,
-// relu(bn(z_{l-1})), goes from the epilogue's registers straight into the MFMA (8 consecutive registers = one operand):
-// it never touches the LDS.
+// relu(bn(z_{l-1})), is 8 consecutive epilogue registers per MFMA operand: each lane stores its two operands (16 bytes
+// each) into a small [64 k][8 chunks] image of the same form, so that every wave can contract over all 64 rows of the
+// tile and a wave owns whole dW tiles (half as many accumulators as with per-half partial sums, one partial per worker).
 #include "kernels.h"
 
 namespace pnpp {
@@ -49,7 +50,7 @@ __device__ __forceinline__ uint2 pk4_bf16(float a, float b, float c, float d) { 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 template <int KD, int AMODE, int EMODE, bool FDW>
-__global__ void __launch_bounds__(256, ((KD >= 256 || (FDW && KD >= 128)) ? 1 : 2))  // the fused kernels hold KD / 32 dW accumulators per wave
+__global__ void __launch_bounds__(256, (KD >= 256 ? 1 : 2))  // K = 256: the three images fill the LDS, one workgroup per CU anyway
 gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, const Epilogue E) {
     constexpr int BM = 64, BN = 64;
     constexpr int G4 = KD / 4;             // float4 column groups per row = threads per row
@@ -62,6 +63,7 @@ gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, c
     static_assert(!FDW || EMODE == E_MASK_STATS, "fused dW needs the ReLU-mask epilogue");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *Wb = lds, *Ab = lds + BN * PITCH, *AT = Ab + BM * PITCH;  // AT: [KD][128 bytes]
+    unsigned char *aT = AT + KD * 128;                                         // FDW: [BN][128 bytes], relu(bn(z_{l-1})) transposed
     auto swz = [](int r) { return CH >= 16 ? (r & 15) : ((r >> 1) & 7); };       // chunk XOR of row r (Wb / Ab)
     auto swzT = [](int c) { return (c >> 1) & 7; };                              // chunk XOR of row c (AT, 8 chunks)
 
@@ -104,16 +106,24 @@ gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, c
                 for (int e = 0; e < 4; ++e) t[e] *= (n < Nout && k4 + e < B.rows) ? 1.f : 0.f;
                 *reinterpret_cast<uint2 *>(Wb + nl * PITCH + 16 * ((k4 >> 3) ^ swz(nl)) + 2 * (k4 & 7)) = pk4_bf16(t[0], t[1], t[2], t[3]);
             }
-        } else {  // b is [Kd][Nout]: a thread takes four consecutive k of one output column (coalesced over n)
-            for (int f = tid; f < BN * G4; f += 256) {
-                const int nl = f % BN, k4 = 4 * (f / BN), n = n0 + nl;
+        } else {  // b is [Kd][Nout]: one 16-byte load of four consecutive output columns of row k, four 2-byte LDS stores
+            const bool bvec = (ldb & 3) == 0 && ((uintptr_t)Bm & 15) == 0;
+            for (int f = tid; f < KD * (BN / 4); f += 256) {
+                const int kk = f / (BN / 4), nl = 4 * (f % (BN / 4)), n = n0 + nl;
+                const float *src = Bm + (size_t)min(kk, B.rows - 1) * ldb;
                 float t[4];
+                if (bvec) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src + min(n, Nout - 4));
+                    t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = src[min(n + e, Nout - 1)];
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int kk = k4 + e;
-                    t[e] = Bm[(size_t)min(kk, B.rows - 1) * ldb + min(n, Nout - 1)] * ((kk < B.rows && n < Nout) ? 1.f : 0.f);
+                    const float w = t[e] * ((kk < B.rows && n + e < Nout) ? 1.f : 0.f);
+                    *reinterpret_cast<__bf16 *>(Wb + (nl + e) * PITCH + 16 * ((kk >> 3) ^ swz(nl + e)) + 2 * (kk & 7)) = (__bf16)w;
                 }
-                *reinterpret_cast<uint2 *>(Wb + nl * PITCH + 16 * ((k4 >> 3) ^ swz(nl)) + 2 * (k4 & 7)) = pk4_bf16(t[0], t[1], t[2], t[3]);
             }
         }
     }
@@ -141,9 +151,10 @@ gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, c
     const int a_x = swz(arow), b_x = swz(brow);
 
     double s1 = 0.0, s2 = 0.0;
-    f32x16 dwacc[FDW ? NCT : 1];
+    constexpr int NDW = FDW ? NCT / 2 : 1;   // dW tiles per wave: c-tiles ct = 2 t + wm, column tile wn
+    f32x16 dwacc[NDW];
 #pragma unroll
-    for (int t = 0; t < (FDW ? NCT : 1); ++t)
+    for (int t = 0; t < NDW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dwacc[t][r] = 0.f;
 
@@ -234,9 +245,9 @@ gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, c
             }
         }
         __syncthreads();
-        if (tile + nworkers < tiles) fetch((tile + nworkers) * BM);  // next tile's HBM stream flies during the MFMA work
-
         // rows / column of this lane's 16 accumulator registers: register 8 s + j  <->  tile row 32 wm + (2 s + lh) + 4 j
+        // (the epilogue's loads go out FIRST: vmcnt retires in order, so waiting for them later leaves the next tile's
+        // stream, issued behind them, in flight -- the MFMA work of a bf16 tile is too short to hide a full round trip)
         const int col = n0 + 32 * wn + l31;
         float zp[16];
         if constexpr (EMODE == E_MASK_STATS) {
@@ -246,6 +257,7 @@ gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, c
                 zp[r] = E.zp[(size_t)min(row, M - 1) * E.ldc + min(col, Nout - 1)];
             }
         }
+        if (tile + nworkers < tiles) fetch((tile + nworkers) * BM);  // next tile's HBM stream flies during the rest of this tile
 
         f32x16 acc;
 #pragma unroll
@@ -296,34 +308,50 @@ gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, c
         if constexpr (EMODE != E_STORE) s1 += (double)t1, s2 += (double)t2;
 
         if constexpr (FDW) {
-            // dW[c][k] += sum over this wave's 32 rows of dZ[row][c] a[row][k]: first operand from the transposed image
-            // (lane = c, chunk 4 wm + 2 s + lh = rows (2 s + lh) + 4 j of half wm), second operand = av registers 8 s .. 8 s + 7
-            uint4 bop[2];
+            // relu(bn(z_{l-1})) of this lane's column k and its 16 rows -> the transposed image: chunk 4 wm + 2 s + lh of row k
+            // holds rows (2 s + lh) + 4 j of half wm, the same slot the dZ image uses for them
+            {
+                const int k = 32 * wn + l31;
+                unsigned char *krow = aT + k * 128;
+                const int kx = swzT(k);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                bop[s] = make_uint4(pk_bf16(av[8 * s + 0], av[8 * s + 1]), pk_bf16(av[8 * s + 2], av[8 * s + 3]),
-                                    pk_bf16(av[8 * s + 4], av[8 * s + 5]), pk_bf16(av[8 * s + 6], av[8 * s + 7]));
+                for (int s = 0; s < 2; ++s)
+                    *reinterpret_cast<uint4 *>(krow + 16 * ((4 * wm + 2 * s + lh) ^ kx)) =
+                        make_uint4(pk_bf16(av[8 * s + 0], av[8 * s + 1]), pk_bf16(av[8 * s + 2], av[8 * s + 3]),
+                                   pk_bf16(av[8 * s + 4], av[8 * s + 5]), pk_bf16(av[8 * s + 6], av[8 * s + 7]));
+            }
+            __syncthreads();
+            // dW[c][k] += sum over the tile's 64 rows of dZ[row][c] a[row][k]: step p = 2 h + s contracts the 16 rows
+            // {(2 s + g) + 4 j of half h : g = lane half}; both operands read chunk 4 h + 2 s + lh of their row
+            uint4 bop[4];
+            {
+                const int k = 32 * wn + l31;
+                const unsigned char *krow = aT + k * 128;
+                const int kx = swzT(k);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const int c = 32 * ct + l31;
+                for (int p2 = 0; p2 < 4; ++p2) bop[p2] = *reinterpret_cast<const uint4 *>(krow + 16 * ((4 * (p2 >> 1) + 2 * (p2 & 1) + lh) ^ kx));
+            }
+#pragma unroll
+            for (int t = 0; t < NDW; ++t) {
+                const int c = 32 * (2 * t + wm) + l31;
                 const unsigned char *crow = AT + c * 128;
                 const int cx = swzT(c);
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const uint4 aop = *reinterpret_cast<const uint4 *>(crow + 16 * ((4 * wm + 2 * s + lh) ^ cx));
-                    dwacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(aop), as_bf16x8(bop[s]), dwacc[ct], 0, 0, 0);
+                for (int p2 = 0; p2 < 4; ++p2) {
+                    const uint4 aop = *reinterpret_cast<const uint4 *>(crow + 16 * ((4 * (p2 >> 1) + 2 * (p2 & 1) + lh) ^ cx));
+                    dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(aop), as_bf16x8(bop[p2]), dwacc[t], 0, 0, 0);
                 }
             }
         }
     }
 
-    if constexpr (FDW) {  // one partial dW per (worker, row half): dwslab[2 worker + wm][c][n0 + k]; standard accumulator layout
+    if constexpr (FDW) {  // one partial dW per worker: dwslab[worker][c][n0 + k]; standard accumulator layout
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
+        for (int t = 0; t < NDW; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int c = 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lh, k = n0 + 32 * wn + l31;
-                if (k < Nout) E.dwslab[((size_t)(2 * worker + wm) * KD + c) * E.dw_ld + k] = dwacc[ct][r];
+                const int c = 32 * (2 * t + wm) + (r & 3) + 8 * (r >> 2) + 4 * lh, k = n0 + 32 * wn + l31;
+                if (k < Nout) E.dwslab[((size_t)worker * KD + c) * E.dw_ld + k] = dwacc[t][r];
             }
     }
 
@@ -349,18 +377,17 @@ template <int KD, int AM, int EM, bool FDW>
 static int launch_wsb_one(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int *nslab, hipStream_t st,
                           int *dw_slabs) {
     const int tiles = cdiv(M, 64), ncol = cdiv(Nout, 64);
-    size_t lds = (size_t)64 * KD * 2 * 2 + (FDW ? (size_t)KD * 128 : 0);
+    size_t lds = (size_t)64 * KD * 2 * 2 + (FDW ? (size_t)KD * 128 + 64 * 128 : 0);
     if (lds < 4096) lds = 4096;  // the column-statistics reduction reuses the LDS: 2 x 2 x 64 doubles
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 3) per_cu = 3;
-    if (KD >= 256 || (FDW && KD >= 128)) per_cu = 1;   // __launch_bounds__(256, 1), see the kernel
+    if (per_cu > 2) per_cu = FDW ? 2 : 3;   // __launch_bounds__(256, 2): the fused kernels need ~200 registers
     int workers = (256 * per_cu) / ncol;
     if (workers > tiles) workers = tiles;
-    const int cap = FDW ? kMaxStatBlocks / 2 : kMaxStatBlocks;  // two dW partials per worker
-    if (workers > cap) workers = cap;
+    if (workers > kMaxStatBlocks) workers = kMaxStatBlocks;
     if (workers < 1) workers = 1;
     if (nslab) *nslab = workers;
-    if (dw_slabs) *dw_slabs = FDW ? 2 * workers : 0;
+    if (dw_slabs) *dw_slabs = FDW ? workers : 0;
     ProfScope ps(st, "gemm_wsb_kernel<%d,64,64,A%d,E%d%s> M=%d N=%d K=%d grid=%dx1", KD, AM, EM, FDW ? ",dW" : "", M, Nout, KD,
                  workers * ncol);
     auto kfn = gemm_wsb_kernel<KD, AM, EM, FDW>;
