@@ -469,7 +469,7 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
 using namespace pnpp;
 
 extern "C" const char *pnpp_last_error(void) { return g_err; }
-extern "C" int pnpp_abi_version(void) { return 1; }
+extern "C" int pnpp_abi_version(void) { return 2; }
 
 extern "C" int pnpp_profile_enable(int on) {
     for (auto &r : g_recs) {

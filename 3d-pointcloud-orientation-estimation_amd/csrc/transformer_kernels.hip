@@ -121,7 +121,7 @@ constexpr int ATT_DH = 16;
 constexpr int ATT_KP = 17;  // LDS pitch of the key / value tiles
 
 __global__ void __launch_bounds__(256)
-attention_fwd_kernel(const float *__restrict__ qkv, int N, int H, float scale, const unsigned *__restrict__ mask,
+attention_fwd_kernel(const float *__restrict__ qkv, int N, int Nv, int H, float scale, const unsigned *__restrict__ mask,
                      float keep_scale, float *__restrict__ out, float *__restrict__ lse) {
     __shared__ float Ks[2][32][ATT_KP], Vs[2][32][ATT_KP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -146,18 +146,24 @@ attention_fwd_kernel(const float *__restrict__ qkv, int N, int H, float scale, c
         float *d = (tid < 128 ? &Ks[buf][st_row][st_c4] : &Vs[buf][st_row][st_c4]);
         d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
     };
-    const int nkb = N / 32;
+    // N rows are allocated per cloud (a multiple of 128), the first Nv of them are points: keys beyond Nv get no weight
+    // (their scores are set to -inf before the softmax), key blocks that hold no point are not visited at all
+    const int nkb = N / 32, nkbv = (Nv + 31) / 32;
     put(fetch(0), 0);
     __syncthreads();
     const float vmask = l31 < ATT_DH ? 1.f : 0.f;  // rows 16..31 of V^T do not exist
-    for (int kb = 0; kb < nkb; ++kb) {
+    for (int kb = 0; kb < nkbv; ++kb) {
         const int buf = kb & 1;
-        const float4 nxt = fetch(min(kb + 1, nkb - 1));  // in flight while this block is computed
+        const float4 nxt = fetch(min(kb + 1, nkbv - 1));  // in flight while this block is computed
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
         for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[buf][l31][2 * t + lh], qreg[t], s, 0, 0, 0);
+        if ((kb + 1) * 32 > Nv) {   // the last block of a cloud whose size is not a multiple of 32
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh < Nv ? s[r] : -INFINITY;
+        }
         float mx = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
@@ -185,7 +191,7 @@ attention_fwd_kernel(const float *__restrict__ qkv, int N, int H, float scale, c
             const int key = (t & 3) + 8 * (t >> 2) + 4 * lh;
             o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[buf][key][l31 & (ATT_DH - 1)] * vmask, s[t], o, 0, 0, 0);
         }
-        if (kb + 1 < nkb) put(nxt, buf ^ 1);  // the other buffer was last read before the previous barrier
+        if (kb + 1 < nkbv) put(nxt, buf ^ 1);  // the other buffer was last read before the previous barrier
         __syncthreads();
     }
     const float inv = 1.f / l_run;
@@ -285,7 +291,7 @@ __global__ void __launch_bounds__(256) linear_smallk_bwd_kernel(const float *__r
 // Also writes D (B,H,N) for the dK/dV kernel.
 __global__ void __launch_bounds__(256)
 attention_bwd_dq_kernel(const float *__restrict__ qkv, const float *__restrict__ o, const float *__restrict__ d_o,
-                        const float *__restrict__ lse, int N, int H, float scale, const unsigned *__restrict__ mask,
+                        const float *__restrict__ lse, int N, int Nv, int H, float scale, const unsigned *__restrict__ mask,
                         float keep_scale, float *__restrict__ dqkv, float *__restrict__ dsum) {
     __shared__ float Ks[2][32][ATT_KP], Vs[2][32][ATT_KP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -314,13 +320,13 @@ attention_bwd_dq_kernel(const float *__restrict__ qkv, const float *__restrict__
         float *d = (tid < 128 ? &Ks[buf][st_row][st_c4] : &Vs[buf][st_row][st_c4]);
         d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
     };
-    const int nkb = N / 32;
+    const int nkb = N / 32, nkbv = (Nv + 31) / 32;   // keys beyond the cloud's Nv points carry no weight (P = 0)
     put(fetch(0), 0);
     __syncthreads();
     const float vmask = l31 < ATT_DH ? 1.f : 0.f;
-    for (int kb = 0; kb < nkb; ++kb) {
+    for (int kb = 0; kb < nkbv; ++kb) {
         const int buf = kb & 1;
-        const float4 nxt = fetch(min(kb + 1, nkb - 1));
+        const float4 nxt = fetch(min(kb + 1, nkbv - 1));
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
@@ -334,6 +340,10 @@ attention_bwd_dq_kernel(const float *__restrict__ qkv, const float *__restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) dp[r] = ((mw >> ((r & 3) + 8 * (r >> 2) + 4 * lh)) & 1u) ? dp[r] * keep_scale : 0.f;
         }
+        if ((kb + 1) * 32 > Nv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh < Nv ? s[r] : -INFINITY;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = __expf(s[r] - L) * (dp[r] - D);  // dS^T = P^T * (dP^T - D)
 #pragma unroll
@@ -341,7 +351,7 @@ attention_bwd_dq_kernel(const float *__restrict__ qkv, const float *__restrict__
             const int key = (t & 3) + 8 * (t >> 2) + 4 * lh;
             dq = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[buf][key][l31 & (ATT_DH - 1)] * vmask, s[t], dq, 0, 0, 0);
         }
-        if (kb + 1 < nkb) put(nxt, buf ^ 1);
+        if (kb + 1 < nkbv) put(nxt, buf ^ 1);
         __syncthreads();
     }
     float *drow = dqkv + ((size_t)b * N + q) * ld + h * ATT_DH;
@@ -353,7 +363,7 @@ attention_bwd_dq_kernel(const float *__restrict__ qkv, const float *__restrict__
 // directly the B operands of dV^T = dO^T P and dK^T = (scale Q)^T dS.  Per-query L and D come from LDS (one per register).
 __global__ void __launch_bounds__(256)
 attention_bwd_dkv_kernel(const float *__restrict__ qkv, const float *__restrict__ d_o, const float *__restrict__ lse,
-                         const float *__restrict__ dsum, int N, int H, float scale, const unsigned *__restrict__ maskT,
+                         const float *__restrict__ dsum, int N, int Nv, int H, float scale, const unsigned *__restrict__ maskT,
                          float keep_scale, float *__restrict__ dqkv) {
     __shared__ float Qs[2][32][ATT_KP], Gs[2][32][ATT_KP], Ls[2][32], Ds[2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -390,14 +400,17 @@ attention_bwd_dkv_kernel(const float *__restrict__ qkv, const float *__restrict_
         if (tid < 32) Ls[buf][tid] = x;
         else if (tid < 64) Ds[buf][tid - 32] = x;
     };
-    const int nqb = N / 32;
+    // queries beyond the cloud's Nv points are padding: their dO is zero, so they add nothing and their blocks are skipped;
+    // keys beyond Nv got no weight in the forward pass: their dK / dV rows are written as zeros
+    const int nqb = N / 32, nqbv = (Nv + 31) / 32;
     put(fetch(0), fetch_ld(0), 0);
     __syncthreads();
     const float vmask = l31 < ATT_DH ? 1.f : 0.f;
-    for (int qb = 0; qb < nqb; ++qb) {
+    const float kvalid = key < Nv ? 1.f : 0.f;
+    for (int qb = 0; qb < nqbv; ++qb) {
         const int buf = qb & 1;
-        const float4 nxt = fetch(min(qb + 1, nqb - 1));
-        const float nxt_ld = fetch_ld(min(qb + 1, nqb - 1));
+        const float4 nxt = fetch(min(qb + 1, nqbv - 1));
+        const float nxt_ld = fetch_ld(min(qb + 1, nqbv - 1));
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
@@ -411,7 +424,7 @@ attention_bwd_dkv_kernel(const float *__restrict__ qkv, const float *__restrict_
         for (int r = 0; r < 16; ++r) {
             const int qi = (r & 3) + 8 * (r >> 2) + 4 * lh;       // the query this register belongs to
             const float keep = ((mw >> qi) & 1u) ? keep_scale : 0.f;
-            const float pr = __expf(s[r] - Ls[buf][qi]);          // P
+            const float pr = (qb * 32 + qi < Nv ? __expf(s[r] - Ls[buf][qi]) : 0.f) * kvalid;   // P (0 for padding rows / keys)
             dp[r] = pr * (dp[r] * keep - Ds[buf][qi]);            // dS = P * (d(dropped P) * keep / (1 - p) - D)
             s[r] = pr * keep;                                     // dropped P, the operand of dV
         }
@@ -421,7 +434,7 @@ attention_bwd_dkv_kernel(const float *__restrict__ qkv, const float *__restrict_
             dv = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[buf][qi][l31 & (ATT_DH - 1)] * vmask, s[t], dv, 0, 0, 0);   // dV^T += dO^T P
             dk = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[buf][qi][l31 & (ATT_DH - 1)] * vmask, dp[t], dk, 0, 0, 0);  // dK^T += (scale Q)^T dS
         }
-        if (qb + 1 < nqb) put(nxt, nxt_ld, buf ^ 1);
+        if (qb + 1 < nqbv) put(nxt, nxt_ld, buf ^ 1);
         __syncthreads();
     }
     float *drow = dqkv + ((size_t)b * N + key) * ld + h * ATT_DH;
@@ -547,16 +560,17 @@ extern "C" int pnpp_attention_dropout_mask_dev(uint64_t seed, uint64_t *stream_i
     return attention_dropout_mask_impl(seed, offset, stream_id_dev, B, N, H, p, mask, maskT, stream);
 }
 
-extern "C" int pnpp_attention_fwd(const float *qkv, int B, int N, int H, int head_dim, const uint32_t *mask, float p, float *out,
-                                  float *lse, void *stream) {
+extern "C" int pnpp_attention_fwd(const float *qkv, int B, int N, int n_valid, int H, int head_dim, const uint32_t *mask, float p,
+                                  float *out, float *lse, void *stream) {
     PNPP_REQUIRE(qkv && out, PNPP_ERR_ARG, "attention_fwd: null pointer");
     PNPP_REQUIRE(B > 0 && N > 0 && H > 0, PNPP_ERR_ARG, "attention_fwd: non-positive size");
     PNPP_REQUIRE(head_dim == ATT_DH, PNPP_ERR_ARG, "attention_fwd: head dimension %d is not supported (only %d)", head_dim, ATT_DH);
-    PNPP_REQUIRE(N % 128 == 0, PNPP_ERR_ARG, "attention_fwd: N=%d must be a multiple of 128", N);
+    PNPP_REQUIRE(N % 128 == 0, PNPP_ERR_ARG, "attention_fwd: the row count N=%d must be a multiple of 128 (pad, and pass n_valid)", N);
+    PNPP_REQUIRE(n_valid > 0 && n_valid <= N, PNPP_ERR_ARG, "attention_fwd: n_valid=%d outside 1..N=%d", n_valid, N);
     PNPP_REQUIRE(B <= 65535 && H <= 65535, PNPP_ERR_ARG, "attention_fwd: B or H exceeds the grid limit");
     ProfScope ps(as_stream(stream), "attention_fwd_kernel B=%d N=%d H=%d", B, N, H);
     PNPP_REQUIRE(p >= 0.f && p < 1.f, PNPP_ERR_ARG, "attention_fwd: dropout p=%g outside [0, 1)", (double)p);
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(N / 128, H, B), dim3(256), 0, as_stream(stream), qkv, N, H,
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(N / 128, H, B), dim3(256), 0, as_stream(stream), qkv, N, n_valid, H,
                        1.0f / sqrtf((float)head_dim), mask, 1.0f / (1.0f - p), out, lse);
     PNPP_CHECK_LAUNCH("attention_fwd");
     return PNPP_OK;
@@ -602,7 +616,7 @@ extern "C" int pnpp_linear_smallk_bwd(const float *x, const float *dy, int M, in
     return rc;
 }
 
-extern "C" int pnpp_attention_bwd(const float *qkv, const float *out, const float *d_out, const float *lse, int B, int N, int H,
+extern "C" int pnpp_attention_bwd(const float *qkv, const float *out, const float *d_out, const float *lse, int B, int N, int n_valid, int H,
                                   int head_dim, const uint32_t *mask, const uint32_t *maskT, float p, float *dqkv, float *dsum,
                                   void *stream) {
     PNPP_REQUIRE((mask == nullptr) == (maskT == nullptr), PNPP_ERR_ARG, "attention_bwd: pass both mask orientations or neither");
@@ -611,19 +625,20 @@ extern "C" int pnpp_attention_bwd(const float *qkv, const float *out, const floa
     PNPP_REQUIRE(qkv && out && d_out && lse && dqkv && dsum, PNPP_ERR_ARG, "attention_bwd: null pointer");
     PNPP_REQUIRE(B > 0 && N > 0 && H > 0, PNPP_ERR_ARG, "attention_bwd: non-positive size");
     PNPP_REQUIRE(head_dim == ATT_DH, PNPP_ERR_ARG, "attention_bwd: head dimension %d is not supported (only %d)", head_dim, ATT_DH);
-    PNPP_REQUIRE(N % 128 == 0, PNPP_ERR_ARG, "attention_bwd: N=%d must be a multiple of 128", N);
+    PNPP_REQUIRE(N % 128 == 0, PNPP_ERR_ARG, "attention_bwd: the row count N=%d must be a multiple of 128 (pad, and pass n_valid)", N);
+    PNPP_REQUIRE(n_valid > 0 && n_valid <= N, PNPP_ERR_ARG, "attention_bwd: n_valid=%d outside 1..N=%d", n_valid, N);
     PNPP_REQUIRE(B <= 65535 && H <= 65535, PNPP_ERR_ARG, "attention_bwd: B or H exceeds the grid limit");
     hipStream_t st = as_stream(stream);
     const float scale = 1.0f / sqrtf((float)head_dim);
     {
         ProfScope ps(st, "attention_bwd_dq_kernel B=%d N=%d H=%d", B, N, H);
-        hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3(N / 128, H, B), dim3(256), 0, st, qkv, out, d_out, lse, N, H, scale, mask,
+        hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3(N / 128, H, B), dim3(256), 0, st, qkv, out, d_out, lse, N, n_valid, H, scale, mask,
                            keep_scale, dqkv, dsum);
         PNPP_CHECK_LAUNCH("attention_bwd_dq");
     }
     {
         ProfScope ps(st, "attention_bwd_dkv_kernel B=%d N=%d H=%d", B, N, H);
-        hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3(N / 128, H, B), dim3(256), 0, st, qkv, d_out, lse, dsum, N, H, scale, maskT,
+        hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3(N / 128, H, B), dim3(256), 0, st, qkv, d_out, lse, dsum, N, n_valid, H, scale, maskT,
                            keep_scale, dqkv);
         PNPP_CHECK_LAUNCH("attention_bwd_dkv");
     }

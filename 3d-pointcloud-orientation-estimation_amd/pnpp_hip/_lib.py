@@ -98,14 +98,14 @@ SIGNATURES = {
     "pnpp_proj_probs": (_i, [_fp, _fp, _i, _i, _fp, _fp]),
     "pnpp_proj_probs_bwd": (_i, [_fp, _fp, _fp, _i, _i, _fp, _fp]),
     "pnpp_linear_smallk": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
-    "pnpp_attention_fwd": (_i, [_fp, _i, _i, _i, _i, _fp, _f, _fp, _fp, _fp]),
+    "pnpp_attention_fwd": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _f, _fp, _fp, _fp]),
     "pnpp_attention_dropout_mask": (_i, [_u64, _u64, _i, _i, _i, _f, _fp, _fp, _fp]),
     "pnpp_attention_dropout_mask_dev": (_i, [_u64, _fp, _u64, _i, _i, _i, _f, _fp, _fp, _fp]),
     "pnpp_add_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp, _fp]),
     "pnpp_mean_points": (_i, [_fp, _i, _i, _i, _fp, _fp]),
     "pnpp_linear_smallk_bwd_scratch_bytes": (_sz, [_i, _i]),
     "pnpp_linear_smallk_bwd": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp]),
-    "pnpp_attention_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _f, _fp, _fp, _fp]),
+    "pnpp_attention_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _f, _fp, _fp, _fp]),
     "pnpp_add_layernorm_bwd_scratch_bytes": (_sz, [_i, _i]),
     "pnpp_add_layernorm_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp, _fp, _fp, _fp]),
     "pnpp_mean_points_bwd": (_i, [_fp, _i, _i, _i, _fp, _fp]),
@@ -142,7 +142,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.pnpp_abi_version() != 1:
+        if h.pnpp_abi_version() != 2:
             raise HipExtensionMissing("libpnpp_hip.so ABI version mismatch; rebuild it")
         _lib = h
     return _lib

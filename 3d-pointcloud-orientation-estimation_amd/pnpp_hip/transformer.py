@@ -89,20 +89,22 @@ def attention_dropout_mask(B: int, N: int, H: int, p: float, device, seed=None, 
 
 class _Attention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, num_heads, p, masks):
+    def forward(ctx, qkv, num_heads, p, masks, n_valid):
         qkv = _f32(qkv, "qkv")
         B, N, E3 = qkv.shape
+        if N % 128 != 0 or not 0 < n_valid <= N:
+            raise ValueError(f"attention: {N} rows per cloud (must be a multiple of 128: pad) with {n_valid} valid points")
         if E3 % (3 * num_heads) != 0:
             raise ValueError(f"attention: last dimension {E3} is not 3 * heads * head_dim")
         E = E3 // 3
         mask, maskT = masks if masks is not None else (None, None)
         out = torch.empty(B, N, E, device=qkv.device, dtype=torch.float32)
         lse = torch.empty(B, num_heads, N, device=qkv.device, dtype=torch.float32)
-        L.check(L.lib().pnpp_attention_fwd(qkv.data_ptr(), B, N, num_heads, E // num_heads,
+        L.check(L.lib().pnpp_attention_fwd(qkv.data_ptr(), B, N, int(n_valid), num_heads, E // num_heads,
                                            None if mask is None else mask.data_ptr(), float(p), out.data_ptr(), lse.data_ptr(),
                                            _stream()))
         ctx.save_for_backward(qkv, out, lse)
-        ctx.heads, ctx.p, ctx.masks = num_heads, float(p), (mask, maskT)
+        ctx.heads, ctx.p, ctx.masks, ctx.n_valid = num_heads, float(p), (mask, maskT), int(n_valid)
         ctx.mark_non_differentiable(lse)
         return out, lse
 
@@ -114,20 +116,22 @@ class _Attention(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dsum = torch.empty_like(lse)
         mask, maskT = ctx.masks
-        L.check(L.lib().pnpp_attention_bwd(qkv.data_ptr(), out.data_ptr(), d_out.data_ptr(), lse.data_ptr(), B, N, ctx.heads,
+        L.check(L.lib().pnpp_attention_bwd(qkv.data_ptr(), out.data_ptr(), d_out.data_ptr(), lse.data_ptr(), B, N, ctx.n_valid, ctx.heads,
                                            E3 // 3 // ctx.heads, None if mask is None else mask.data_ptr(),
                                            None if maskT is None else maskT.data_ptr(), ctx.p, dqkv.data_ptr(), dsum.data_ptr(),
                                            _stream()))
-        return dqkv, None, None, None
+        return dqkv, None, None, None, None
 
 
-def attention(qkv: torch.Tensor, num_heads: int, want_lse: bool = False, p: float = 0.0, masks=None):
+def attention(qkv: torch.Tensor, num_heads: int, want_lse: bool = False, p: float = 0.0, masks=None, n_valid=None):
     """qkv (B,N,3E), in_proj bias included -> (B,N,E) [, log-sum-exp of the scaled scores (B,H,N)].
+    N (rows per cloud) must be a multiple of 128; n_valid <= N (default N) says how many of them are points -- the rest is
+    the caller's padding: it receives no attention weight, its own output rows are to be ignored and its d_out must be zero.
     p > 0 applies dropout to the attention weights with the keep bits `masks` = attention_dropout_mask(...)
     (drawn here when not given)."""
     if p > 0.0 and masks is None:
         masks = attention_dropout_mask(qkv.shape[0], qkv.shape[1], num_heads, p, qkv.device)
-    out, lse = _Attention.apply(qkv, num_heads, p if masks is not None else 0.0, masks)
+    out, lse = _Attention.apply(qkv, num_heads, p if masks is not None else 0.0, masks, qkv.shape[1] if n_valid is None else n_valid)
     return (out, lse) if want_lse else out
 
 
@@ -206,7 +210,12 @@ def point_transformer_forward(model, xyz: torch.Tensor) -> torch.Tensor:
     bits), after out_proj (dropout1), after the ReLU (dropout) and after linear2 (dropout2) as keep-masks of the
     projection kernels."""
     xyz = _f32(xyz, "xyz")
-    B, N, K = xyz.shape
+    B, n_pts, K = xyz.shape
+    N = (n_pts + 127) // 128 * 128          # rows per cloud: the attention kernels walk 128-query / 32-key blocks
+    if N != n_pts:                          # any cloud size (the reference's data has 10,000 points): zero rows are appended,
+        pad = xyz.new_zeros(B, N, K)        # the attention kernels give them no weight, and the pooling below leaves them out
+        pad[:, :n_pts] = xyz
+        xyz = pad
     x = linear_smallk(xyz.reshape(B * N, K), model.input_proj)                        # (B*N, E)
     E = x.shape[1]
     tr = model.training
@@ -215,11 +224,11 @@ def point_transformer_forward(model, xyz: torch.Tensor) -> torch.Tensor:
         if layer.norm_first or att.in_proj_weight is None or not att.batch_first:
             raise NotImplementedError("only the post-norm, packed in_proj, batch_first encoder layer of the reference")
         qkv = ops.fc_block(x, _Affine(att.in_proj_weight, att.in_proj_bias), training=tr)   # (B*N, 3E), bias added
-        o = attention(qkv.view(B, N, 3 * E), att.num_heads, p=att.dropout if tr else 0.0).view(B * N, E)
+        o = attention(qkv.view(B, N, 3 * E), att.num_heads, p=att.dropout if tr else 0.0, n_valid=n_pts).view(B * N, E)
         o = ops.fc_block(o, att.out_proj, dropout=layer.dropout1, training=tr)
         x = add_layernorm(x, o, layer.norm1)
         hid = ops.fc_block(x, layer.linear1, relu=True, dropout=layer.dropout, training=tr)   # dropout(relu(W1 x + b1))
         f = ops.fc_block(hid, layer.linear2, dropout=layer.dropout2, training=tr)
         x = add_layernorm(x, f, layer.norm2)
-    pooled = mean_points(x.view(B, N, E))
+    pooled = mean_points(x.view(B, N, E) if N == n_pts else x.view(B, N, E)[:, :n_pts])
     return ops.fc_block(pooled, model.fc_out, training=tr)

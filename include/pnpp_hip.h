@@ -285,11 +285,14 @@ int pnpp_linear_smallk(const float *x, const float *w, const float *b, int M, in
 /* nn.MultiheadAttention core (torch.nn.functional.multi_head_attention_forward between in_proj and out_proj):
  * qkv (B,N,3E) with the in_proj bias added, E = H*head_dim, head h = columns h*head_dim.. of each third;
  * out (B,N,E) = concat_h dropout(softmax(q_h k_h^T / sqrt(head_dim))) v_h; lse (B,H,N) optional log-sum-exp of the
- * scaled scores.  The N x N matrix is never materialised.  head_dim must be 16 and N a multiple of 128.
+ * scaled scores.  The N x N matrix is never materialised.  head_dim must be 16.  N is the number of ROWS per cloud in
+ * qkv / out and must be a multiple of 128; the first n_valid of them are points, the rest padding supplied by the caller:
+ * keys >= n_valid get no attention weight, outputs of queries >= n_valid are unspecified (finite) and must be ignored
+ * (the reference takes any N: models/point_transformer.py:15-20; the drop-in module pads to the next multiple of 128).
  * Dropout on the attention weights (train mode, nn.MultiheadAttention(dropout=p)): mask = bit-packed keep bits from
  * pnpp_attention_dropout_mask (kept weights are scaled by 1/(1-p)); mask == NULL means no dropout (p is then ignored). */
-int pnpp_attention_fwd(const float *qkv, int B, int N, int H, int head_dim, const uint32_t *mask, float p, float *out,
-                       float *lse, void *stream);
+int pnpp_attention_fwd(const float *qkv, int B, int N, int n_valid, int H, int head_dim, const uint32_t *mask, float p,
+                       float *out, float *lse, void *stream);
 /* Keep bits, Bernoulli(1-p), a pure function of (seed, stream_id, element): mask (B,H,N,N/32) holds for every query the
  * bits of its keys (bit = key % 32 of word key / 32); maskT (B,H,N,N/32) is the transpose (for every key the bits of the
  * queries), read by the dK/dV kernel. */
@@ -312,8 +315,8 @@ int pnpp_linear_smallk_bwd(const float *x, const float *dy, int M, int K, int N,
                            void *stream);
 /* attention: dqkv (B,N,3E) from qkv, the forward's out and lse, and d_out (B,N,E); dsum (B,H,N) is scratch
  * (rowsum(d_out * out) per head).  Scores are recomputed, never stored.  mask / maskT / p as in the forward (both NULL:
- * no dropout). */
-int pnpp_attention_bwd(const float *qkv, const float *out, const float *d_out, const float *lse, int B, int N, int H,
+ * no dropout).  n_valid as in the forward: d_out rows >= n_valid must be zero; dK / dV rows >= n_valid are written as zeros. */
+int pnpp_attention_bwd(const float *qkv, const float *out, const float *d_out, const float *lse, int B, int N, int n_valid, int H,
                        int head_dim, const uint32_t *mask, const uint32_t *maskT, float p, float *dqkv, float *dsum,
                        void *stream);
 /* add_layernorm: du (M,E) = gradient w.r.t. both x and r; dwb (2,E) = (d weight, d bias). */
