@@ -380,7 +380,6 @@ static int launch_wsb_one(const AOperand &A, const BOperand &B, int M, int Nout,
     size_t lds = (size_t)64 * KD * 2 * 2 + (FDW ? (size_t)KD * 128 + 64 * 128 : 0);
     if (lds < 4096) lds = 4096;  // the column-statistics reduction reuses the LDS: 2 x 2 x 64 doubles
     int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 3) per_cu = 3;
     const int cap_cu = FDW ? 2 : 4;          // __launch_bounds__(256, 2): the fused kernels need ~200 registers, the others < 128
     if (per_cu > cap_cu) per_cu = cap_cu;
     int workers = (256 * per_cu) / ncol;
