@@ -11,14 +11,16 @@ P=$OUT/profiles
 mkdir -p $P
 export TMPDIR=/tmp
 BENCH="bench.py --steps 200 --warmup 20 --no-cpu-baseline"
-echo "[1/6] bench line"; python3 bench.py --steps 200 --warmup 20 > $P/${TAG}_bench.json 2> $OUT/bench.err
-PNPP_BENCH_DUMP=$P/${TAG}_kernel_table_events.txt python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline > /dev/null 2>> $OUT/bench.err
-echo "[2/6] kernel trace of the step"; rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $BENCH --no-roofline > $OUT/trace.log 2>&1
-python3 tools/summarize_rocprof.py stats $OUT/trace $P/${TAG}_kernel_stats.csv
-echo "[3/6] FETCH_SIZE of the step"; rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-graph > $OUT/fetch.log 2>&1
-echo "[4/6] WRITE_SIZE of the step"; rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-graph > $OUT/write.log 2>&1
+echo "[1/6] FETCH_SIZE of the step"; rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-graph --no-bf16-variant > $OUT/fetch.log 2>&1
+echo "[2/6] WRITE_SIZE of the step"; rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-graph --no-bf16-variant > $OUT/write.log 2>&1
 python3 tools/summarize_rocprof.py pmc $OUT/fetch $OUT/write $P/pmc_traffic.json $P/${TAG}_pmc_traffic.csv
 python3 tools/summarize_rocprof.py pmc-all $OUT/fetch $OUT/write $P/${TAG}_pmc_traffic_all_kernels.json $P/${TAG}_pmc_traffic_all_kernels.csv
+cp $P/pmc_traffic.json profiles/pmc_traffic.json   # the bench line below reads the counters that belong to THESE kernel sources
+echo "[3/6] bench line"; python3 bench.py --steps 200 --warmup 20 > $P/${TAG}_bench.json 2> $OUT/bench.err
+PNPP_BENCH_DUMP=$P/${TAG}_kernel_table_events.txt python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-bf16-variant > /dev/null 2>> $OUT/bench.err
+PNPP_BENCH_DUMP=$P/${TAG}_kernel_table_events_bf16.txt python3 bench.py --precision bf16 --steps 50 --warmup 10 --no-cpu-baseline > $P/${TAG}_bench_bf16.json 2>> $OUT/bench.err
+echo "[4/6] kernel trace of the step"; rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $BENCH --no-roofline --no-bf16-variant > $OUT/trace.log 2>&1
+python3 tools/summarize_rocprof.py stats $OUT/trace $P/${TAG}_kernel_stats.csv
 echo "[5/6] index kernels: events, trace, counters"
 python3 tools/bench_index_kernels.py --json $P/${TAG}_index_kernels.json > $P/${TAG}_index_kernels.txt 2> $OUT/idx.err
 rocprofv3 --kernel-trace --stats -d $OUT/idx_trace -o idx --output-format csv -- python3 tools/bench_index_kernels.py --reps 5 > $OUT/idx_trace.log 2>&1
