@@ -160,16 +160,19 @@ gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, c
 
     const int tiles = (M + BM - 1) / BM;
     float4 rp[RPT], rq[AMODE == A_DZ ? RPT : 1];
+    // Addresses: (uniform tile pointer, advanced by scalar arithmetic) + (ONE 32-bit lane offset computed once).  M is a
+    // multiple of 64 and Nout of 64 (launcher), so no load or store of this kernel needs a clamp -- 64-bit multiply-adds and
+    // clamps per element were half of the vector instructions of the first version, and every one of them is MFMA time.
+    const unsigned offA = (unsigned)row_of(0) * (unsigned)A.lda + (unsigned)kq;
+    const unsigned offC = (unsigned)(32 * wm + lh) * (unsigned)E.ldc + (unsigned)(n0 + 32 * wn + l31);   // this lane's first output element
     auto fetch = [&](int m0) {
+        const float *pa = (AMODE == A_DZ_POOL ? A.z : A.a) + (size_t)m0 * A.lda;
+        const float *pz = A.z + (size_t)m0 * A.lda;
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
-            const int rc = min(m0 + row_of(i), M - 1);
-            if constexpr (AMODE == A_DZ_POOL) {
-                rp[i] = *reinterpret_cast<const float4 *>(A.z + (size_t)rc * A.lda + kq);   // the only HBM stream
-            } else {
-                rp[i] = *reinterpret_cast<const float4 *>(A.a + (size_t)rc * A.lda + kq);
-                if constexpr (AMODE == A_DZ) rq[i] = *reinterpret_cast<const float4 *>(A.z + (size_t)rc * A.lda + kq);
-            }
+            const int dr = KD == 256 ? 32 * (i >> 3) + 4 * (i & 7) : 4 * i;   // row_of(i) - row_of(0): a compile-time constant
+            rp[i] = *reinterpret_cast<const float4 *>(pa + (size_t)dr * A.lda + offA);
+            if constexpr (AMODE == A_DZ) rq[i] = *reinterpret_cast<const float4 *>(pz + (size_t)dr * A.lda + offA);
         }
     };
     int tile = worker;
@@ -182,17 +185,27 @@ gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, c
         if constexpr (AMODE == A_DZ_POOL) {
 #pragma unroll
             for (int h = 0; h < (KD == 256 ? 2 : 1); ++h) {
-                const int g = min(m0 / 32 + (KD == 256 ? h : hq), (M - 1) / 32);
+                const int g = m0 / 32 + (KD == 256 ? h : hq);
                 gdm[h] = *reinterpret_cast<const float4 *>(A.a + (size_t)g * A.lda + kq);
                 garg[h] = *reinterpret_cast<const int4 *>(A.arg + (size_t)g * A.lda + kq);
             }
+        }
+        // rows / column of this lane's 16 accumulator registers: register 8 s + j  <->  tile row 32 wm + (2 s + lh) + 4 j.
+        // The epilogue's loads go out at the TOP of the tile: they depend on nothing, the MFMA work of a bf16 tile is far too
+        // short to hide a round trip, and vmcnt retires in order -- behind the prefetched operand stream (older: consumed by
+        // the staging pass below), ahead of the next tile's prefetch (younger: still in flight when the epilogue waits)
+        const int col = n0 + 32 * wn + l31;
+        float zp[16];
+        if constexpr (EMODE == E_MASK_STATS) {
+            const float *pzp = E.zp + (size_t)m0 * E.ldc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zp[r] = pzp[(size_t)(2 * (r >> 3) + 4 * (r & 7)) * E.ldc + offC];
         }
         __syncthreads();  // the previous tile's operand reads are done (first time: nothing; the weights are fenced below)
         float v[RPT][4];
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int r = row_of(i);
-            const float ok = (m0 + r < M) ? 1.f : 0.f;
             if constexpr (AMODE == A_PLAIN) {
                 v[i][0] = rp[i].x, v[i][1] = rp[i].y, v[i][2] = rp[i].z, v[i][3] = rp[i].w;
             } else if constexpr (AMODE == A_BNRELU) {
@@ -218,8 +231,6 @@ gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, c
                 v[i][2] = fmaf(c_g.z, dy.z, fmaf(c_a.z, z.z, c_b.z));
                 v[i][3] = fmaf(c_g.w, dy.w, fmaf(c_a.w, z.w, c_b.w));
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[i][e] *= ok;
             *reinterpret_cast<uint2 *>(Ab + r * PITCH + 16 * ((kq >> 3) ^ swz(r)) + 2 * (kq & 7)) = pk4_bf16(v[i][0], v[i][1], v[i][2], v[i][3]);
         }
         if constexpr (FDW) {  // the transposed image: per column one 16-byte chunk per (half h, row slot rho) = 8 rows rho + 4 j
@@ -245,18 +256,6 @@ gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, c
             }
         }
         __syncthreads();
-        // rows / column of this lane's 16 accumulator registers: register 8 s + j  <->  tile row 32 wm + (2 s + lh) + 4 j
-        // (the epilogue's loads go out FIRST: vmcnt retires in order, so waiting for them later leaves the next tile's
-        // stream, issued behind them, in flight -- the MFMA work of a bf16 tile is too short to hide a full round trip)
-        const int col = n0 + 32 * wn + l31;
-        float zp[16];
-        if constexpr (EMODE == E_MASK_STATS) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + 32 * wm + 2 * (r >> 3) + lh + 4 * (r & 7);
-                zp[r] = E.zp[(size_t)min(row, M - 1) * E.ldc + min(col, Nout - 1)];
-            }
-        }
         if (tile + nworkers < tiles) fetch((tile + nworkers) * BM);  // next tile's HBM stream flies during the rest of this tile
 
         f32x16 acc;
@@ -282,16 +281,11 @@ gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, c
         float av[16];   // FDW: relu(bn(z_{l-1})) of this lane's 16 rows, the second operand of the dW product
         {
             float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
-            if constexpr (EMODE == E_MASK_STATS) {
-                const int cc = min(col, Nout - 1);
-                sc = E.scale[cc], sh = E.shift[cc], mu = E.mu[cc], is = E.istd[cc];
-            }
-            float *cbase = E.c + (size_t)(m0 + 32 * wm + lh) * E.ldc + col;
+            if constexpr (EMODE == E_MASK_STATS) sc = E.scale[col], sh = E.shift[col], mu = E.mu[col], is = E.istd[col];
+            float *pc = E.c + (size_t)m0 * E.ldc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rl = 2 * (r >> 3) + 4 * (r & 7);   // + lh + 32 wm: row inside the tile
-                const bool ok = m0 + 32 * wm + lh + rl < M && col < Nout;
-                float o = ok ? acc[r] : 0.f;
+                float o = acc[r];
                 if constexpr (EMODE == E_STORE_STATS) {
                     t1 += o;
                     t2 = fmaf(o, o, t2);
@@ -300,9 +294,9 @@ gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, c
                     o = a0 > 0.f ? o : 0.f;
                     t1 += o;
                     t2 = fmaf(o, (zp[r] - mu) * is, t2);
-                    av[r] = ok ? fmaxf(a0, 0.f) : 0.f;
+                    av[r] = fmaxf(a0, 0.f);
                 }
-                if (ok) cbase[(size_t)rl * E.ldc] = o;
+                pc[(size_t)(2 * (r >> 3) + 4 * (r & 7)) * E.ldc + offC] = o;
             }
         }
         if constexpr (EMODE != E_STORE) s1 += (double)t1, s2 += (double)t2;
@@ -436,7 +430,7 @@ static int launch_wsb_k(const AOperand &A, const BOperand &B, int M, int Nout, c
 bool try_launch_ws_bf16(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st,
                         int *rc, int *dw_slabs) {
     if (!matmul_precision()) return false;
-    if (M < 8192 || Nout % 64 != 0) return false;
+    if (M < 8192 || M % 64 != 0 || Nout % 64 != 0) return false;   // whole 64 x 64 tiles only: the kernel has no bounds tests
     if (!(A.mode == A_PLAIN || A.mode == A_BNRELU || A.mode == A_DZ || A.mode == A_DZ_POOL)) return false;
     if (A.lda != Kd || A.lda % 4 != 0 || ((uintptr_t)A.a & 15) != 0) return false;
     if (A.mode == A_DZ_POOL && (A.K != 32 || M % 32 != 0)) return false;
