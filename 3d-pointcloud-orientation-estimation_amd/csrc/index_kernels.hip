@@ -511,18 +511,19 @@ subsample_points_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_lo, uns
                         const float *__restrict__ bank, const int32_t *__restrict__ lengths,
                         const int32_t *__restrict__ cloud_ids, int Lmax, int num, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long cand[];
-    __shared__ int nc_s;
-    const int b = blockIdx.x;
+    // gridDim.y workgroups share one batch slot: each builds the slot's whole candidate list (cheap: one Philox call per
+    // point) and ranks / gathers every gridDim.y-th candidate -- ranks do not depend on the order candidates were compacted in
+    const int b = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
     const int cloud = cloud_ids ? cloud_ids[b] : b;
     const int L = min(lengths[cloud], Lmax);
     const float *src = bank + (size_t)cloud * Lmax * 3;
     float *dst = out + (size_t)b * num * 3;
     if (L <= 0) {
-        for (int j = threadIdx.x; j < 3 * num; j += 256) dst[j] = 0.f;
+        for (int j = part * 256 + threadIdx.x; j < 3 * num; j += 256 * nparts) dst[j] = 0.f;
         return;
     }
     if (L < num) {  // with replacement: index = floor(u * L), u from the 32-bit Philox word
-        for (int j = threadIdx.x; j < num; j += 256) {
+        for (int j = part * 256 + threadIdx.x; j < num; j += 256 * nparts) {
             const unsigned u = philox_key((unsigned)j, (unsigned)b, str_lo, str_hi, seed_lo, seed_hi);
             const int n = (int)(((unsigned long long)u * (unsigned long long)L) >> 32);
             dst[3 * j] = src[3 * n], dst[3 * j + 1] = src[3 * n + 1], dst[3 * j + 2] = src[3 * n + 2];
@@ -531,40 +532,50 @@ subsample_points_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_lo, uns
     }
     const double keep = (num + 4.0 * sqrt((double)num) + 16.0) / (double)L;
     unsigned cut = keep >= 1.0 ? 0xffffffffu : (unsigned)(keep * 4294967296.0);
-    int nc;
+    // Compaction without atomics: wave w scans the points [w L/4, (w+1) L/4) and appends its survivors to its own segment
+    // of the list, so the list -- positions included -- is the same in every workgroup of the slot: position p of the
+    // concatenated segments belongs to part p / 256 % nparts.  Segments are padded to an even length with a word above every key.
+    __shared__ int cnt_s[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int seg = ((L + 3) / 4 + 3) & ~1;                 // capacity of one segment (even, >= its range + 2)
+    const int lo = wave * ((L + 3) / 4), hi = min(L, lo + (L + 3) / 4);
+    unsigned long long *mycand = cand + (size_t)wave * seg;
     for (;;) {
-        if (threadIdx.x == 0) nc_s = 0;
-        __syncthreads();
-        for (int n0 = 0; n0 < L; n0 += 256) {
-            const int n = n0 + threadIdx.x;
-            const unsigned k = n < L ? philox_key((unsigned)n, (unsigned)b, str_lo, str_hi, seed_lo, seed_hi) : 0u;
-            const bool keepit = n < L && k <= cut;
+        int cnt = 0;
+        for (int n0 = lo; n0 < hi; n0 += 64) {
+            const int n = n0 + lane;
+            const unsigned k = n < hi ? philox_key((unsigned)n, (unsigned)b, str_lo, str_hi, seed_lo, seed_hi) : 0u;
+            const bool keepit = n < hi && k <= cut;
             const unsigned long long vote = __ballot(keepit);
-            const int lane = threadIdx.x & 63;
-            int base = 0;
-            if (lane == 0 && vote) base = atomicAdd(&nc_s, __popcll(vote));
-            base = __shfl(base, 0, 64);
-            if (keepit) cand[base + __popcll(vote & ((1ull << lane) - 1ull))] = ((unsigned long long)k << 32) | (unsigned)n;
+            if (keepit) mycand[cnt + __popcll(vote & ((1ull << lane) - 1ull))] = ((unsigned long long)k << 32) | (unsigned)n;
+            cnt += __popcll(vote);
+        }
+        if (lane == 0) {
+            if (cnt & 1) mycand[cnt] = ~0ull;
+            cnt_s[wave] = cnt;
         }
         __syncthreads();
-        nc = nc_s;
-        if (nc >= num || cut == 0xffffffffu) break;
-        cut = 0xffffffffu;
+        const int total = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+        if (total >= num || cut == 0xffffffffu) break;   // uniform
+        cut = 0xffffffffu;                                // a > 5 sigma event: redo without the cut
         __syncthreads();
     }
-    if (nc & 1) {
-        if (threadIdx.x == 0) cand[nc] = ~0ull;
-        __syncthreads();
-    }
-    const int nc2 = (nc + 1) >> 1;
-    const ulonglong2 *c2 = reinterpret_cast<const ulonglong2 *>(cand);
-    for (int i = threadIdx.x; i < nc; i += 256) {
-        const unsigned long long mine = cand[i];
+    const int c0 = cnt_s[0], c1 = cnt_s[1], c2n = cnt_s[2], c3 = cnt_s[3], nc = c0 + c1 + c2n + c3;
+    const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(cand);
+    for (int p = part * 256 + threadIdx.x; p < nc; p += 256 * nparts) {
+        int w = 0, q = p;                                  // position p -> (segment, index)
+        if (q >= c0) { q -= c0, w = 1; if (q >= c1) { q -= c1, w = 2; if (q >= c2n) q -= c2n, w = 3; } }
+        const unsigned long long mine = cand[(size_t)w * seg + q];
         int rank = 0;
+#pragma unroll
+        for (int sgm = 0; sgm < 4; ++sgm) {
+            const int np = (cnt_s[sgm] + 1) >> 1;
+            const ulonglong2 *c2 = pairs + (size_t)sgm * (seg >> 1);
 #pragma unroll 4
-        for (int j = 0; j < nc2; ++j) {
-            const ulonglong2 o = c2[j];
-            rank += (o.x < mine) + (o.y < mine);
+            for (int jj = 0; jj < np; ++jj) {             // one 16-byte LDS broadcast per two candidates
+                const ulonglong2 o = c2[jj];
+                rank += (o.x < mine) + (o.y < mine);
+            }
         }
         if (rank < num) {
             const int n = (int)(unsigned)mine;
@@ -714,14 +725,17 @@ extern "C" int pnpp_subsample_points(uint64_t seed, uint64_t stream_id, const fl
     PNPP_REQUIRE(bank && lengths && out, PNPP_ERR_ARG, "subsample_points: null pointer");
     PNPP_REQUIRE(B > 0 && Lmax > 0 && num > 0, PNPP_ERR_ARG, "subsample_points: non-positive size");
     PNPP_REQUIRE((size_t)(Lmax + 1) * 8 <= 128 * 1024, PNPP_ERR_ARG, "subsample_points: Lmax=%d too large (<= 16383)", Lmax);
-    const size_t lds = (size_t)(Lmax + 1) * sizeof(unsigned long long);
+    const size_t lds = (size_t)(Lmax + 32) * sizeof(unsigned long long);   // four segments of (Lmax / 4 rounded up, + padding)
     static size_t granted = 0;
     if (lds > 48 * 1024 && lds > granted) {
         (void)hipFuncSetAttribute((const void *)subsample_points_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         granted = lds;
     }
-    ProfScope ps(as_stream(stream), "subsample_points_kernel B=%d Lmax=%d num=%d", B, Lmax, num);
-    hipLaunchKernelGGL(subsample_points_kernel, dim3(B), dim3(256), lds, as_stream(stream), (unsigned)seed,
+    // the rank-by-counting pass is quadratic in the ~num survivors: spread a slot over several workgroups until the chip is full
+    int nparts = 1;
+    while (nparts < 8 && (long long)B * nparts * 2 <= 512 && num >= 128 * nparts * 2) nparts *= 2;
+    ProfScope ps(as_stream(stream), "subsample_points_kernel B=%d Lmax=%d num=%d parts=%d", B, Lmax, num, nparts);
+    hipLaunchKernelGGL(subsample_points_kernel, dim3(B, nparts), dim3(256), lds, as_stream(stream), (unsigned)seed,
                        (unsigned)(seed >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32), bank, lengths, cloud_ids, Lmax,
                        num, out);
     PNPP_CHECK_LAUNCH("subsample_points");
