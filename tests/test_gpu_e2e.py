@@ -400,3 +400,30 @@ def test_split_hipgraph_step_equals_eager(oracle):
             assert seen[1][1] == tail and torch.equal(seen[1][2], o2.flat_g[:tail])
     finally:
         PointNetSetAbstraction.sampler = old
+
+
+def test_hipgraph_replays_are_bitwise_reproducible(oracle):
+    """Race detection by determinism: the captured training step replayed 100 times from the same sampler
+    and dropout counters produces, every time, bit for bit the flat gradient and the loss of the eager launches -- every
+    cross-workgroup reduction of the step is a fixed-order sum of per-worker partials, so any ordering bug, missing barrier
+    or stale read between the ~60 kernels of a replay shows up as a differing bit."""
+    import copy
+    from models.pointnet_pp_vonMises import PointNetPPVonMises
+    from pnpp_hip import ops, optim, sampling
+    from pnpp_hip.graph import GraphedStep
+    torch.manual_seed(42)
+    m1 = PointNetPPVonMises(sampler="device").cuda().train()
+    m2 = copy.deepcopy(m1)
+    o1, o2 = optim.FlatAdam(m1.parameters()), optim.FlatAdam(m2.parameters())
+    xyz, mu_gt, kappa_gt, _ = oracle.synthetic_clouds(32, 1024, seed=3)
+    xyz, mu_gt, kappa_gt = xyz.cuda(), mu_gt.cuda(), kappa_gt.cuda()
+    g = GraphedStep(o1, lambda x, m, k: ops.vm_head_kl_loss_backward(m1.features(x), m, k), [xyz, mu_gt, kappa_gt], adopt_inputs=True)
+    snap = sampling.snapshot()                      # centre-sampler and in-kernel dropout counters
+    o2.zero_grad()
+    ref_loss = ops.vm_head_kl_loss_backward(m2.features(xyz), mu_gt, kappa_gt)
+    ref_g, ref_l = o2.flat_g.clone(), float(ref_loss)
+    for it in range(100):
+        sampling.restore(snap)
+        loss = g(xyz, mu_gt, kappa_gt)
+        assert float(loss) == ref_l, (it, float(loss), ref_l)
+        assert torch.equal(o1.flat_g, ref_g), it
