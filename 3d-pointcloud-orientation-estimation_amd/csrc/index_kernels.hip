@@ -205,6 +205,30 @@ __global__ void __launch_bounds__(256) knn_kernel(const float *__restrict__ new_
     }
 }
 
+// Wave-wide maximum of a 64-bit key, result in every lane.  Six dependent ds_bpermute round trips (what __shfl_xor compiles
+// to) are most of a farthest-point round; this is the DPP form: an inclusive row scan (row_shr 1, 2, 4, 8 inside the rows of
+// 16 lanes, shifted-in lanes keep their own value), row_bcast15 / row_bcast31 to fold the four rows, lane 63 read back
+// through the scalar unit -- VALU latency only.
+__device__ __forceinline__ unsigned long long wave_max_u64_dpp(unsigned long long v) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#define PNPP_DPP_MAX_STEP(CTRL, ROWMASK)                                                                              \
+    {                                                                                                                 \
+        const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROWMASK, 0xf, false);      \
+        const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROWMASK, 0xf, false);      \
+        const bool take = ohi > hi || (ohi == hi && olo > lo);                                                        \
+        lo = take ? olo : lo, hi = take ? ohi : hi;                                                                   \
+    }
+    PNPP_DPP_MAX_STEP(0x111, 0xf)  // row_shr:1
+    PNPP_DPP_MAX_STEP(0x112, 0xf)  // row_shr:2
+    PNPP_DPP_MAX_STEP(0x114, 0xf)  // row_shr:4
+    PNPP_DPP_MAX_STEP(0x118, 0xf)  // row_shr:8   -> lane 15 of every row holds its row's maximum
+    PNPP_DPP_MAX_STEP(0x142, 0xa)  // row_bcast15 -> rows 1 and 3 fold in the row below
+    PNPP_DPP_MAX_STEP(0x143, 0xc)  // row_bcast31 -> rows 2 and 3 fold in lane 31: lane 63 holds the wave's maximum
+#undef PNPP_DPP_MAX_STEP
+    const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63), rhi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    return ((unsigned long long)rhi << 32) | rlo;
+}
+
 // ---------------------------------------------------------------------------------------------
 // farthest point sampling (PointNet++Demo.py:8-29): one workgroup per cloud.
 //
@@ -272,18 +296,15 @@ __global__ void __launch_bounds__(T) fps_kernel(const float *__restrict__ xyz, i
         // a thread without a valid point (bv < 0) contributes key 0, below every real key (~index is never 0)
         const unsigned long long bestk =
             bv < 0.f ? 0ull : ((unsigned long long)__float_as_uint(bv) << 32) | (unsigned)(0xffffffffu - (unsigned)bp);
-        unsigned long long wk = bestk;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const unsigned long long o = shfl_xor_u64(wk, m);
-            wk = o > wk ? o : wk;
-        }
+        const unsigned long long wk = wave_max_u64_dpp(bestk);
         if (bestk == wk && (wk != 0ull || lane == 0)) {   // keys carry the point index: exactly one lane of the wave holds the maximum
             wkey[(it & 1) * NW + wave] = wk;
             float *w4 = wxyz + ((it & 1) * NW + wave) * 4;
             w4[0] = bx, w4[1] = by, w4[2] = bz;
         }
         __syncthreads();
+        // (folding the NW slots with a second DPP maximum + readlane instead of reading them all was measured slower:
+        // 98.6 vs 80.3 us at N = 1024 -- the scalar round trip is longer than two LDS round trips)
         unsigned long long g = 0;
         int gw = 0;
 #pragma unroll
@@ -681,7 +702,7 @@ extern "C" int pnpp_fps(const float *xyz, int B, int N, int npoint, const int32_
     PNPP_REQUIRE(npoint <= N, PNPP_ERR_RANGE, "fps: npoint=%d > N=%d", npoint, N);
     hipStream_t st = as_stream(stream);
     // points per thread live in registers; clouds beyond 1024 x 16 points keep the rest in the LDS (16 bytes per point)
-    constexpr int kRegPoints = 1024 * 16, kTailMax = (160 * 1024 - 2048) / 16;
+    constexpr int kRegPoints = 1024 * 16, kTailMax = (160 * 1024 - 2048) / 16;   // 1 KiB of winner slots at T = 1024
     PNPP_REQUIRE(N <= kRegPoints + kTailMax, PNPP_ERR_ARG, "fps: N=%d exceeds the %d points one CU can hold (registers + LDS)", N,
                  kRegPoints + kTailMax);
     const int ntail = N > kRegPoints ? N - kRegPoints : 0;
