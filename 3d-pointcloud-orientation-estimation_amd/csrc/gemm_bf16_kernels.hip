@@ -70,7 +70,15 @@ gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, c
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int col_blk = blockIdx.x % ncol, worker = blockIdx.x / ncol, nworkers = gridDim.x / ncol;
+    // XCD-aware tile map (speed only, never correctness): blocks b and b + 8 share an XCD and with it an L2, so the ncol
+    // column blocks of one worker -- which stream the SAME operand rows -- are placed 8 apart: the rows come from HBM once
+    // and from that L2 for the other column blocks, instead of once per XCD
+    const int nworkers = gridDim.x / ncol;
+    int col_blk = blockIdx.x % ncol, worker = blockIdx.x / ncol;
+    if ((nworkers & 7) == 0) {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        col_blk = i % ncol, worker = (i / ncol) * 8 + xcd;
+    }
     const int n0 = col_blk * BN;
     const int kq = 4 * (tid % G4), q = tid / G4;   // this thread's first column and its row slot
     // rows of the tile this thread stages: 32 h + rho + 4 j

@@ -533,7 +533,15 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int col_blk = blockIdx.x % ncol, worker = blockIdx.x / ncol, nworkers = gridDim.x / ncol;
+    // XCD-aware tile map (speed only, never correctness): blocks b and b + 8 share an XCD and with it an L2, so the ncol
+    // column blocks of one worker -- which stream the SAME operand rows -- are placed 8 apart: the rows come from HBM once
+    // and from that L2 for the other column blocks, instead of once per XCD
+    const int nworkers = gridDim.x / ncol;
+    int col_blk = blockIdx.x % ncol, worker = blockIdx.x / ncol;
+    if ((nworkers & 7) == 0) {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        col_blk = i % ncol, worker = (i / ncol) * 8 + xcd;
+    }
     const int n0 = col_blk * BN;
     const int kq = G4 > 0 ? 4 * (tid % (G4 > 0 ? G4 : 1)) : 0;  // this thread's first column
     const int r_base = G4 > 0 ? tid / (G4 > 0 ? G4 : 1) : 0;
