@@ -424,9 +424,14 @@ attention_bwd_dkv_kernel(const float *__restrict__ qkv, const float *__restrict_
         for (int r = 0; r < 16; ++r) {
             const int qi = (r & 3) + 8 * (r >> 2) + 4 * lh;       // the query this register belongs to
             const float keep = ((mw >> qi) & 1u) ? keep_scale : 0.f;
-            const float pr = (qb * 32 + qi < Nv ? __expf(s[r] - Ls[buf][qi]) : 0.f) * kvalid;   // P (0 for padding rows / keys)
+            const float pr = __expf(s[r] - Ls[buf][qi]);          // P
             dp[r] = pr * (dp[r] * keep - Ds[buf][qi]);            // dS = P * (d(dropped P) * keep / (1 - p) - D)
             s[r] = pr * keep;                                     // dropped P, the operand of dV
+        }
+        if ((qb + 1) * 32 > Nv) {   // the cloud's last, partial query block: padding queries contribute nothing
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= Nv) dp[r] = 0.f, s[r] = 0.f;
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -439,10 +444,10 @@ attention_bwd_dkv_kernel(const float *__restrict__ qkv, const float *__restrict_
     }
     float *drow = dqkv + ((size_t)b * N + key) * ld + h * ATT_DH;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < 8; ++r) {   // padding keys took no part in the forward softmax: their rows are written as zeros
         const int d = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        drow[E + d] = dk[r];
-        drow[2 * E + d] = dv[r];
+        drow[E + d] = dk[r] * kvalid;
+        drow[2 * E + d] = dv[r] * kvalid;
     }
 }
 
