@@ -1599,7 +1599,7 @@ dw_kernel(const AOperand dz, const AOperand a2, int M, int Nc, int Kp, int tiles
 // lane = channel (64 channels x 4 row lanes), so dY and Z are read once, fully coalesced, and dZ is rebuilt on the
 // fly.  Output: one partial [C][4] per workgroup in the slab layout slab_reduce expects (pitch 4).
 // ---------------------------------------------------------------------------------------------
-template <int DZMODE>
+template <int DZMODE, int A2MODE>  // A2MODE: A_GATHER (neighbourhoods) or A_CONCAT (group_all on raw coordinates: centre = origin)
 __global__ void __launch_bounds__(256)
 dw_xyz_kernel(const AOperand dz, const AOperand a2, int M, int C, float *__restrict__ slab) {
     __shared__ float rel[256][4];
@@ -1607,9 +1607,9 @@ dw_xyz_kernel(const AOperand dz, const AOperand a2, int M, int C, float *__restr
     const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
     const int m0 = blockIdx.x * 256;
     {  // this thread's row: relative coordinates, zero for rows beyond M
-        const float2 x = fetch_a1<A_GATHER>(a2, m0 + tid, 0, 3, M);
-        const float2 y = fetch_a1<A_GATHER>(a2, m0 + tid, 1, 3, M);
-        const float2 z = fetch_a1<A_GATHER>(a2, m0 + tid, 2, 3, M);
+        const float2 x = fetch_a1<A2MODE>(a2, m0 + tid, 0, 3, M);
+        const float2 y = fetch_a1<A2MODE>(a2, m0 + tid, 1, 3, M);
+        const float2 z = fetch_a1<A2MODE>(a2, m0 + tid, 2, 3, M);
         const float okf = (m0 + tid < M) ? 1.f : 0.f;
         rel[tid][0] = __fsub_rn(x.x, x.y) * okf;
         rel[tid][1] = __fsub_rn(y.x, y.y) * okf;
@@ -1642,17 +1642,26 @@ dw_xyz_kernel(const AOperand dz, const AOperand a2, int M, int C, float *__restr
 // number of partial slabs launch_dw_xyz writes (pitch 4), for sizing
 int dw_xyz_splits(int M) { return cdiv(M, 256); }
 
-int launch_dw_xyz(const AOperand &dz, int C, const AOperand &a2, int M, float *slab, hipStream_t st) {
-    PNPP_REQUIRE(a2.mode == A_GATHER && a2.D == 0, PNPP_ERR_ARG, "dw_xyz: the second operand must be an xyz-only gather");
-    PNPP_REQUIRE(M > 0 && C > 0, PNPP_ERR_ARG, "dw_xyz: non-positive size");
-    const dim3 grid(dw_xyz_splits(M), 1);
-    ProfScope ps(st, "dw_xyz_kernel<A%d> M=%d N=%d K=3 grid=%dx1", dz.mode, M, C, grid.x);
+template <int A2MODE>
+static int launch_dw_xyz_a2(const AOperand &dz, int C, const AOperand &a2, int M, float *slab, dim3 grid, hipStream_t st) {
     switch (dz.mode) {
-        case A_PLAIN: hipLaunchKernelGGL(dw_xyz_kernel<A_PLAIN>, grid, dim3(256), 0, st, dz, a2, M, C, slab); break;
-        case A_DZ: hipLaunchKernelGGL(dw_xyz_kernel<A_DZ>, grid, dim3(256), 0, st, dz, a2, M, C, slab); break;
-        case A_DZ_POOL: hipLaunchKernelGGL(dw_xyz_kernel<A_DZ_POOL>, grid, dim3(256), 0, st, dz, a2, M, C, slab); break;
+        case A_PLAIN: hipLaunchKernelGGL((dw_xyz_kernel<A_PLAIN, A2MODE>), grid, dim3(256), 0, st, dz, a2, M, C, slab); break;
+        case A_DZ: hipLaunchKernelGGL((dw_xyz_kernel<A_DZ, A2MODE>), grid, dim3(256), 0, st, dz, a2, M, C, slab); break;
+        case A_DZ_POOL: hipLaunchKernelGGL((dw_xyz_kernel<A_DZ_POOL, A2MODE>), grid, dim3(256), 0, st, dz, a2, M, C, slab); break;
         default: set_error("dw_xyz: bad dZ mode %d", dz.mode); return PNPP_ERR_ARG;
     }
+    return PNPP_OK;
+}
+
+int launch_dw_xyz(const AOperand &dz, int C, const AOperand &a2, int M, float *slab, hipStream_t st) {
+    PNPP_REQUIRE((a2.mode == A_GATHER || a2.mode == A_CONCAT) && a2.D == 0, PNPP_ERR_ARG,
+                 "dw_xyz: the second operand must be xyz-only (gathered or whole-cloud)");
+    PNPP_REQUIRE(M > 0 && C > 0, PNPP_ERR_ARG, "dw_xyz: non-positive size");
+    const dim3 grid(dw_xyz_splits(M), 1);
+    ProfScope ps(st, "dw_xyz_kernel<A%d,A%d> M=%d N=%d K=3 grid=%dx1", dz.mode, a2.mode, M, C, grid.x);
+    const int rc = a2.mode == A_GATHER ? launch_dw_xyz_a2<A_GATHER>(dz, C, a2, M, slab, grid, st)
+                                       : launch_dw_xyz_a2<A_CONCAT>(dz, C, a2, M, slab, grid, st);
+    if (rc != PNPP_OK) return rc;
     PNPP_CHECK_LAUNCH("dw_xyz");
     return PNPP_OK;
 }
@@ -2570,8 +2579,108 @@ __global__ void __launch_bounds__(256) pool_fwd_kernel(const float *__restrict__
     }
 }
 
+// The same reduction for a level that pools over whole clouds (group_all on raw points: K = N in the thousands, few
+// groups): K is cut into gridDim.z chunks, a workgroup = 64 channels x 4 interleaved row lanes reduces one chunk to a
+// (value, position) partial, and pool_fwd_merge_kernel takes the first maximum over the chunks in ascending order.
+__global__ void __launch_bounds__(256) pool_fwd_split_kernel(const float *__restrict__ z, const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, int K, int C, int chunk,
+                                                             float *__restrict__ pmax, int32_t *__restrict__ parg) {
+    __shared__ float sv[4][64];
+    __shared__ int si[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int g = blockIdx.y, s = blockIdx.z;
+    const int k0 = s * chunk, k1 = k0 + chunk < K ? k0 + chunk : K;
+    float best = -INFINITY;
+    int bi = k0;
+    if (c < C) {
+        const float sc = scale[c], sh = shift[c];
+        const float *p = z + (size_t)g * K * C + c;
+        int k = k0 + rl;
+        for (; k + 12 < k1; k += 16) {  // four independent strided loads in flight per lane
+            float t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = p[(size_t)(k + 4 * u) * C];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = fmaxf(fmaf(t[u], sc, sh), 0.f);
+                if (v > best) best = v, bi = k + 4 * u;
+            }
+        }
+        for (; k < k1; k += 4) {
+            const float v = fmaxf(fmaf(p[(size_t)k * C], sc, sh), 0.f);
+            if (v > best) best = v, bi = k;
+        }
+    }
+    sv[rl][cl] = best;
+    si[rl][cl] = bi;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            const float v = sv[r][cl];
+            const int i = si[r][cl];
+            if (v > best || (v == best && i < bi)) best = v, bi = i;
+        }
+        const size_t o = ((size_t)g * gridDim.z + s) * C + c;
+        pmax[o] = best;
+        parg[o] = bi;
+    }
+}
+
+__global__ void __launch_bounds__(256) pool_fwd_merge_kernel(const float *__restrict__ pmax, const int32_t *__restrict__ parg, int G,
+                                                             int nsplit, int C, float *__restrict__ out, int32_t *__restrict__ arg,
+                                                             float *__restrict__ origin_a, float *__restrict__ origin_b, int norigin) {
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < norigin; i += 256) {
+            if (origin_a) origin_a[i] = 0.f;
+            if (origin_b) origin_b[i] = 0.f;
+        }
+    const size_t total = (size_t)G * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t g = i / C;
+        const int c = (int)(i - g * C);
+        float best = -INFINITY;
+        int bi = 0;
+        for (int s = 0; s < nsplit; ++s) {
+            const size_t o = (g * nsplit + s) * C + c;
+            const float v = pmax[o];
+            if (v > best) best = v, bi = parg[o];
+        }
+        out[i] = best;
+        arg[i] = bi;
+    }
+}
+
+int pool_fwd_splits(int G, int K, int C) {
+    if (K < 512) return 1;  // neighbourhood-sized groups: one thread per (group, channel)
+    const long long blocks = (long long)cdiv(C, 64) * G;
+    int nsplit = (int)cdiv(2048, blocks);          // >= 2048 workgroups over the chip ...
+    const int most = K / 64;                        // ... of at least 64 rows each
+    nsplit = nsplit > most ? most : nsplit;
+    return nsplit < 1 ? 1 : nsplit;
+}
+
 int launch_pool_fwd(const float *z, const float *scale, const float *shift, int G, int K, int C, float *out, int32_t *arg,
-                    hipStream_t st, float *origin_a, float *origin_b, int norigin) {
+                    hipStream_t st, float *origin_a, float *origin_b, int norigin, void *part) {
+    const int nsplit = part ? pool_fwd_splits(G, K, C) : 1;
+    if (nsplit > 1) {
+        const int chunk = (cdiv(K, nsplit) + 3) & ~3;
+        float *pmax = (float *)part;
+        int32_t *parg = (int32_t *)(pmax + (size_t)G * nsplit * C);
+        {
+            ProfScope ps(st, "pool_fwd_split_kernel G=%d K=%d C=%d split=%d", G, K, C, nsplit);
+            hipLaunchKernelGGL(pool_fwd_split_kernel, dim3(cdiv(C, 64), G, nsplit), dim3(256), 0, st, z, scale, shift, K, C, chunk,
+                               pmax, parg);
+            PNPP_CHECK_LAUNCH("pool_fwd_split");
+        }
+        const size_t tot = (size_t)G * C;
+        ProfScope ps(st, "pool_fwd_merge_kernel G=%d C=%d split=%d", G, C, nsplit);
+        hipLaunchKernelGGL(pool_fwd_merge_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, st, pmax, parg, G, nsplit, C, out, arg,
+                           origin_a, origin_b, norigin);
+        PNPP_CHECK_LAUNCH("pool_fwd_merge");
+        return PNPP_OK;
+    }
     const size_t total = (size_t)G * C;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     ProfScope ps(st, "pool_fwd_kernel G=%d K=%d C=%d", G, K, C);

@@ -143,8 +143,11 @@ int launch_post_gemm(const double *slab, int nslab, int C, double count, int tra
                      int Nc, int kp_pad, int Kvalid, int perm_D, float *dw, int ldo, hipStream_t st, const AOperand *dz = nullptr, int M = 0,
                      float *dz_out = nullptr);
 
+// part (optional): workspace of pool_fwd_splits(G, K, C) * G * C * 8 bytes; with it, pooling over whole clouds (K >= 512)
+// is split over K into partial maxima that a second launch merges (first maximum wins, as in the one-launch form)
+int pool_fwd_splits(int G, int K, int C);
 int launch_pool_fwd(const float *z, const float *scale, const float *shift, int G, int K, int C, float *out, int32_t *arg,
-                    hipStream_t st, float *origin_a = nullptr, float *origin_b = nullptr, int norigin = 0);
+                    hipStream_t st, float *origin_a = nullptr, float *origin_b = nullptr, int norigin = 0, void *part = nullptr);
 // backward of max + ReLU without materialising the dense gradient: writes the masked pooled gradient dm (G x C)
 // and collects the BatchNorm-backward column sums; consumers rebuild dy on the fly (A_DZ_POOL)
 int launch_pool_bwd(const float *dout, const int32_t *arg, const float *z, const float *scale, const float *shift,

@@ -565,6 +565,23 @@ __global__ void __launch_bounds__(256) mse_kernel(const float *__restrict__ p, c
     if (threadIdx.x == 0) *loss = (float)(red[0] * inv);
 }
 
+// per-row mean squared error: loss_vec[b] = mean_c (p[b,c] - t[b,c])^2 -- the per-sample line of simple_pointnet_train.py:174
+// (the mean of these rows is nn.MSELoss() of the batch, :153,182); dp[b,c] = 2 (p - t) / C = d loss_vec[b] / d p[b,c].
+__global__ void __launch_bounds__(256) mse_rows_kernel(const float *__restrict__ p, const float *__restrict__ t, int B, int C,
+                                                       float *__restrict__ loss_vec, float *__restrict__ dp) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const double inv = 1.0 / (double)C;
+    double acc = 0.0;
+    for (int c = 0; c < C; ++c) {
+        const size_t i = (size_t)b * C + c;
+        const double d = (double)p[i] - (double)t[i];
+        acc += d * d;
+        if (dp) dp[i] = (float)(2.0 * d * inv);
+    }
+    loss_vec[b] = (float)(acc * inv);
+}
+
 // orthogonality penalty of two predicted axes: mean_b (a_b . b_b)^2   (train.py:184-185)
 __global__ void __launch_bounds__(256) orth_loss_kernel(const float *__restrict__ a, const float *__restrict__ b, int B, int C,
                                                         float *__restrict__ loss, float *__restrict__ da,
@@ -753,6 +770,14 @@ extern "C" int pnpp_mse(const float *p, const float *t, size_t n, float *loss, f
     PNPP_REQUIRE(n > 0, PNPP_ERR_ARG, "mse: empty input");
     hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, as_stream(stream), p, t, n, loss, dp);
     PNPP_CHECK_LAUNCH("mse");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_mse_rows(const float *p, const float *t, int B, int C, float *loss_vec, float *dp, void *stream) {
+    PNPP_REQUIRE(p && t && loss_vec, PNPP_ERR_ARG, "mse_rows: null pointer");
+    PNPP_REQUIRE(B > 0 && C > 0, PNPP_ERR_ARG, "mse_rows: B=%d C=%d", B, C);
+    hipLaunchKernelGGL(mse_rows_kernel, dim3(cdiv(B, 256)), dim3(256), 0, as_stream(stream), p, t, B, C, loss_vec, dp);
+    PNPP_CHECK_LAUNCH("mse_rows");
     return PNPP_OK;
 }
 

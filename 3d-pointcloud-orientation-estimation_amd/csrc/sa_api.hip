@@ -266,7 +266,8 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
     // 3. max over the neighbourhood (pointnet_pp_8dir.py:42-43)
     const int Lm = d->L - 1;
     PNPP_TRY(launch_pool_fwd(sv.z[Lm], sv.scale[Lm], sv.shift[Lm], g.G, d->K, d->C[Lm], a->out, sv.arg, st,
-                             d->group_all ? a->new_xyz : nullptr, d->group_all ? sv.new_xyz : nullptr, d->group_all ? g.G * 3 : 0));
+                             d->group_all ? a->new_xyz : nullptr, d->group_all ? sv.new_xyz : nullptr, d->group_all ? g.G * 3 : 0,
+                             sc.dy[0]));  // dy[0] (M x C floats) is idle in the forward pass: >= the K/64 partials per (group, channel)
     return PNPP_OK;
 }
 
@@ -362,7 +363,8 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             }
             fused_slabs = dw_slabs;
         }
-        const bool xyz_only = l == 0 && a2.mode == A_GATHER && d->D == 0 && dw_xyz_splits(g.M) <= nsplit * (kp_pad / 4);
+        const bool xyz_only = l == 0 && d->D == 0 && (a2.mode == A_GATHER || (a2.mode == A_CONCAT && g.M >= 8192)) &&
+                              dw_xyz_splits(g.M) <= nsplit * (kp_pad / 4);
         if (l == 0 && sa_delayed(d)) {
             // G = dZ_0 summed per source point (dW_xyz = dZ_0^T (x - c) in the same pass); dW_f = G^T F, dF = G W_f
             const int R = d->B * d->N;

@@ -94,6 +94,7 @@ SIGNATURES = {
     "pnpp_l2_normalize": (_i, [_fp, _i, _i, _f, _fp, _fp]),
     "pnpp_l2_normalize_bwd": (_i, [_fp, _fp, _i, _i, _f, _fp, _fp]),
     "pnpp_mse": (_i, [_fp, _fp, _sz, _fp, _fp, _fp]),
+    "pnpp_mse_rows": (_i, [_fp, _fp, _i, _i, _fp, _fp, _fp]),
     "pnpp_orth_loss": (_i, [_fp, _fp, _i, _i, _fp, _fp, _fp, _fp]),
     "pnpp_proj_probs": (_i, [_fp, _fp, _i, _i, _fp, _fp]),
     "pnpp_proj_probs_bwd": (_i, [_fp, _fp, _fp, _i, _i, _fp, _fp]),

@@ -767,6 +767,28 @@ def mse_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     return _Mse.apply(pred, target)
 
 
+class _MseRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, t):
+        p, t = _f32(p, "input"), _f32(t, "target")
+        if p.shape != t.shape or p.dim() != 2:
+            raise ValueError(f"mse_rows: expected two (B,C) tensors, got {tuple(p.shape)} and {tuple(t.shape)}")
+        lv, dp = torch.empty(p.shape[0], device=p.device, dtype=torch.float32), torch.empty_like(p)
+        L.check(L.lib().pnpp_mse_rows(p.data_ptr(), t.data_ptr(), p.shape[0], p.shape[1], lv.data_ptr(), dp.data_ptr(), _stream()))
+        ctx.save_for_backward(dp)
+        return lv
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        return g[:, None] * dp, None
+
+
+def mse_rows(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """Per-sample mean squared error (B,C) -> (B,) (simple_pointnet_train.py:174); its mean is nn.MSELoss()(pred, target)."""
+    return _MseRows.apply(pred, target)
+
+
 class _Orth(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

@@ -272,6 +272,9 @@ int pnpp_l2_normalize_bwd(const float *x, const float *dy, int M, int C, float e
 /* nn.MSELoss() (train.py:168,183; train_multi_8dir.py:80,100; train_8dir.py:53,67): loss[0] = mean_i (p_i - t_i)^2 over
  * all n elements, dp (optional) = 2 (p - t) / n.  One workgroup, fixed-order float64 sum. */
 int pnpp_mse(const float *p, const float *t, size_t n, float *loss, float *dp, void *stream);
+/* simple_pointnet_train.py:153,174,182: the per-sample form, loss_vec[b] = mean_c (p[b,c] - t[b,c])^2 (its mean over b is
+ * nn.MSELoss() of the batch); dp (optional) [b,c] = 2 (p - t) / C. */
+int pnpp_mse_rows(const float *p, const float *t, int B, int C, float *loss_vec, float *dp, void *stream);
 /* train.py:184-185: loss[0] = mean_b (a_b . b_b)^2 for two (B,C) sets of axes; da, db optional (both or neither). */
 int pnpp_orth_loss(const float *a, const float *b, int B, int C, float *loss, float *da, float *db, void *stream);
 /* train_multi_8dir.py:41-44 proj_probs: v = normalize(vec (B,3)); sims = clamp(v dirs^T, min=0) with dirs (D,3), D <= 16;

@@ -510,6 +510,51 @@ def golden_pt():
     save("pt.npz", **out)
 
 
+def load_simple():
+    """simple_pointnet_train.py as a module: its training only starts under `if __name__ == "__main__"` (:271)."""
+    spec = importlib.util.spec_from_file_location("ref_simple_pointnet_train", os.path.join(REF, "simple_pointnet_train.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def golden_simple():
+    """BASELINE configs[0]: the reference's own SimplePointNet (simple_pointnet_train.py:86-113) with nn.MSELoss (:243) on
+    256-point clouds, batch 4 -- float32 and float64, without dropout and with an injected mask; train-mode outputs, loss,
+    gradient summaries, the BatchNorm running statistics after that one forward, and the eval-mode outputs that follow."""
+    ref = load_simple()
+    B, N = 4, 256
+    xyz, _, _, fwd = R.synthetic_clouds(B, N, seed=77)
+    mask = (torch.rand(B, 128, generator=torch.Generator().manual_seed(9)) < 0.7).float()
+    crit = nn.MSELoss()
+    out = dict(xyz_ck=np.array([xyz.double().sum().item(), xyz.double().abs().sum().item()]), fwd=n(fwd),
+               drop_mask=n(mask).astype(np.uint8))
+    for dt_name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        for variant in ("nodrop", "mask"):
+            torch.manual_seed(42)
+            model = ref.SimplePointNet()
+            if dt_name == "f32" and variant == "nodrop":
+                out.update(_param_checksums(model))
+            model = model.to(dt)
+            model.dropout = nn.Identity() if variant == "nodrop" else _Mask(mask, 0.3)
+            model.train()
+            res = model(xyz.to(dt))
+            loss = crit(res, fwd.to(dt))
+            loss.backward()
+            tag = f"{dt_name}_{variant}"
+            out[f"{tag}.out"], out[f"{tag}.loss"] = n(res), np.array(loss.item())
+            for k, v in _grad_summary(model).items():
+                out[f"{tag}.{k}"] = v
+            if variant == "nodrop":
+                for k, v in model.state_dict().items():
+                    if "running" in k:
+                        out[f"{tag}.after.{k}"] = n(v)
+                model.eval()
+                with torch.no_grad():
+                    out[f"{tag}.eval_out"] = n(model(xyz.to(dt)))
+    save("simple.npz", **out)
+
+
 def golden_vm_gt():
     """data_process/demo_vm_gt/*.txt + the mu values printed in 2d_single_peak_vM_test.ipynb."""
     d = os.path.join(REF, "data_process/demo_vm_gt")
@@ -531,6 +576,6 @@ def golden_vm_gt():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["index", "sa", "e2e", "kl", "debug_log", "vm_gt", "f3", "pt"]
+    which = sys.argv[1:] or ["index", "sa", "e2e", "kl", "debug_log", "vm_gt", "f3", "pt", "simple"]
     for w in which:
         globals()[f"golden_{w}"]()

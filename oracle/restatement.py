@@ -291,6 +291,34 @@ def axes_forward(xyz32, P, centres, heads, drop_mask=None, training=True, bn_sta
     return tuple(l2_normalize(_lin(feat, P, h)) for h in heads)
 
 
+def simple_pointnet_forward(xyz32, P, drop_mask=None, training=True, bn_state=None, p_drop=0.3, argmax=None, diag=None):
+    """SimplePointNet.forward of the reference's simple_pointnet_train.py:103-113: Conv1d/BatchNorm1d/ReLU x 3 over every
+    point (conv1..3, bn1..3), max over the cloud (:110), relu(bn4(fc1)), dropout(0.3), fc2.  The per-point part is the
+    whole-cloud (group_all) form of sa_forward on raw coordinates, so the max-pool routing can be injected the same way.
+    drop_mask (B,128) of {0,1} replaces the dropout draw; None = no dropout."""
+    Q = {}
+    for i in range(3):
+        for k in ("weight", "bias"):
+            Q[f"enc.convs.{i}.{k}"] = P[f"conv{i + 1}.{k}"]
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            Q[f"enc.bns.{i}.{k}"] = P[f"bn{i + 1}.{k}"]
+    st = BNState() if bn_state is not None else None
+    _, feat, _ = sa_forward(xyz32, None, Q, "enc", None, None, True, training, st, argmax=argmax, diag=diag)
+    if bn_state is not None:
+        for i in range(3):
+            if f"enc.bns.{i}" in st.updates:
+                bn_state.updates[f"bn{i + 1}"] = st.updates[f"enc.bns.{i}"]
+    x = torch.relu(_bn1d(_lin(feat.reshape(feat.shape[0], -1), P, "fc1"), P, "bn4", training, bn_state))
+    if training and drop_mask is not None:
+        x = x * drop_mask.to(x.dtype) / (1.0 - p_drop)
+    return _lin(x, P, "fc2")
+
+
+def mse_rows(pred, target):
+    """Per-sample line of simple_pointnet_train.py:174; the mean of the rows is nn.MSELoss() (:153,182)."""
+    return ((pred - target) ** 2).mean(dim=1)
+
+
 def mse(pred, target):
     """nn.MSELoss() (train.py:168)."""
     return ((pred - target) ** 2).mean()

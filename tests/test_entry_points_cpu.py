@@ -119,6 +119,38 @@ def test_train_scripts_surface(monkeypatch):
     assert abs(float(v) - 0.29115965962409973) < 2e-6
 
 
+def test_simple_pointnet_script_surface(cloud, tmp_path):
+    """BASELINE configs[0]: the names simple_pointnet_train.py defines, its dataset's tuple layout and errors
+    (reference :46-81), the module's state_dict (reference :87-101), and the refusal to run without the GPU."""
+    import simple_pointnet_train as spt
+    for name in ("read_ply", "sample_points", "PointCloudDataset", "SimplePointNet", "train_model", "test_model", "main"):
+        assert hasattr(spt, name), name
+    assert (spt.NUM_POINTS, spt.BATCH, spt.EPOCHS, spt.LR, spt.SEED) == (10_000, 16, 200, 1e-3, 42)   # :226,231,246,244,197
+    p, pts = cloud
+    p.with_suffix(".txt").write_text("0.5 0.0 -0.8660254 ignored\n")
+    ds = spt.PointCloudDataset(str(p.parent), [p.name], num_points=64)
+    xyz, target = ds[0]
+    assert len(ds) == 1 and xyz.shape == (64, 3) and xyz.dtype == torch.float32
+    assert torch.allclose(target, torch.tensor([0.5, 0.0, -0.8660254]))
+    p.with_suffix(".txt").write_text("0.5 0.0\n")
+    with pytest.raises(ValueError):
+        ds[0]
+    p.with_suffix(".txt").unlink()
+    with pytest.raises(FileNotFoundError):
+        ds[0]
+    with pytest.raises(RuntimeError):
+        spt.read_ply(str(tmp_path / "missing.ply"))
+    sd = spt.SimplePointNet().state_dict()
+    shapes = {"conv1.weight": (64, 3, 1), "conv2.weight": (128, 64, 1), "conv3.weight": (256, 128, 1), "bn3.running_var": (256,),
+              "fc1.weight": (128, 256), "bn4.weight": (128,), "fc2.weight": (3, 128), "fc2.bias": (3,)}
+    for k, shp in shapes.items():
+        assert tuple(sd[k].shape) == shp, k
+    assert sum(v.numel() for k, v in sd.items() if "running" not in k and "tracked" not in k) == 76_035
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no GPU"):
+            spt.main(["--synthetic", "8", "--points", "256", "--batch", "4", "--epochs", "1"])
+
+
 def test_results_txt_format(tmp_path):
     import train_multi_peaks_vonMises_KL as t2
     hist = {"total": {"train": [0.2, 0.084364], "val": [0.3, 0.083457]}, "bathtub": {"train": [0.7, 0.71], "val": [0.8, 0.77]},
