@@ -499,6 +499,19 @@ __device__ __forceinline__ RawTail ws_fetch_tail(const AOperand &A, int row, int
 // Thread -> (column group kq = tid % G4, rows tid / G4 + i * RPP): every thread keeps ONE column group
 // for the whole kernel, so its per-channel constants live in registers, and with K_nbr == 32 the
 // pooled-gradient / arg-max entries of a tile's few neighbour groups are fetched once per tile.
+#ifdef PNPP_STAMPS
+__device__ unsigned long long g_stamps[16];
+__device__ int g_stamp_kd;
+#define PNPP_STAMP(i)                                                 \
+    if (st_on) {                                                      \
+        __builtin_amdgcn_s_waitcnt(0);                                \
+        const unsigned long long st_t = __builtin_amdgcn_s_memtime(); \
+        if (lane == 0) g_stamps[i] += st_t - st_last;                 \
+        st_last = st_t;                                               \
+    }
+#else
+#define PNPP_STAMP(i)
+#endif
 template <int KD, int BM, int BN, int WM, int WN, int AMODE, int EMODE, bool FDW>
 __global__ void __launch_bounds__(256, (KD >= 256 ? 1 : 2))  // the K=256 panels leave room for one workgroup per CU anyway
 gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, const Epilogue E) {
@@ -551,8 +564,9 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
         const float *__restrict__ Bm = B.b;
         const int ldb = B.ldb;
         const bool bvec = (ldb & 3) == 0 && ((uintptr_t)Bm & 15) == 0 && B.perm_D < 0;
-        for (int f = tid; f < KD * (BN / 4); f += 256) {
-            float t[4];
+        // two passes: every 16-byte group of the panel this thread owns is REQUESTED first (all loads in flight together: one
+        // L2 / HBM round trip for the whole panel instead of one per group of a rolled loop), then masked and written to LDS
+        auto wload = [&](int f, float (&t)[4]) {
             if (!B.trans) {
                 const int kk = f / (BN / 4), n = n0 + 4 * (f % (BN / 4));
                 const float *src = Bm + (size_t)min(kk, B.rows - 1) * ldb;
@@ -562,15 +576,6 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) t[e] = src[min(n + e, Nout - 1)];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] *= (kk < B.rows && n + e < Nout) ? 1.f : 0.f;
-                if constexpr (SWZ) {  // transposed image: four scalar stores (once per workgroup)
-                    const int nl = 4 * (f % (BN / 4));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) Ws[(nl + e) * KD + (kk ^ a_swz(nl + e))] = t[e];
-                } else {
-                    *reinterpret_cast<float4 *>(Ws + kk * BN + 4 * (f % (BN / 4))) = make_float4(t[0], t[1], t[2], t[3]);
                 }
             } else {
                 const int nl = f % BN, k4 = 4 * (f / BN), n = n0 + nl;
@@ -587,6 +592,22 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                         t[e] = src[col];
                     }
                 }
+            }
+        };
+        auto wstore = [&](int f, float (&t)[4]) {
+            if (!B.trans) {
+                const int kk = f / (BN / 4), n = n0 + 4 * (f % (BN / 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] *= (kk < B.rows && n + e < Nout) ? 1.f : 0.f;
+                if constexpr (SWZ) {  // transposed image: four scalar stores (once per workgroup)
+                    const int nl = 4 * (f % (BN / 4));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Ws[(nl + e) * KD + (kk ^ a_swz(nl + e))] = t[e];
+                } else {
+                    *reinterpret_cast<float4 *>(Ws + kk * BN + 4 * (f % (BN / 4))) = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            } else {
+                const int nl = f % BN, k4 = 4 * (f / BN), n = n0 + nl;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[e] *= (n < Nout && k4 + e < B.rows) ? 1.f : 0.f;
                 if constexpr (SWZ) {
@@ -594,6 +615,68 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) Ws[(k4 + e) * BN + nl] = t[e];
+                }
+            }
+        };
+        // (row-major panels of the backward kernels, K >= 128: -1.6 us on the K = 256 launch; the [n][k] weights of the forward
+        // kernels are read 16 bytes per lane from 64 different rows, and more of THOSE requests in flight was 2 us slower)
+        constexpr int NWF = (KD * (BN / 4)) / 256;
+        bool staged = false;
+        if constexpr ((KD * (BN / 4)) % 256 == 0 && NWF >= 8 && NWF <= 16) {
+            if (!B.trans) {
+                staged = true;
+                float tw[NWF][4];
+#pragma unroll
+                for (int j = 0; j < NWF; ++j) wload(tid + 256 * j, tw[j]);
+#pragma unroll
+                for (int j = 0; j < NWF; ++j) wstore(tid + 256 * j, tw[j]);
+            }
+        }
+        if (!staged) {
+            for (int f = tid; f < KD * (BN / 4); f += 256) {
+                float t[4];
+                if (!B.trans) {
+                    const int kk = f / (BN / 4), n = n0 + 4 * (f % (BN / 4));
+                    const float *src = Bm + (size_t)min(kk, B.rows - 1) * ldb;
+                    if (bvec) {
+                        const float4 v = *reinterpret_cast<const float4 *>(src + min(n, Nout - 4));
+                        t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+                    } else {
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = src[min(n + e, Nout - 1)];
+                    }
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] *= (kk < B.rows && n + e < Nout) ? 1.f : 0.f;
+                    if constexpr (SWZ) {  // transposed image: four scalar stores (once per workgroup)
+                        const int nl = 4 * (f % (BN / 4));
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) Ws[(nl + e) * KD + (kk ^ a_swz(nl + e))] = t[e];
+                    } else {
+                        *reinterpret_cast<float4 *>(Ws + kk * BN + 4 * (f % (BN / 4))) = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                } else {
+                    const int nl = f % BN, k4 = 4 * (f / BN), n = n0 + nl;
+                    const float *src = Bm + (size_t)min(n, Nout - 1) * ldb;
+                    if (bvec) {
+                        const float4 v = *reinterpret_cast<const float4 *>(src + min(k4, B.rows - 4));
+                        t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+                    } else {
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int kp = min(k4 + e, B.rows - 1);
+                            int col = kp;
+                            if (B.perm_D >= 0) col = kp < B.perm_D ? kp + 3 : kp - B.perm_D;
+                            t[e] = src[col];
+                        }
+                    }
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] *= (n < Nout && k4 + e < B.rows) ? 1.f : 0.f;
+                    if constexpr (SWZ) {
+                        *reinterpret_cast<float4 *>(Ws + nl * KD + (k4 ^ a_swz(nl))) = make_float4(t[0], t[1], t[2], t[3]);
+                    } else {
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) Ws[(k4 + e) * BN + nl] = t[e];
+                    }
                 }
             }
         }
@@ -632,7 +715,27 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     const bool pool_fast = (AMODE == A_DZ_POOL) && A.K == 32;  // tiles start on neighbour-group boundaries (BM % 32 == 0)
     float4 rp[NG > 0 ? NG : 1], rq[(AMODE == A_DZ && NG > 0) ? NG : 1];
     RawTail rt;
+    // M a multiple of BM (every shape of the training step): no row of a tile needs a clamp or a bounds test, and the operand
+    // streams are (uniform tile pointer, advanced by scalar arithmetic) + (one 32-bit lane offset computed once) -- the 64-bit
+    // multiply-add, clamp and EXEC branch per 16-byte group were a third of the staging pass, and VALU time is MFMA time
+    // (measured: -4.6 % on the K = 256 kernels, which run one wave per SIMD; nothing or a small loss on the K <= 128 kernels with
+    // two waves per SIMD, which keep the general path)
+    constexpr bool DENSE_A = (AMODE == A_PLAIN || AMODE == A_BNRELU || AMODE == A_DZ || AMODE == A_DZ_POOL) && KD >= 256;
+    const bool full_rows = DENSE_A && (M % BM) == 0 && (AMODE != A_DZ_POOL || A.K == 32);
+    const unsigned offA = (unsigned)r_base * (unsigned)A.lda + (unsigned)kq;
     auto fetch = [&](int m0) {
+        if constexpr (DENSE_A) {
+            if (full_rows) {
+                const float *pa = (AMODE == A_DZ_POOL ? A.z : A.a) + (size_t)m0 * A.lda;
+                const float *pz = A.z + (size_t)m0 * A.lda;
+#pragma unroll
+                for (int i = 0; i < NG; ++i) {
+                    rp[i] = *reinterpret_cast<const float4 *>(pa + (size_t)(i * RPP) * A.lda + offA);
+                    if constexpr (AMODE == A_DZ) rq[i] = *reinterpret_cast<const float4 *>(pz + (size_t)(i * RPP) * A.lda + offA);
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int rc = min(m0 + r_base + i * RPP, M - 1);
@@ -654,13 +757,27 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     };
     int tile = worker;
     if (tile < tiles) fetch(tile * BM);
+    // see the K loop: with `inter` the operand loads of the NEXT tile are issued between this tile's MFMAs
+    const bool inter = DENSE_A && SWZ && EMODE == E_MASK_STATS && !(FDW && NT > 1) && full_rows && n0 + BN <= Nout;
+#ifdef PNPP_STAMPS
+    const bool st_on = FDW && AMODE == A_DZ_POOL && blockIdx.x == 8 && wave == 0 && g_stamp_kd == KD;
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
     for (; tile < tiles; tile += nworkers) {
         const int m0 = tile * BM;
+        PNPP_STAMP(0)
         // pooled gradient / arg-max of the tile's neighbour groups at this thread's columns (L2-resident tables)
         float4 gdm[GPT];
         int4 garg[GPT];
         if constexpr (AMODE == A_DZ_POOL) {
-            if (pool_fast) {
+            if (full_rows) {
+#pragma unroll
+                for (int g = 0; g < GPT; ++g) {
+                    const size_t gi = (size_t)(m0 / 32 + g) * A.lda + kq;
+                    gdm[g] = *reinterpret_cast<const float4 *>(A.a + gi);
+                    garg[g] = *reinterpret_cast<const int4 *>(A.arg + gi);
+                }
+            } else if (pool_fast) {
 #pragma unroll
                 for (int g = 0; g < GPT; ++g) {
                     const size_t gi = (size_t)min(m0 / 32 + g, (M - 1) / 32) * A.lda + kq;
@@ -670,11 +787,18 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
             }
         }
         __syncthreads();  // previous tile's operand reads are done (and, first time, the weights are staged)
+        PNPP_STAMP(1)
+        // two copies of the staging pass, the compile-time flag FULL picking which one runs (full_rows is uniform): the copy for
+        // M % BM == 0 has no bounds test, no zero fill and no EXEC branch per 16-byte group
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+        const bool FULL = pass == 0;
+        if (FULL != full_rows) continue;
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int r = r_base + i * RPP, row = m0 + r;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (row < M) {
+            if (FULL || row < M) {
                 if constexpr (AMODE == A_PLAIN || AMODE == A_GATHER || AMODE == A_CONCAT) {
                     v[0] = rp[i].x, v[1] = rp[i].y, v[2] = rp[i].z, v[3] = rp[i].w;
                 } else if constexpr (AMODE == A_BNRELU) {
@@ -691,7 +815,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                         float4 dm;
                         int4 ia;
                         int kk;
-                        if (pool_fast) {
+                        if (FULL || pool_fast) {   // (FULL implies pool_fast: no merge with the general path below)
                             // neighbour group of this row inside the tile: a constant per unrolled pass when RPP | 32
                             const int g = (RPP >= 32) ? r / 32 : (i * RPP) / 32;
                             dm = gdm[0], ia = garg[0];
@@ -721,6 +845,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                 for (int e = 0; e < 4; ++e) As[a_idx(r, kq + e)] = v[e];
             }
         }
+        }
         if constexpr (HAS_TAIL) {
             if (tid < BM) {
                 const bool ok = m0 + tid < M;
@@ -731,12 +856,31 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                 As[a_idx(tid, KMAIN + 3)] = 0.f;
             }
         }
+        PNPP_STAMP(2)
         __syncthreads();
-        if (tile + nworkers < tiles) fetch((tile + nworkers) * BM);  // next tile's HBM stream flies during the MFMA loop
+        PNPP_STAMP(3)
+        // K >= 256 (one wave per SIMD), dense operand, full tiles: the next tile's operand loads and this tile's epilogue operand are
+        // issued BETWEEN the MFMAs of the unrolled K loop below -- a memory instruction issues while the matrix pipe works
+        // on the previous MFMA, whereas 32 loads issued in front of the loop are ~1k cycles in which the pipe idles
+        const bool have_next = tile + nworkers < tiles;
+        if (!inter && have_next) fetch((tile + nworkers) * BM);  // next tile's HBM stream flies during the MFMA loop
 
         // the ReLU-mask operand of the epilogue is fetched now and lands while the MFMA loop runs
         float zp[MT][NT][16];
         if constexpr (EMODE == E_MASK_STATS) {
+          if (inter) {
+            // (issued inside the K loop)
+          } else if (full_rows && n0 + BN <= Nout) {
+            const float *pzp = E.zp + (size_t)m0 * E.ldc;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const unsigned oz = (unsigned)(wm * TM + i * 32 + 4 * lh) * (unsigned)E.ldc + (unsigned)(n0 + wn * TN + j * 32 + l31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zp[i][j][r] = pzp[(size_t)((r & 3) + 8 * (r >> 2)) * E.ldc + oz];
+                }
+          } else {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -748,6 +892,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                         zp[i][j][r] = E.zp[(size_t)min(row, M - 1) * E.ldc + cc];
                     }
                 }
+          }
         }
 
         f32x16 acc[MT][NT];
@@ -817,13 +962,55 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                     mm(0);
                 }
             } else {
-                ld(0, 0);
+                bool looped = false;
+                if constexpr (DENSE_A && EMODE == E_MASK_STATS) {
+                    if (inter) {
+                        looped = true;
+                        const size_t mn = (size_t)(tile + nworkers) * BM;
+                        const float *pa = (AMODE == A_DZ_POOL ? A.z : A.a) + mn * A.lda;
+                        const float *pz = A.z + mn * A.lda;
+                        const float *pzp = E.zp + (size_t)m0 * E.ldc;
+                        auto issue = [&](int u) {  // an eighth of the two load streams
+                            constexpr int GP = (NG + 7) / 8, ZP = MT * NT * 2;
+                            if (have_next) {
+#pragma unroll
+                                for (int g = 0; g < GP; ++g) {
+                                    const int i = u * GP + g;
+                                    if (i < NG) {
+                                        rp[i] = *reinterpret_cast<const float4 *>(pa + (size_t)(i * RPP) * A.lda + offA);
+                                        if constexpr (AMODE == A_DZ)
+                                            rq[i] = *reinterpret_cast<const float4 *>(pz + (size_t)(i * RPP) * A.lda + offA);
+                                    }
+                                }
+                            }
+#pragma unroll
+                            for (int q = u * ZP; q < (u + 1) * ZP; ++q) {
+                                const int r = q & 15, j = (q >> 4) % NT, i = (q >> 4) / NT;
+                                const unsigned oz = (unsigned)(wm * TM + i * 32 + 4 * lh) * (unsigned)E.ldc + (unsigned)(n0 + wn * TN + j * 32 + l31);
+                                zp[i][j][r] = pzp[(size_t)((r & 3) + 8 * (r >> 2)) * E.ldc + oz];
+                            }
+                        };
+                        ld(0, 0);
+#pragma unroll
+                        for (int t = 0; t < 8; t += 2) {
+                            ld(1, t + 1);
+                            issue(t);
+                            mm(0);
+                            if (t + 2 < 8) ld(0, t + 2);
+                            issue(t + 1);
+                            mm(1);
+                        }
+                    }
+                }
+                if (!looped) {
+                    ld(0, 0);
 #pragma unroll 1
-                for (int t = 0; t < 8; t += 2) {
-                    ld(1, t + 1);
-                    mm(0);
-                    if (t + 2 < 8) ld(0, t + 2);
-                    mm(1);
+                    for (int t = 0; t < 8; t += 2) {
+                        ld(1, t + 1);
+                        mm(0);
+                        if (t + 2 < 8) ld(0, t + 2);
+                        mm(1);
+                    }
                 }
             }
         } else {
@@ -862,6 +1049,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
             }
         }
 
+        PNPP_STAMP(4)
         // epilogue: each accumulator register is one row; a half-wave writes 32 consecutive floats (128 B)
         bool done = false;
         if constexpr (EMODE != E_MASK_STATS) {
@@ -952,8 +1140,10 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                 }
                 if constexpr (EMODE != E_STORE) s1[j] += (double)t1, s2[j] += (double)t2;
             }
+        PNPP_STAMP(5)
         if constexpr (FDW) {
             __syncthreads();  // the whole relu(bn(zp)) tile is in LDS; the dZ tile still is
+            PNPP_STAMP(6)
             // dW tile (ct, kt) += dZ^T (columns ct*32.. of the A tile) x activation tile (columns kt*32..).  A wave's DT tiles
             // (tile_id = wave + 4 t) share kt, so one activation operand feeds DT MFMAs on DT independent accumulators.
             // The reduction index is the tile row m = 32 c + 2 t2 + lh; f(m) = f(2 t2) | (lh << 2) (the swizzle only looks at
@@ -986,14 +1176,46 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                     for (int t = 0; t < DT; ++t)
                         dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[buf][c][t], db[buf][c], dwacc[t], 0, 0, 0);
             };
-            ld(0, 0);
+            if constexpr (KD >= 256) {
+                // one wave per SIMD here, registers to spare: the swizzled operand addresses of the eight F values are a table
+                // built once per tile from this lane's colx, and with t2 unrolled every read of the loop is (table entry) +
+                // (immediate offset) -- no address arithmetic between the MFMAs (it was 45 VALU per 8 MFMAs)
+                const float *pre[DT][8];
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) pre[t][f] = abase + 2 * f * KP + (colx[t] ^ (f << 3));
+                auto ldt = [&](int buf, int t2) {
+                    const int f = t2 & 7, h = t2 >> 3;
+                    const float *pb = bbase + 2 * t2 * BN;
+#pragma unroll
+                    for (int c = 0; c < MC; ++c) db[buf][c] = pb[32 * c * BN];
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) {
+                        const float *pa = pre[t][f] + 16 * h * KP;
+#pragma unroll
+                        for (int c = 0; c < MC; ++c) da[buf][c][t] = pa[32 * c * KP];
+                    }
+                };
+                ldt(0, 0);
+#pragma unroll
+                for (int t2 = 0; t2 < 16; t2 += 2) {
+                    ldt(1, t2 + 1);
+                    mm(0);
+                    if (t2 + 2 < 16) ldt(0, t2 + 2);
+                    mm(1);
+                }
+            } else {
+                ld(0, 0);
 #pragma unroll 1
-            for (int t2 = 0; t2 < 16; t2 += 2) {
-                ld(1, t2 + 1);
-                mm(0);
-                if (t2 + 2 < 16) ld(0, t2 + 2);
-                mm(1);
+                for (int t2 = 0; t2 < 16; t2 += 2) {
+                    ld(1, t2 + 1);
+                    mm(0);
+                    if (t2 + 2 < 16) ld(0, t2 + 2);
+                    mm(1);
+                }
             }
+            PNPP_STAMP(7)
         }
     }
 
@@ -1123,6 +1345,8 @@ static bool try_launch_ws(const AOperand &A, const BOperand &B, int M, int Nout,
         return true;
     }
     if (Kd == 128) {
+        // (a 128-row tile with one workgroup per CU and the K = 256 kernel's unrolled, interleaved loops was measured at the same
+        // 57.8 us for the SA1 backward launch and 4-7 % slower for the others)
         *rc = launch_ws_dense<128, 64, 64, 2, 2>(A, B, M, Nout, E, nslab, st, dw_slabs);
         return true;
     }
@@ -2742,6 +2966,21 @@ __global__ void __launch_bounds__(256) fill_zero_kernel(float4 *__restrict__ p, 
         p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+#ifdef PNPP_STAMPS
+}  // namespace pnpp
+extern "C" int pnpp_debug_stamps(unsigned long long *out16, int kd) {  // kd > 0: select + reset; kd == 0: read
+    if (kd > 0) {
+        unsigned long long z[16] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(pnpp::g_stamps), z, sizeof(z));
+        hipMemcpyToSymbol(HIP_SYMBOL(pnpp::g_stamp_kd), &kd, sizeof(int));
+    } else {
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(out16, HIP_SYMBOL(pnpp::g_stamps), 16 * sizeof(unsigned long long));
+    }
+    return 0;
+}
+namespace pnpp {
+#endif
 int launch_fill_zero(void *p, size_t bytes, hipStream_t st) {
     if (bytes == 0) return PNPP_OK;
     hipError_t e = hipMemsetAsync(p, 0, bytes, st);

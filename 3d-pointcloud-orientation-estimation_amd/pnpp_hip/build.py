@@ -25,7 +25,7 @@ COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wno-unused-v
 # compiler must not introduce fused multiply-adds of its own there
 SOURCES = {
     "index_kernels.hip": ["-ffp-contract=off"],
-    "gemm_kernels.hip": [],
+    "gemm_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_bf16_kernels.hip": [],
     "loss_kernels.hip": [],
     "sa_api.hip": [],
