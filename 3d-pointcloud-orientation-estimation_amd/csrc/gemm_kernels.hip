@@ -546,6 +546,10 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+#ifdef PNPP_STAMPS
+    const bool st_on = FDW && AMODE == A_DZ_POOL && blockIdx.x == 8 && wave == 0 && g_stamp_kd == KD;
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
     // XCD-aware tile map (speed only, never correctness): blocks b and b + 8 share an XCD and with it an L2, so the ncol
     // column blocks of one worker -- which stream the SAME operand rows -- are placed 8 apart: the rows come from HBM once
     // and from that L2 for the other column blocks, instead of once per XCD
@@ -559,130 +563,9 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     const int kq = G4 > 0 ? 4 * (tid % (G4 > 0 ? G4 : 1)) : 0;  // this thread's first column
     const int r_base = G4 > 0 ? tid / (G4 > 0 ? G4 : 1) : 0;
 
-    // ---- weights: staged once, [k][n] ----
-    {
-        const float *__restrict__ Bm = B.b;
-        const int ldb = B.ldb;
-        const bool bvec = (ldb & 3) == 0 && ((uintptr_t)Bm & 15) == 0 && B.perm_D < 0;
-        // two passes: every 16-byte group of the panel this thread owns is REQUESTED first (all loads in flight together: one
-        // L2 / HBM round trip for the whole panel instead of one per group of a rolled loop), then masked and written to LDS
-        auto wload = [&](int f, float (&t)[4]) {
-            if (!B.trans) {
-                const int kk = f / (BN / 4), n = n0 + 4 * (f % (BN / 4));
-                const float *src = Bm + (size_t)min(kk, B.rows - 1) * ldb;
-                if (bvec) {
-                    const float4 v = *reinterpret_cast<const float4 *>(src + min(n, Nout - 4));
-                    t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = src[min(n + e, Nout - 1)];
-                }
-            } else {
-                const int nl = f % BN, k4 = 4 * (f / BN), n = n0 + nl;
-                const float *src = Bm + (size_t)min(n, Nout - 1) * ldb;
-                if (bvec) {
-                    const float4 v = *reinterpret_cast<const float4 *>(src + min(k4, B.rows - 4));
-                    t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int kp = min(k4 + e, B.rows - 1);
-                        int col = kp;
-                        if (B.perm_D >= 0) col = kp < B.perm_D ? kp + 3 : kp - B.perm_D;
-                        t[e] = src[col];
-                    }
-                }
-            }
-        };
-        auto wstore = [&](int f, float (&t)[4]) {
-            if (!B.trans) {
-                const int kk = f / (BN / 4), n = n0 + 4 * (f % (BN / 4));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] *= (kk < B.rows && n + e < Nout) ? 1.f : 0.f;
-                if constexpr (SWZ) {  // transposed image: four scalar stores (once per workgroup)
-                    const int nl = 4 * (f % (BN / 4));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) Ws[(nl + e) * KD + (kk ^ a_swz(nl + e))] = t[e];
-                } else {
-                    *reinterpret_cast<float4 *>(Ws + kk * BN + 4 * (f % (BN / 4))) = make_float4(t[0], t[1], t[2], t[3]);
-                }
-            } else {
-                const int nl = f % BN, k4 = 4 * (f / BN), n = n0 + nl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] *= (n < Nout && k4 + e < B.rows) ? 1.f : 0.f;
-                if constexpr (SWZ) {
-                    *reinterpret_cast<float4 *>(Ws + nl * KD + (k4 ^ a_swz(nl))) = make_float4(t[0], t[1], t[2], t[3]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) Ws[(k4 + e) * BN + nl] = t[e];
-                }
-            }
-        };
-        // (row-major panels of the backward kernels, K >= 128: -1.6 us on the K = 256 launch; the [n][k] weights of the forward
-        // kernels are read 16 bytes per lane from 64 different rows, and more of THOSE requests in flight was 2 us slower)
-        constexpr int NWF = (KD * (BN / 4)) / 256;
-        bool staged = false;
-        if constexpr ((KD * (BN / 4)) % 256 == 0 && NWF >= 8 && NWF <= 16) {
-            if (!B.trans) {
-                staged = true;
-                float tw[NWF][4];
-#pragma unroll
-                for (int j = 0; j < NWF; ++j) wload(tid + 256 * j, tw[j]);
-#pragma unroll
-                for (int j = 0; j < NWF; ++j) wstore(tid + 256 * j, tw[j]);
-            }
-        }
-        if (!staged) {
-            for (int f = tid; f < KD * (BN / 4); f += 256) {
-                float t[4];
-                if (!B.trans) {
-                    const int kk = f / (BN / 4), n = n0 + 4 * (f % (BN / 4));
-                    const float *src = Bm + (size_t)min(kk, B.rows - 1) * ldb;
-                    if (bvec) {
-                        const float4 v = *reinterpret_cast<const float4 *>(src + min(n, Nout - 4));
-                        t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
-                    } else {
-    #pragma unroll
-                        for (int e = 0; e < 4; ++e) t[e] = src[min(n + e, Nout - 1)];
-                    }
-    #pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] *= (kk < B.rows && n + e < Nout) ? 1.f : 0.f;
-                    if constexpr (SWZ) {  // transposed image: four scalar stores (once per workgroup)
-                        const int nl = 4 * (f % (BN / 4));
-    #pragma unroll
-                        for (int e = 0; e < 4; ++e) Ws[(nl + e) * KD + (kk ^ a_swz(nl + e))] = t[e];
-                    } else {
-                        *reinterpret_cast<float4 *>(Ws + kk * BN + 4 * (f % (BN / 4))) = make_float4(t[0], t[1], t[2], t[3]);
-                    }
-                } else {
-                    const int nl = f % BN, k4 = 4 * (f / BN), n = n0 + nl;
-                    const float *src = Bm + (size_t)min(n, Nout - 1) * ldb;
-                    if (bvec) {
-                        const float4 v = *reinterpret_cast<const float4 *>(src + min(k4, B.rows - 4));
-                        t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
-                    } else {
-    #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int kp = min(k4 + e, B.rows - 1);
-                            int col = kp;
-                            if (B.perm_D >= 0) col = kp < B.perm_D ? kp + 3 : kp - B.perm_D;
-                            t[e] = src[col];
-                        }
-                    }
-    #pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] *= (n < Nout && k4 + e < B.rows) ? 1.f : 0.f;
-                    if constexpr (SWZ) {
-                        *reinterpret_cast<float4 *>(Ws + nl * KD + (k4 ^ a_swz(nl))) = make_float4(t[0], t[1], t[2], t[3]);
-                    } else {
-    #pragma unroll
-                        for (int e = 0; e < 4; ++e) Ws[(k4 + e) * BN + nl] = t[e];
-                    }
-                }
-            }
-        }
-    }
-
-    // ---- per-channel constants of this thread's column group: registers for the whole kernel ----
+    // ---- per-channel constants of this thread's column group: registers for the whole kernel.  Their loads go out FIRST (the table
+    // was written by the previous launch: a cold ~1.5 us round trip), then the weight panel's, then the first tile's: one wait
+    // covers the three instead of three round trips in a row ----
     float4 c_g = make_float4(0.f, 0.f, 0.f, 0.f), c_mu = c_g, c_is = c_g, c_c1 = c_g, c_c2 = c_g, c_sc = c_g, c_sh = c_g;
     if constexpr (G4 > 0 && (AMODE == A_DZ || AMODE == A_DZ_POOL)) {
         const float *c = A.cst + kq;
@@ -691,25 +574,10 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
         c_is = *reinterpret_cast<const float4 *>(c + 2 * A.C);
         c_c1 = *reinterpret_cast<const float4 *>(c + 3 * A.C);
         c_c2 = *reinterpret_cast<const float4 *>(c + 4 * A.C);
-        // dz = g (dy - c1 - (z - mu) istd c2) as two FMAs per element: g dy + (a z + b), a = -g istd c2, b = -g c1 - a mu
-        // (c_is keeps a, c_c1 keeps b from here on; six dependent VALU per element otherwise, and VALU time is MFMA time)
-        c_is = make_float4(-c_g.x * c_is.x * c_c2.x, -c_g.y * c_is.y * c_c2.y, -c_g.z * c_is.z * c_c2.z, -c_g.w * c_is.w * c_c2.w);
-        c_c1 = make_float4(-c_g.x * c_c1.x - c_is.x * c_mu.x, -c_g.y * c_c1.y - c_is.y * c_mu.y, -c_g.z * c_c1.z - c_is.z * c_mu.z,
-                           -c_g.w * c_c1.w - c_is.w * c_mu.w);
     } else if constexpr (G4 > 0 && AMODE == A_BNRELU) {
         c_sc = *reinterpret_cast<const float4 *>(A.scale + kq);
         c_sh = *reinterpret_cast<const float4 *>(A.shift + kq);
     }
-
-    double s1[NT], s2[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) s1[i] = s2[i] = 0.0;
-
-    f32x16 dwacc[DT];  // FDW: this wave's (32 x 32) tiles of dW, accumulated over every row tile of the worker
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dwacc[t][r] = 0.f;
 
     const int tiles = (M + BM - 1) / BM;
     const bool pool_fast = (AMODE == A_DZ_POOL) && A.K == 32;  // tiles start on neighbour-group boundaries (BM % 32 == 0)
@@ -756,13 +624,174 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
         if constexpr (HAS_TAIL) rt = ws_fetch_tail<AMODE>(A, m0 + min(tid, BM - 1), M);
     };
     int tile = worker;
-    if (tile < tiles) fetch(tile * BM);
+    bool fetched = false;
+    // ---- weights: staged once, [k][n] ----
+    {
+        const float *__restrict__ Bm = B.b;
+        const int ldb = B.ldb;
+        const bool bvec = (ldb & 3) == 0 && ((uintptr_t)Bm & 15) == 0 && B.perm_D < 0;
+        // two passes: every 16-byte group of the panel this thread owns is REQUESTED first (all loads in flight together: one
+        // L2 / HBM round trip for the whole panel instead of one per group of a rolled loop), then masked and written to LDS
+        auto wload = [&](int f, float (&t)[4]) {
+            if (!B.trans && SWZ) {
+                // row-major panel -> [n][k ^ f(n)] image: lane = column (four dword loads of consecutive rows, each 256 B per
+                // wave), then ONE conflict-free ds_write_b128 per group.  (The first version read 16 bytes along n and wrote
+                // four transposed ds_write_b32 that met 8-way bank conflicts: 5.8 us of a 54 us launch went into this panel.)
+                const int nl = f % BN, k4 = 4 * (f / BN), n = min(n0 + nl, Nout - 1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = Bm[(size_t)min(k4 + e, B.rows - 1) * ldb + n];
+            } else if (!B.trans) {
+                const int kk = f / (BN / 4), n = n0 + 4 * (f % (BN / 4));
+                const float *src = Bm + (size_t)min(kk, B.rows - 1) * ldb;
+                if (bvec) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src + min(n, Nout - 4));
+                    t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = src[min(n + e, Nout - 1)];
+                }
+            } else {
+                // swizzled image: consecutive lanes take consecutive 16-byte groups of ONE weight row (coalesced 1 KB per wave, and
+                // the ds_write_b128 of a row land in distinct slots); the [k][n] image keeps lane = column
+                const int nl = SWZ ? f / (KD / 4) : f % BN, k4 = SWZ ? 4 * (f % (KD / 4)) : 4 * (f / BN), n = n0 + nl;
+                const float *src = Bm + (size_t)min(n, Nout - 1) * ldb;
+                if (bvec) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src + min(k4, B.rows - 4));
+                    t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kp = min(k4 + e, B.rows - 1);
+                        int col = kp;
+                        if (B.perm_D >= 0) col = kp < B.perm_D ? kp + 3 : kp - B.perm_D;
+                        t[e] = src[col];
+                    }
+                }
+            }
+        };
+        auto wstore = [&](int f, float (&t)[4]) {
+            if (!B.trans && SWZ) {
+                const int nl = f % BN, k4 = 4 * (f / BN);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] *= (n0 + nl < Nout && k4 + e < B.rows) ? 1.f : 0.f;
+                *reinterpret_cast<float4 *>(Ws + nl * KD + (k4 ^ a_swz(nl))) = make_float4(t[0], t[1], t[2], t[3]);
+            } else if (!B.trans) {
+                const int kk = f / (BN / 4), n = n0 + 4 * (f % (BN / 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] *= (kk < B.rows && n + e < Nout) ? 1.f : 0.f;
+                if constexpr (SWZ) {  // transposed image: four scalar stores (once per workgroup)
+                    const int nl = 4 * (f % (BN / 4));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Ws[(nl + e) * KD + (kk ^ a_swz(nl + e))] = t[e];
+                } else {
+                    *reinterpret_cast<float4 *>(Ws + kk * BN + 4 * (f % (BN / 4))) = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            } else {
+                // swizzled image: consecutive lanes take consecutive 16-byte groups of ONE weight row (coalesced 1 KB per wave, and
+                // the ds_write_b128 of a row land in distinct slots); the [k][n] image keeps lane = column
+                const int nl = SWZ ? f / (KD / 4) : f % BN, k4 = SWZ ? 4 * (f % (KD / 4)) : 4 * (f / BN), n = n0 + nl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] *= (n < Nout && k4 + e < B.rows) ? 1.f : 0.f;
+                if constexpr (SWZ) {
+                    *reinterpret_cast<float4 *>(Ws + nl * KD + (k4 ^ a_swz(nl))) = make_float4(t[0], t[1], t[2], t[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Ws[(k4 + e) * BN + nl] = t[e];
+                }
+            }
+        };
+        // (row-major panels of the backward kernels; for the [n][k] weights of the forward kernels the same two passes were worth
+        // 0.2 us per launch and cost the backward instantiations as much -- A/B on one box, tools/ab_trace.sh -- so they keep the loop)
+        constexpr int NWF = (KD * (BN / 4)) / 256;
+        bool staged = false;
+        if constexpr (SWZ && (KD * (BN / 4)) % 256 == 0 && NWF >= 4 && NWF <= 16) {
+            if (!B.trans) {
+                staged = true;
+                float tw[NWF][4];
+#pragma unroll
+                for (int j = 0; j < NWF; ++j) wload(tid + 256 * j, tw[j]);
+                if (tile < tiles) fetch(tile * BM);   // behind the panel in the queue: its HBM round trip overlaps the LDS writes
+                fetched = true;
+#pragma unroll
+                for (int j = 0; j < NWF; ++j) wstore(tid + 256 * j, tw[j]);
+            }
+        }
+        if (!staged) {
+            for (int f = tid; f < KD * (BN / 4); f += 256) {
+                float t[4];
+                if (!B.trans) {
+                    const int kk = f / (BN / 4), n = n0 + 4 * (f % (BN / 4));
+                    const float *src = Bm + (size_t)min(kk, B.rows - 1) * ldb;
+                    if (bvec) {
+                        const float4 v = *reinterpret_cast<const float4 *>(src + min(n, Nout - 4));
+                        t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+                    } else {
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = src[min(n + e, Nout - 1)];
+                    }
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] *= (kk < B.rows && n + e < Nout) ? 1.f : 0.f;
+                    if constexpr (SWZ) {  // transposed image: four scalar stores (once per workgroup)
+                        const int nl = 4 * (f % (BN / 4));
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) Ws[(nl + e) * KD + (kk ^ a_swz(nl + e))] = t[e];
+                    } else {
+                        *reinterpret_cast<float4 *>(Ws + kk * BN + 4 * (f % (BN / 4))) = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                } else {
+                    // swizzled image: consecutive lanes take consecutive 16-byte groups of ONE weight row (coalesced 1 KB per wave, and
+                // the ds_write_b128 of a row land in distinct slots); the [k][n] image keeps lane = column
+                const int nl = SWZ ? f / (KD / 4) : f % BN, k4 = SWZ ? 4 * (f % (KD / 4)) : 4 * (f / BN), n = n0 + nl;
+                    const float *src = Bm + (size_t)min(n, Nout - 1) * ldb;
+                    if (bvec) {
+                        const float4 v = *reinterpret_cast<const float4 *>(src + min(k4, B.rows - 4));
+                        t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+                    } else {
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int kp = min(k4 + e, B.rows - 1);
+                            int col = kp;
+                            if (B.perm_D >= 0) col = kp < B.perm_D ? kp + 3 : kp - B.perm_D;
+                            t[e] = src[col];
+                        }
+                    }
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] *= (n < Nout && k4 + e < B.rows) ? 1.f : 0.f;
+                    if constexpr (SWZ) {
+                        *reinterpret_cast<float4 *>(Ws + nl * KD + (k4 ^ a_swz(nl))) = make_float4(t[0], t[1], t[2], t[3]);
+                    } else {
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) Ws[(k4 + e) * BN + nl] = t[e];
+                    }
+                }
+            }
+        }
+    }
+
+    PNPP_STAMP(11)  // prologue: weight panel in LDS
+    if (!fetched && tile < tiles) fetch(tile * BM);
+    if constexpr (G4 > 0 && (AMODE == A_DZ || AMODE == A_DZ_POOL)) {
+        // dz = g (dy - c1 - (z - mu) istd c2) as two FMAs per element: g dy + (a z + b), a = -g istd c2, b = -g c1 - a mu
+        // (c_is keeps a, c_c1 keeps b from here on; six dependent VALU per element otherwise, and VALU time is MFMA time)
+        c_is = make_float4(-c_g.x * c_is.x * c_c2.x, -c_g.y * c_is.y * c_c2.y, -c_g.z * c_is.z * c_c2.z, -c_g.w * c_is.w * c_c2.w);
+        c_c1 = make_float4(-c_g.x * c_c1.x - c_is.x * c_mu.x, -c_g.y * c_c1.y - c_is.y * c_mu.y, -c_g.z * c_c1.z - c_is.z * c_mu.z,
+                           -c_g.w * c_c1.w - c_is.w * c_mu.w);
+    }
+
+    PNPP_STAMP(12)  // prologue: per-channel constants
+    double s1[NT], s2[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) s1[i] = s2[i] = 0.0;
+
+    f32x16 dwacc[DT];  // FDW: this wave's (32 x 32) tiles of dW, accumulated over every row tile of the worker
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dwacc[t][r] = 0.f;
+
     // see the K loop: with `inter` the operand loads of the NEXT tile are issued between this tile's MFMAs
     const bool inter = DENSE_A && SWZ && EMODE == E_MASK_STATS && !(FDW && NT > 1) && full_rows && n0 + BN <= Nout;
-#ifdef PNPP_STAMPS
-    const bool st_on = FDW && AMODE == A_DZ_POOL && blockIdx.x == 8 && wave == 0 && g_stamp_kd == KD;
-    unsigned long long st_last = __builtin_amdgcn_s_memtime();
-#endif
+    PNPP_STAMP(8)   // prologue, rest: first tile's loads complete
     for (; tile < tiles; tile += nworkers) {
         const int m0 = tile * BM;
         PNPP_STAMP(0)
@@ -1219,7 +1248,19 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
         }
     }
 
+    PNPP_STAMP(9)       // (nothing: closes the last tile)
     if constexpr (FDW) {  // one partial dW per worker: dwslab[worker][c][n0 + k]
+      if (n0 + BN <= Nout) {  // (uniform row pointer) + (one lane offset): scalar address arithmetic, no bounds test per element
+        float *wb = E.dwslab + (size_t)worker * KD * E.dw_ld + n0;
+        const unsigned lo = (unsigned)(4 * lh) * (unsigned)E.dw_ld + (unsigned)l31;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const int tile_id = wave + 4 * t, ct = tile_id / (BN / 32), kt = tile_id % (BN / 32);
+            float *tb = wb + (size_t)(ct * 32) * E.dw_ld + kt * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tb[(size_t)((r & 3) + 8 * (r >> 2)) * E.dw_ld + lo] = dwacc[t][r];
+        }
+      } else
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
             const int tile_id = wave + 4 * t, ct = tile_id / (BN / 32), kt = tile_id % (BN / 32);
@@ -1253,6 +1294,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
             if (n0 + cl < Nout) E.slab[((size_t)worker * 2 + which) * Nout + n0 + cl] = t;
         }
     }
+    PNPP_STAMP(10)      // tail: dW partial, statistics slab (stores complete)
 }
 
 template <int KD, int BM, int BN, int WM, int WN, int AM, int EM, bool FDW>

@@ -34,3 +34,4 @@ for kd in (256, 128):
     for i, n in enumerate(names):
         print(f"  {n:45s} {buf[i]/tiles:10.0f} ticks/tile  {100*buf[i]/max(tot,1):5.1f}%")
     print("  total per tile", tot / tiles)
+    print(f"  per launch: weight panel {buf[11] / N:.0f}, constants {buf[12] / N:.0f}, first tile's loads {buf[8] / N:.0f} ticks, tail (dW partial + statistics, stores complete) {buf[10] / N:.0f} ticks")
