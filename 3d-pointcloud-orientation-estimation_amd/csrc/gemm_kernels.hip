@@ -547,7 +547,10 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 #ifdef PNPP_STAMPS
-    const bool st_on = FDW && AMODE == A_DZ_POOL && blockIdx.x == 8 && wave == 0 && g_stamp_kd == KD;
+    // selector: KD for the fused pooled backward kernels, 1000 + KD for the forward kernels (BN+ReLU operand, statistics)
+    const bool st_on = blockIdx.x == 8 && wave == 0 &&
+                       ((FDW && AMODE == A_DZ_POOL && g_stamp_kd == KD) ||
+                        (!FDW && AMODE == A_BNRELU && EMODE == E_STORE_STATS && g_stamp_kd == 1000 + KD));
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
     // XCD-aware tile map (speed only, never correctness): blocks b and b + 8 share an XCD and with it an L2, so the ncol

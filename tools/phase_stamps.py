@@ -22,7 +22,7 @@ def step():
 for _ in range(3): step()
 torch.cuda.synchronize()
 names = ["loop top (prev tile tail) + gdm issue", "barrier 1", "stage (wait loads + transform + ds_write)", "barrier 2", "fetch issue + zp issue + dA MFMA loop", "epilogue", "barrier 3", "dW loop"]
-for kd in (256, 128):
+for kd in (256, 128, 1128, 1064):
     lib.pnpp_debug_stamps(None, kd)
     N = 20
     for _ in range(N): step()
