@@ -1430,6 +1430,22 @@ __device__ __forceinline__ void gemm_smallm_body(const AOperand &A, const BOpera
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    // E_BN_APPLY: the epilogue's per-column parameters and the dropout stream id are requested now -- behind the K loop and its
+    // barriers each of them would be one more cold round trip (~1.5 us) on the tail of a 10 us launch
+    float p_g = 1.f, p_b = 0.f, p_bias = 0.f, p_rm = 0.f, p_rv = 0.f;
+    unsigned long long p_sid = 0ull;
+    if constexpr (EMODE == E_BN_APPLY) {
+        const BnTail &T = E.bn;
+        if (tid < 32 && n0 + tid < Nout) {
+            const int c = n0 + tid;
+            if (T.gamma) p_g = T.gamma[c];
+            if (T.beta) p_b = T.beta[c];
+            if (T.bias) p_bias = T.bias[c];
+            if (T.rm) p_rm = T.rm[c], p_rv = T.rv[c];
+        }
+        if (T.mask_out) p_sid = T.rng_counter[0];
+    }
+
     RawA na[4];
     float4 nw[4];        // BT: weight rows, same (row, 4k) mapping as the A chunk
     float nb[KC / 2];    // !BT: weights already in operand layout
@@ -1545,7 +1561,7 @@ __device__ __forceinline__ void gemm_smallm_body(const AOperand &A, const BOpera
             double var = s2 / count - mu * mu;
             if (var < 0.0) var = 0.0;
             const double is = 1.0 / sqrt(var + (double)T.eps);
-            const double g = T.gamma ? (double)T.gamma[c] : 1.0, bt = T.beta ? (double)T.beta[c] : 0.0;
+            const double g = (double)p_g, bt = (double)p_b;
             const float sc = (float)(g * is), sh = (float)(bt - mu * g * is);
             T.mean[c] = (float)mu;
             T.istd[c] = (float)is;
@@ -1554,10 +1570,10 @@ __device__ __forceinline__ void gemm_smallm_body(const AOperand &A, const BOpera
             cs[tid] = sc;
             cs[32 + tid] = sh;
             if (T.rm) {
-                const double bmean = mu + (T.bias ? (double)T.bias[c] : 0.0);  // the linear bias was folded out of z
+                const double bmean = mu + (double)p_bias;  // the linear bias was folded out of z
                 const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                T.rm[c] = (float)((1.0 - (double)T.momentum) * (double)T.rm[c] + (double)T.momentum * bmean);
-                T.rv[c] = (float)((1.0 - (double)T.momentum) * (double)T.rv[c] + (double)T.momentum * unbiased);
+                T.rm[c] = (float)((1.0 - (double)T.momentum) * (double)p_rm + (double)T.momentum * bmean);
+                T.rv[c] = (float)((1.0 - (double)T.momentum) * (double)p_rv + (double)T.momentum * unbiased);
             }
         }
         if (T.nbt && bx == 0 && tid == 0) *T.nbt += 1;
@@ -1570,7 +1586,7 @@ __device__ __forceinline__ void gemm_smallm_body(const AOperand &A, const BOpera
                 if (T.relu) y = fmaxf(y, 0.f);
                 if (T.mask) y = T.mask[(size_t)row * E.ldc + col] ? y * T.drop_scale : 0.f;
                 if (T.mask_out) {  // draw the keep bit of this element: one Philox word per element (a few hundred per workgroup)
-                    const unsigned long long sid = T.rng_counter[0];
+                    const unsigned long long sid = p_sid;
                     const unsigned idx = (unsigned)(row * E.ldc + col);
                     unsigned c0 = idx, c1 = 0x44524f50u /* "DROP" */, c2 = (unsigned)sid, c3 = (unsigned)(sid >> 32);
                     unsigned k0 = (unsigned)T.rng_seed, k1 = (unsigned)(T.rng_seed >> 32);
@@ -2604,6 +2620,19 @@ bn_finalize_fwd_kernel(const double *__restrict__ slab, int nslab, int C, double
     __shared__ double red[32][2][FIN_COLS];
     if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;  // num_batches_tracked (nn.BatchNorm forward)
     const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
+    // The per-channel parameters are requested BEFORE the slab reduction: at a kernel boundary every line is a cold miss of this
+    // XCD's L2 (~1.5 us), the reduction ends in a barrier the compiler will not move loads across, and a launch this short is
+    // the sum of its dependent round trips -- one instead of two.
+    const bool owner = threadIdx.x < FIN_COLS && c < C;
+    float p_bias = 0.f, p_g = 1.f, p_b = 0.f, p_rm = 0.f, p_rv = 0.f;
+    if (owner || (!training && c < C)) {
+        if (bias) p_bias = bias[c];
+        if (rm) p_rm = rm[c], p_rv = rv[c];
+    }
+    if (owner) {
+        if (gamma) p_g = gamma[c];
+        if (beta) p_b = beta[c];
+    }
     double mu, var;
     if (training) {
         double s1, s2;
@@ -2614,21 +2643,21 @@ bn_finalize_fwd_kernel(const double *__restrict__ slab, int nslab, int C, double
     } else {
         if (c >= C) return;
         // eval: normalise z + bias with the running statistics  ->  "mean" of the bias-free z is rm - bias
-        mu = (double)rm[c] - (bias ? (double)bias[c] : 0.0);
-        var = (double)rv[c];
+        mu = (double)p_rm - (double)p_bias;
+        var = (double)p_rv;
     }
-    if (threadIdx.x >= FIN_COLS || c >= C) return;
+    if (!owner) return;
     const double is = 1.0 / sqrt(var + (double)eps);
-    const double g = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
+    const double g = (double)p_g, bt = (double)p_b;
     mean[c] = (float)mu;
     istd[c] = (float)is;
     scale[c] = (float)(g * is);
     shift[c] = (float)(bt - mu * g * is);
     if (training && rm) {
-        const double bmean = mu + (bias ? (double)bias[c] : 0.0);  // the conv/linear bias was folded out of z
+        const double bmean = mu + (double)p_bias;  // the conv/linear bias was folded out of z
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * bmean);
-        rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * unbiased);
+        rm[c] = (float)((1.0 - (double)momentum) * (double)p_rm + (double)momentum * bmean);
+        rv[c] = (float)((1.0 - (double)momentum) * (double)p_rv + (double)momentum * unbiased);
     }
 }
 
@@ -2645,21 +2674,27 @@ __device__ __forceinline__ void bn_finalize_bwd_block(const BnFinalizeBwdArgs &F
     __shared__ double red[32][2][FIN_COLS];
     const int C = F.C;
     const int c = bid * FIN_COLS + (threadIdx.x % FIN_COLS);
+    // (parameters first, reduction second: see bn_finalize_fwd_kernel)
+    const bool owner = threadIdx.x < FIN_COLS && c < C;
+    float g = 1.f, p_is = 0.f, p_mu = 0.f;
+    if (owner) {
+        if (F.gamma) g = F.gamma[c];
+        p_is = F.istd[c], p_mu = F.mean[c];
+    }
     double s1, s2;
     slab_column_sums(F.slab, F.nslab, C, c, s1, s2, red);
-    if (threadIdx.x >= FIN_COLS || c >= C) return;
-    const float g = F.gamma ? F.gamma[c] : 1.f;
+    if (!owner) return;
     float *cst = F.cst;
-    cst[c] = g * F.istd[c];
-    cst[C + c] = F.mean[c];
-    cst[2 * C + c] = F.istd[c];
+    cst[c] = g * p_is;
+    cst[C + c] = p_mu;
+    cst[2 * C + c] = p_is;
     cst[3 * C + c] = F.training ? (float)(s1 / F.count) : 0.f;
     cst[4 * C + c] = F.training ? (float)(s2 / F.count) : 0.f;
     if (F.dgamma) F.dgamma[c] = (float)s2;
     if (F.dbeta) F.dbeta[c] = (float)s1;
     // a bias in front of a train-mode BatchNorm has exactly zero gradient; with running
     // statistics the layer is affine and d(bias) = sum_m dz = g * sum_m dy
-    if (F.dbias) F.dbias[c] = F.training ? 0.f : (float)((double)cst[c] * s1);
+    if (F.dbias) F.dbias[c] = F.training ? 0.f : (float)((double)(g * p_is) * s1);
 }
 
 // Small-M levels materialise dZ once per layer (dz_materialize_kernel).  The BatchNorm-backward constants it needs are

@@ -125,6 +125,63 @@ __global__ void __launch_bounds__(256) vm_head_kl_kernel(const float *__restrict
     }
 }
 
+// The float64 work of a sample is four independent chains of library calls and Chebyshev series (~5 us one after the other on one
+// lane).  They cannot be spread over the lanes of a wave (different code per lane = divergence = serial again), so each of a
+// 256-thread workgroup's four WAVES evaluates one chain for up to 64 samples, the pieces meet in LDS, and wave 0 combines them with
+// the same float64 operations in the same order as kl_single_eval: bitwise the same result, a third of the latency.
+struct KlPieces {
+    double th[64], cd[64], sd[64], i0e_kp[64], logi0_kp[64], i1e_kp[64], logi0_kq[64], sig[64];
+    float mu[64], kap[64];
+};
+// Called by ALL 256 threads (two barriers inside) for sample i = chunk base + lane; returns true on the wave-0 lane that owns a valid
+// sample, with mu, kappa (float32, as the reference's head returns them), the loss value and d loss_mean / d o.
+__device__ __forceinline__ bool vm_head_kl_chunk(KlPieces &S, int i, int B, double o0, double o1, const float *__restrict__ mu_gt,
+                                                 const float *__restrict__ kappa_gt, double inv_b, float &mu_f, float &kap_f, float &vf,
+                                                 float &g0, float &g1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (i < B) {
+        if (wave == 0) {
+            const double th = tanh(o0);
+            const float m = (float)(th * kPi);                               // torch.tanh(out[:,0]) * np.pi
+            const double d = (double)m - (double)mu_gt[i];
+            S.th[lane] = th, S.cd[lane] = cos(d), S.sd[lane] = sin(d), S.mu[lane] = m;
+        } else if (wave == 1) {
+            const float k = (float)(o1 > 20.0 ? o1 : log1p(exp(o1)));        // F.softplus (beta 1, threshold 20)
+            const double kp = (double)k, e0 = i0e(kp);
+            S.i0e_kp[lane] = e0, S.logi0_kp[lane] = kp + log(e0), S.kap[lane] = k;
+        } else if (wave == 2) {
+            const float k = (float)(o1 > 20.0 ? o1 : log1p(exp(o1)));
+            S.i1e_kp[lane] = i1e((double)k);
+        } else {
+            S.logi0_kq[lane] = log_i0((double)kappa_gt[i]);
+            S.sig[lane] = o1 > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-o1));
+        }
+    }
+    __syncthreads();
+    bool mine = false;
+    if (wave == 0 && i < B) {
+        mine = true;
+        const double th = S.th[lane], cd = S.cd[lane], sd = S.sd[lane];
+        mu_f = S.mu[lane], kap_f = S.kap[lane];
+        const double kp = (double)kap_f, kq = (double)kappa_gt[i];
+        const double A = S.i1e_kp[lane] / S.i0e_kp[lane];          // bessel_ratio(kp)
+        const double basev = S.logi0_kq[lane] - S.logi0_kp[lane];  // log I0(kq) - log I0(kp)
+        double v, a, b;
+        if (kp <= 1e-6) {
+            v = basev, a = 0.0, b = -A;
+        } else {
+            v = basev + kp * A - kq * A * cd;
+            a = kq * A * sd;
+            b = bessel_ratio_prime(kp, A) * (kp - kq * cd);
+        }
+        vf = (float)v;
+        g0 = (float)(a * kPi * (1.0 - th * th) * inv_b);
+        g1 = (float)(b * S.sig[lane] * inv_b);
+    }
+    __syncthreads();
+    return mine;
+}
+
 // head + KL + batch mean + gradient of the mean in ONE single-workgroup launch: the training step's loss tail
 // (head, KL, mean, and the three elementwise kernels of their autograd backward) collapses into this and one multiply.
 // The mean is a fixed-order fp64 tree, so it is deterministic.
@@ -133,24 +190,22 @@ __global__ void __launch_bounds__(256) vm_head_kl_mean_kernel(const float *__res
                                                               float *__restrict__ kappa, float *__restrict__ loss_vec,
                                                               float *__restrict__ loss_mean, float *__restrict__ d_o_mean) {
     __shared__ double red[256];
+    __shared__ KlPieces S;
+    const int lane = threadIdx.x & 63;
     const double inv_b = 1.0 / (double)B;
     double part = 0.0;
-    for (int i = threadIdx.x; i < B; i += 256) {
-        const double o0 = (double)o[2 * i], o1 = (double)o[2 * i + 1];
-        const double th = tanh(o0);
-        const float mu_f = (float)(th * kPi);
-        const double sp = o1 > 20.0 ? o1 : log1p(exp(o1));
-        const float kap_f = (float)sp;
-        if (mu) mu[i] = mu_f;
-        if (kappa) kappa[i] = kap_f;
-        double v, a, b;
-        kl_single_eval((double)mu_f, (double)kap_f, (double)mu_gt[i], (double)kappa_gt[i], v, a, b);
-        const float vf = (float)v;
-        if (loss_vec) loss_vec[i] = vf;
-        part += (double)vf;
-        const double sig = o1 > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-o1));
-        d_o_mean[2 * i] = (float)(a * kPi * (1.0 - th * th) * inv_b);
-        d_o_mean[2 * i + 1] = (float)(b * sig * inv_b);
+    for (int base = 0; base < B; base += 64) {
+        const int i = base + lane;
+        const double o0 = i < B ? (double)o[2 * i] : 0.0, o1 = i < B ? (double)o[2 * i + 1] : 0.0;
+        float mu_f, kap_f, vf, g0, g1;
+        if (vm_head_kl_chunk(S, i, B, o0, o1, mu_gt, kappa_gt, inv_b, mu_f, kap_f, vf, g0, g1)) {
+            if (mu) mu[i] = mu_f;
+            if (kappa) kappa[i] = kap_f;
+            if (loss_vec) loss_vec[i] = vf;
+            part += (double)vf;
+            d_o_mean[2 * i] = g0;
+            d_o_mean[2 * i + 1] = g1;
+        }
     }
     red[threadIdx.x] = part;
     __syncthreads();
@@ -195,21 +250,19 @@ vm_fc_head_kl_step_kernel(const float *__restrict__ x, const float *__restrict__
         if (part8 == 0 && i < B) o[2 * i] = a0 + bias[0], o[2 * i + 1] = a1 + bias[1];
     }
     __syncthreads();
-    // 2. head + KL + mean; d loss / d o overwrites o
+    // 2. head + KL + mean (the four float64 chains on the four waves: vm_head_kl_chunk); d loss / d o overwrites o
+    __shared__ KlPieces S;
     const double inv_b = 1.0 / (double)B;
     double part = 0.0;
-    for (int i = tid; i < B; i += 256) {
-        const double o0 = (double)o[2 * i], o1 = (double)o[2 * i + 1];
-        const double th = tanh(o0);
-        const float mu_f = (float)(th * kPi);
-        const double sp = o1 > 20.0 ? o1 : log1p(exp(o1));
-        const float kap_f = (float)sp;
-        double v, a, b;
-        kl_single_eval((double)mu_f, (double)kap_f, (double)mu_gt[i], (double)kappa_gt[i], v, a, b);
-        part += (double)(float)v;
-        const double sig = o1 > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-o1));
-        o[2 * i] = (float)(a * kPi * (1.0 - th * th) * inv_b);
-        o[2 * i + 1] = (float)(b * sig * inv_b);
+    for (int base = 0; base < B; base += 64) {
+        const int i = base + (tid & 63);
+        const double o0 = i < B ? (double)o[2 * i] : 0.0, o1 = i < B ? (double)o[2 * i + 1] : 0.0;
+        float mu_f, kap_f, vf, g0, g1;
+        if (vm_head_kl_chunk(S, i, B, o0, o1, mu_gt, kappa_gt, inv_b, mu_f, kap_f, vf, g0, g1)) {
+            part += (double)vf;
+            o[2 * i] = g0;      // (every wave read o[2i], o[2i+1] before the first barrier of the chunk)
+            o[2 * i + 1] = g1;
+        }
     }
     red[tid] = part;
     __syncthreads();
