@@ -49,9 +49,14 @@ struct Carver {
 };
 
 // ---- opt-in per-launch HIP-event timing (pnpp_profile_enable / pnpp_profile_report) ----
+// A ProfScope names the launch that follows it.  While profiling is on, every kernel launch of the library goes out through
+// hipExtLaunchKernelGGL with a start and a stop event ATTACHED TO ITS DISPATCH PACKET: the pair brackets the kernel's own begin and
+// end on the device -- what rocprofv3's kernel trace reports -- and not the few microseconds of dispatch latency that a
+// hipEventRecord in front of the launch would add to it.
 bool prof_on();
 void prof_begin(hipStream_t st, const char *fmt, ...);
 void prof_end(hipStream_t st);
+bool prof_take_events(hipEvent_t *a, hipEvent_t *b);   // events for the next launch of the open scope (false: not profiling)
 struct ProfScope {
     hipStream_t st;
     bool on;
@@ -63,6 +68,26 @@ struct ProfScope {
         if (on) prof_end(st);
     }
 };
+
+}  // namespace pnpp
+#if defined(__HIPCC__)
+#include <hip/hip_ext.h>
+namespace pnpp {
+template <typename... KArgs, typename... Args>
+inline void launch_kernel(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args &&...args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+    hipEvent_t ea, eb;
+    if (prof_on() && prof_take_events(&ea, &eb))
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, st, ea, eb, 0u, static_cast<KArgs>(args)...);
+    else
+        kernel<<<grid, block, lds, st>>>(static_cast<KArgs>(args)...);
+}
+}  // namespace pnpp
+// every launch site of the library is written hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...)
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) ::pnpp::launch_kernel(kernel, grid, block, lds, stream, __VA_ARGS__)
+#endif
+namespace pnpp {
 
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kMaxStatBlocks = 512;  // upper bound on partial-statistic slabs per GEMM

@@ -32,22 +32,32 @@ struct ProfRec {
 };
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
+static std::string g_open_tag;   // tag of the open ProfScope; every launch inside it gets its own record
+static bool g_scope_open = false;
 
 bool prof_on() { return g_prof; }
-void prof_begin(hipStream_t st, const char *fmt, ...) {
+void prof_begin(hipStream_t, const char *fmt, ...) {
     char buf[160];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    ProfRec r;
-    r.tag = buf;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-    (void)hipEventRecord(r.a, st);
-    g_recs.push_back(r);
+    g_open_tag = buf;
+    g_scope_open = true;
 }
-void prof_end(hipStream_t st) {
-    if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().b, st);
+void prof_end(hipStream_t) { g_scope_open = false; }
+bool prof_take_events(hipEvent_t *a, hipEvent_t *b) {
+    if (!g_prof || !g_scope_open) return false;   // a launch outside any scope is not timed
+    ProfRec r;
+    r.tag = g_open_tag;
+    if (hipEventCreate(&r.a) != hipSuccess) return false;
+    if (hipEventCreate(&r.b) != hipSuccess) {
+        (void)hipEventDestroy(r.a);
+        return false;
+    }
+    g_recs.push_back(r);
+    *a = r.a, *b = r.b;
+    return true;
 }
 
 #define PNPP_TRY(expr)                 \
