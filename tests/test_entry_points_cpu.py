@@ -171,7 +171,13 @@ def test_committed_bench_line_follows_the_contract():
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "round1_final_bench.json")))
+    rounds = sorted(f for f in os.listdir(os.path.join(root, "profiles")) if f.startswith("round") and f.endswith("_bench.json"))
+    assert "round1_final_bench.json" in rounds and len(rounds) >= 2        # one committed line per round
+    for name in rounds:
+        _check_bench_line(json.loads(open(os.path.join(root, "profiles", name)).read().strip().splitlines()[-1]))
+
+
+def _check_bench_line(d):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
