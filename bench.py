@@ -42,7 +42,7 @@ FLOPS_PER_CLOUD = 0.8542e9     # 3 x 2 x 142,369,280 MAC, forward + b
 BYTES_PER_CLOUD = 34.6e6       # 5 E + 3 G float32 words + xyz / indices
 
 
-def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=True):
+def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=True, overlap=None):
     """Returns (step, launch_mode, step_without_collective).  zero_grad + forward + loss + backward are replayed from one hipGraph when
     capture succeeds (falls back to eager launches otherwise); the all-reduce and the fused Adam follow eagerly."""
     from pnpp_hip import ops, dist as pdist
@@ -54,7 +54,9 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
         return ops.vm_head_kl_loss_backward(model.features(x), m, k)
 
     graphed, split = None, None
-    if use_graph and world > 1 and collective and os.environ.get("PNPP_NO_OVERLAP") != "1":
+    if overlap is None:
+        overlap = os.environ.get("PNPP_NO_OVERLAP") != "1"
+    if use_graph and world > 1 and collective and overlap:
         # data parallel: the step is captured in two graphs so that the all-reduce of sa3 + head gradients (94 % of the
         # bytes, final a third of the way into the backward pass) runs beside the backward pass of sa2 and sa1
         try:
@@ -385,14 +387,35 @@ def main():
     seen = torch.ones(1, device=dev)
     if world > 1:
         tdist.all_reduce(seen)                             # every rank really is in the job
-    for _ in range(args.warmup):
-        step()
 
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             tdist.barrier()
         torch.cuda.synchronize()
+
+    # Data-parallel schedule, chosen by measurement before the warm-up (never inside the timed region): the two-graph step whose
+    # all-reduce of the sa3 + head gradients runs beside the backward pass of sa2 / sa1, or one graph followed by the whole
+    # all-reduce.  Overlap is not free on this chip: the collective's workgroups need CUs that the persistent GEMM kernels of the
+    # second graph (one or two workgroups per CU, nearly all of the LDS and registers) assume to own, so which one wins depends
+    # on the collective's footprint -- every rank times both (MAX over ranks) and all take the faster.
+    dp_schedule = None
+    if world > 1 and not args.no_graph and os.environ.get("PNPP_NO_OVERLAP") is None and "two hipGraphs" in launch_mode:
+        single, single_mode, single_local = build_step(model, opt, xyz, mu_gt, kappa_gt, world, True, overlap=False)
+        trial = {}
+        for name, fn in (("overlap", step), ("single", single)):
+            for _ in range(5):
+                fn()
+            t_el, _ = timed(fn, 30, fence)
+            t = torch.tensor([t_el], device=dev, dtype=torch.float64)
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+            trial[name] = float(t) / 30 * 1e3
+        dp_schedule = {"overlap_ms": trial["overlap"], "single_ms": trial["single"],
+                       "chosen": "overlap" if trial["overlap"] <= trial["single"] else "single"}
+        if dp_schedule["chosen"] == "single":
+            step, launch_mode, step_local = single, single_mode, single_local
+    for _ in range(args.warmup):
+        step()
 
     el, loss = timed(step, args.steps, fence)
     elapsed = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -449,7 +472,8 @@ def main():
             "config": {"workload": "configs[1]: models/pointnet_pp_vonMises.py single-peak KL, N=1024, batch=32 per GPU, "
                                    "fwd+loss+bwd+allreduce+Adam, random-init weights (seed 42), device-side centre sampling",
                        "per_gpu_batch": B, "global_batch": B * world, "points": N_POINTS,
-                       "parallelism": f"dp{world}" if world > 1 else "single", "launch": launch_mode},
+                       "parallelism": f"dp{world}" if world > 1 else "single", "launch": launch_mode,
+                       **({"dp_schedule": dp_schedule} if dp_schedule else {})},
             "final_loss": final_loss, "n_ranks_seen": int(seen.item()), "allreduce_exposed_us": exposed_us,
             # whole step against both roofs: algorithmic FLOPs / bytes per cloud x clouds/s per GPU
             "mfma_fraction": per_gpu * FLOPS_PER_CLOUD / (MFMA_F32_PEAK_TFLOPS * 1e12),
