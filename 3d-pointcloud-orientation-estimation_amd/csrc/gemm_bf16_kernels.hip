@@ -114,24 +114,24 @@ gemm_wsb_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, c
                 for (int e = 0; e < 4; ++e) t[e] *= (n < Nout && k4 + e < B.rows) ? 1.f : 0.f;
                 *reinterpret_cast<uint2 *>(Wb + nl * PITCH + 16 * ((k4 >> 3) ^ swz(nl)) + 2 * (k4 & 7)) = pk4_bf16(t[0], t[1], t[2], t[3]);
             }
-        } else {  // b is [Kd][Nout]: one 16-byte load of four consecutive output columns of row k, four 2-byte LDS stores
-            const bool bvec = (ldb & 3) == 0 && ((uintptr_t)Bm & 15) == 0;
-            for (int f = tid; f < KD * (BN / 4); f += 256) {
-                const int kk = f / (BN / 4), nl = 4 * (f % (BN / 4)), n = n0 + nl;
-                const float *src = Bm + (size_t)min(kk, B.rows - 1) * ldb;
-                float t[4];
-                if (bvec) {
-                    const float4 v = *reinterpret_cast<const float4 *>(src + min(n, Nout - 4));
-                    t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
-                } else {
+        } else {  // b is [Kd][Nout]: lane = output column -- four coalesced dword loads of consecutive rows k, ONE 8-byte LDS store of
+                  // the packed group; all of a thread's loads are requested before the first is used (the first version read 16
+                  // bytes along n and scattered four 2-byte stores per group from a rolled loop: one L2 round trip per iteration)
+            constexpr int NWF = (KD * (BN / 4)) / 256;
+            float tw[NWF][4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = src[min(n + e, Nout - 1)];
-                }
+            for (int j = 0; j < NWF; ++j) {
+                const int f = tid + 256 * j, nl = f % BN, k4 = 4 * (f / BN), n = min(n0 + nl, Nout - 1);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float w = t[e] * ((kk < B.rows && n + e < Nout) ? 1.f : 0.f);
-                    *reinterpret_cast<__bf16 *>(Wb + (nl + e) * PITCH + 16 * ((kk >> 3) ^ swz(nl + e)) + 2 * (kk & 7)) = (__bf16)w;
-                }
+                for (int e = 0; e < 4; ++e) tw[j][e] = Bm[(size_t)min(k4 + e, B.rows - 1) * ldb + n];
+            }
+#pragma unroll
+            for (int j = 0; j < NWF; ++j) {
+                const int f = tid + 256 * j, nl = f % BN, k4 = 4 * (f / BN);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tw[j][e] *= (n0 + nl < Nout && k4 + e < B.rows) ? 1.f : 0.f;
+                *reinterpret_cast<uint2 *>(Wb + nl * PITCH + 16 * ((k4 >> 3) ^ swz(nl)) + 2 * (k4 & 7)) =
+                    pk4_bf16(tw[j][0], tw[j][1], tw[j][2], tw[j][3]);
             }
         }
     }
