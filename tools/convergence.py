@@ -46,16 +46,19 @@ def main():
     ap.add_argument("--epochs", type=int, default=40)
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"], help="bf16: the opt-in bf16-operand MFMA mode")
     args = ap.parse_args()
     from models.pointnet_pp_8dir import DIRS_8, PointNetPP8Dir
     from models.pointnet_pp_vonMises import PointNetPPVonMises
     from pnpp_hip import ops, sampling, trainer
     import synthetic
     dev = torch.device("cuda", 0)
+    ops.set_matmul_precision(args.precision)
     xyz_tr, mu_tr, f_tr = wedge_clouds(args.clouds, args.points, 1)
     xyz_va, mu_va, f_va = wedge_clouds(1024, args.points, 2)
     out = {"workload": f"tapered-box clouds, N={args.points}, batch {args.batch}, {args.clouds} training / 1024 held-out clouds, "
-                       f"{args.epochs} epochs, Adam lr 1e-3, device-side centre sampling, hipGraph step", "runs": {}}
+                       f"{args.epochs} epochs, Adam lr 1e-3, device-side centre sampling, hipGraph step, matmul precision {args.precision}",
+           "runs": {}}
 
     # --- single-peak von Mises KL (train_single_peak_vonMises_KL.py's loss) ---
     torch.manual_seed(42)
