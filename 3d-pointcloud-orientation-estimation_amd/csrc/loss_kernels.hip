@@ -227,15 +227,19 @@ vm_fc_head_kl_step_kernel(const float *__restrict__ x, const float *__restrict__
     extern __shared__ __attribute__((aligned(16))) float sm[];  // o[B][2] (then d_o in place), xs[B][K] when it fits
     __shared__ double red[256];
     float *o = sm;
-    float *xs = sm + ((2 * B + 3) & ~3);
+    float *ws = sm + ((2 * B + 3) & ~3);         // W (2 x K) in LDS: with x, ONE round trip for everything the kernel reads
+    float *xs = ws + ((2 * K + 3) & ~3);
     const int tid = threadIdx.x;
     const float *xr = x;  // where the features are read from after staging
+    for (int f = tid; f < 2 * K; f += 256) ws[f] = W[f];
+    const float b0 = bias[0], b1 = bias[1];
     if (x_in_lds) {       // one pass of independent 16-byte loads; every later read of x is an LDS read
         const int n4 = (B * K) >> 2;
         for (int f = tid; f < n4; f += 256) reinterpret_cast<float4 *>(xs)[f] = reinterpret_cast<const float4 *>(x)[f];
         xr = xs;
     }
     __syncthreads();
+    const float *Wl = ws;
     // 1. o = x W^T + b: eight lanes per row, each a strided eighth of the features
     const int part8 = tid & 7;
     for (int i = tid >> 3; i < ((B + 31) & ~31); i += 32) {
@@ -243,11 +247,11 @@ vm_fc_head_kl_step_kernel(const float *__restrict__ x, const float *__restrict__
         float a0 = 0.f, a1 = 0.f;
         for (int k = part8; k < K; k += 8) {
             const float xv = xr[(size_t)ic * K + k];
-            a0 = fmaf(xv, W[k], a0), a1 = fmaf(xv, W[K + k], a1);
+            a0 = fmaf(xv, Wl[k], a0), a1 = fmaf(xv, Wl[K + k], a1);
         }
 #pragma unroll
         for (int m = 4; m >= 1; m >>= 1) a0 += __shfl_xor(a0, m), a1 += __shfl_xor(a1, m);
-        if (part8 == 0 && i < B) o[2 * i] = a0 + bias[0], o[2 * i + 1] = a1 + bias[1];
+        if (part8 == 0 && i < B) o[2 * i] = a0 + b0, o[2 * i + 1] = a1 + b1;
     }
     __syncthreads();
     // 2. head + KL + mean (the four float64 chains on the four waves: vm_head_kl_chunk); d loss / d o overwrites o
@@ -273,7 +277,7 @@ vm_fc_head_kl_step_kernel(const float *__restrict__ x, const float *__restrict__
     if (tid == 0) *loss_mean = (float)(red[0] * inv_b);
     // 3. dW = d_o^T x, db = column sums of d_o, dx = d_o W: one thread per feature, rows in order
     for (int k = tid; k < K; k += 256) {
-        const float w0 = W[k], w1 = W[K + k];
+        const float w0 = Wl[k], w1 = Wl[K + k];
         float g0 = 0.f, g1 = 0.f;
 #pragma unroll 8
         for (int i = 0; i < B; ++i) {
@@ -743,7 +747,8 @@ extern "C" int pnpp_vm_fc_head_kl_step(const float *x, const float *w, const flo
     PNPP_REQUIRE(B > 0 && K > 0 && B <= 8192, PNPP_ERR_ARG, "vm_fc_head_kl_step: B must be in 1..8192 and K positive");
     const size_t o_floats = ((size_t)2 * B + 3) & ~(size_t)3;
     const int x_in_lds = ((size_t)B * K <= 12288 && (((size_t)B * K) & 3) == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;  // <= 48 KB
-    const size_t lds = (o_floats + (x_in_lds ? (size_t)B * K : 0)) * sizeof(float);
+    const size_t w_floats = ((size_t)2 * K + 3) & ~(size_t)3;
+    const size_t lds = (o_floats + w_floats + (x_in_lds ? (size_t)B * K : 0)) * sizeof(float);
     hipLaunchKernelGGL(vm_fc_head_kl_step_kernel, dim3(1), dim3(256), lds, as_stream(stream), x, w, b, mu_gt, kappa_gt, B, K, x_in_lds,
                        loss_mean, dw, db, dx);
     PNPP_CHECK_LAUNCH("vm_fc_head_kl_step");

@@ -47,11 +47,17 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
     capture succeeds (falls back to eager launches otherwise); the all-reduce and the fused Adam follow eagerly."""
     from pnpp_hip import ops, dist as pdist
 
-    def loss_fn(x, m, k):   # head + KL + .mean() + the seed of loss.backward() (train_single_peak_vonMises_KL.py:82-84) fused;
-        # PNPP_FUSED_TAIL=1 also folds fc3 and its backward into that launch (one workgroup: measured 0.3 % slower)
-        if os.environ.get("PNPP_FUSED_TAIL") == "1":
-            return ops.vm_fc_head_kl_loss_backward(model.trunk(x), model.fc3, m, k)
-        return ops.vm_head_kl_loss_backward(model.features(x), m, k)
+    fused_tail = os.environ.get("PNPP_FUSED_TAIL", "1") != "0"
+
+    def tail(f, m, k):
+        # fc3 + head + KL + .mean() + the seed of loss.backward() (train_single_peak_vonMises_KL.py:82-84) + fc3's backward in ONE
+        # launch (12.5 us; as three launches -- fc3, head/KL, fc3 backward: 16.1 us, PNPP_FUSED_TAIL=0)
+        if fused_tail:
+            return ops.vm_fc_head_kl_loss_backward(f, model.fc3, m, k)
+        return ops.vm_head_kl_loss_backward(ops.fc_block(f, model.fc3, training=model.training), m, k)
+
+    def loss_fn(x, m, k):
+        return tail(model.trunk(x), m, k)
 
     graphed, split = None, None
     if overlap is None:
@@ -72,7 +78,7 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
                 f = l3.view(l3.size(0), -1)
                 f = ops.fc_block(f, model.fc1, model.bn1, relu=True, training=model.training)
                 f = ops.fc_block(f, model.fc2, model.bn2, relu=True, dropout=model.drop, training=model.training)
-                return ops.vm_head_kl_loss_backward(ops.fc_block(f, model.fc3, training=model.training), mu_gt, kappa_gt)
+                return tail(f, mu_gt, kappa_gt)
 
             tail = opt.offset_of(next(model.sa3.parameters()))
             split = GraphedSplitStep(opt, stage1, stage2, [xyz, mu_gt, kappa_gt], tail, adopt_inputs=True)
