@@ -103,12 +103,13 @@ def _run_bn_head_model(oracle, model_cls, oracle_fwd, loss_hip, loss_ref, B, N, 
     return model, out, loss, res, (g_hip, g64, g32)
 
 
-def test_dir8_config3_full_size(oracle):
-    """configs[3]: models/pointnet_pp_8dir.py:58-85 + train_8dir_KL.py:60-68 at N=2048, 32 clouds per GPU."""
+@pytest.mark.parametrize("B,N", [(32, 2048), (16, 10_000)])
+def test_dir8_config3_full_size(oracle, B, N):
+    """configs[3]: models/pointnet_pp_8dir.py:58-85 + train_8dir_KL.py:60-68 at N=2048, 32 clouds per GPU -- and at the
+    script's own size, 10,000 points and batch 16 (train_8dir_KL.py:22-23)."""
     from models.pointnet_pp_8dir import PointNetPP8Dir, DIRS_8
     from pnpp_hip import ops
     import synthetic
-    B, N = 32, 2048
 
     def prob(fwd):
         return synthetic.dir8_soft_labels(fwd.float(), DIRS_8)
@@ -116,7 +117,7 @@ def test_dir8_config3_full_size(oracle):
     model, logits, loss, res, (g_hip, g64, g32) = _run_bn_head_model(
         oracle, PointNetPP8Dir, oracle.dir8_forward,
         lambda o, m, k, f: ops.soft_ce(o, prob(f).cuda()).mean(),
-        lambda o, m, k, f: oracle.soft_ce(o, prob(f).to(o.dtype)).mean(), B, N, seed_centres=2048)
+        lambda o, m, k, f: oracle.soft_ce(o, prob(f).to(o.dtype)).mean(), B, N, seed_centres=N)
     _, lg64, l64, st = res["f64"]
     _, _, l32, _ = res["f32"]
     d_hip, d_cpu = abs(loss.item() - l64.item()), abs(l32.item() - l64.item())
@@ -186,13 +187,14 @@ def test_vonmises_config1_routed_gradient_and_eval(oracle):
     assert float((kap_e.cpu().double() - kap_r).abs().max()) <= 1e-4 * max(1.0, float(kap_r.abs().max()))
 
 
-def test_mvm_config2_full_batch(oracle):
+@pytest.mark.parametrize("B,N", [(32, 1024), (16, 10_000)])
+def test_mvm_config2_full_batch(oracle, B, N):
     """configs[2]: PointNetPPMvM (models/pointnet_pp_mvM.py:30-127) + match_loss
-    (train_multi_peaks_vonMises_KL.py:54-81) at N=1024, B=32, both dropout masks injected, K_gt in {1,2,4}."""
+    (train_multi_peaks_vonMises_KL.py:54-81) at N=1024, B=32 -- and at the script's own size, 10,000 points and batch 16
+    (train_multi_peaks_vonMises_KL.py:25-26) -- both dropout masks injected, K_gt in {1,2,4}."""
     from models.pointnet_pp_mvM import PointNetPPMvM
     from pnpp_hip import ops
     import synthetic
-    B, N = 32, 1024
     torch.manual_seed(42)
     m = PointNetPPMvM()
     torch.manual_seed(7)
@@ -207,7 +209,7 @@ def test_mvm_config2_full_batch(oracle):
     K = torch.tensor([1, 2, 4])[torch.randint(0, 3, (B,), generator=g)]
     vm_gt = synthetic.multi_peak_gt(fwd, K)
     torch.manual_seed(99)
-    centres = oracle.replay_centres(B)
+    centres = oracle.replay_centres(B, sizes=((N, 128), (128, 32)))
     masks = [(torch.rand(B, w, generator=g) < 0.6).to(torch.uint8) for w in (512, 256)]
 
     ops.sa_tap = []
@@ -229,7 +231,7 @@ def test_mvm_config2_full_batch(oracle):
     oracle.match_loss(*oracle.mvm_forward(xyz, P64r, centres, [t.double() for t in masks], True, None, routing=routing,
                                           diag=diag), vm_gt.double(), K).mean().backward()
     d = abs(loss.item() - lv64.mean().item())
-    print(f"\n[mvM B={B}] loss hip {loss.item():.7f} fp64 {lv64.mean().item():.7f} |d| {d:.2e}")
+    print(f"\n[mvM N={N} B={B}] loss hip {loss.item():.7f} fp64 {lv64.mean().item():.7f} |d| {d:.2e}")
     assert d <= 1e-5 * max(1.0, abs(lv64.mean().item()))
     assert float((lv.detach().cpu().double() - lv64.detach()).abs().max()) <= 1e-4
     assert float((w.detach().cpu().double() - w64.detach()).abs().max()) <= 2e-5
@@ -241,7 +243,7 @@ def test_mvm_config2_full_batch(oracle):
     skip = lambda n: ".convs." in n and n.endswith("bias")
     e = _rel(_flat(dict(m.named_parameters()), skip, names), _flat(P64, skip, names))
     er = _rel(_flat(dict(m.named_parameters()), skip, names), _flat(P64r, skip, names))
-    print(f"[mvM B={B}] flat gradient relL2 vs fp64 {e:.2e} (own routing), {er:.2e} (HIP routing injected, gap "
+    print(f"[mvM N={N} B={B}] flat gradient relL2 vs fp64 {e:.2e} (own routing), {er:.2e} (HIP routing injected, gap "
           f"{max(diag['route_gap']):.2e})")
     assert e <= 1e-2, e      # own routing: arg-max flips (see test_gpu_e2e.py)
     assert max(diag["route_gap"]) <= 2e-6 and er <= 3e-3, (diag, er)
