@@ -7,6 +7,12 @@ The bench's synthetic clouds (a box rotated about +Y) are symmetric u
 modulo 180 degrees and no single-peak predictor can do better than chance on the sign.  The clouds here are the same recipe with
 the box tapered towards its front (a wedge: 0.4 of the width at the front, full width at the back), which makes the yaw observable.
 
+The multi-peak model is not part of this: as the reference writes it (reproduced here), its mu head is zero-initialised, which
+puts every component on the (c, s) = (1, 0) fallback whose gradient is zero (models/pointnet_pp_mvM.py:70-73,104-112), and
+match_loss normalises by the weight of the first K components only (train_multi_peaks_vonMises_KL.py:77-79), so the optimiser
+reaches KL = 0 within an epoch by moving the mixture weight to the unmatched components -- observed with the drop-in, and what
+the reference's own code does on the same inputs.
+
     python tools/convergence.py [--clouds 8192] [--epochs 40] > profiles/<round>_convergence.json
 """
 import argparse
