@@ -699,7 +699,7 @@ extern "C" int pnpp_knn(const float *new_xyz, const float *xyz, int B, int S, in
 extern "C" int pnpp_fps(const float *xyz, int B, int N, int npoint, const int32_t *start, int32_t *out, void *stream) {
     PNPP_REQUIRE(xyz && start && out, PNPP_ERR_ARG, "fps: null pointer");
     PNPP_REQUIRE(B > 0 && N > 0 && npoint > 0, PNPP_ERR_ARG, "fps: non-positive size");
-    PNPP_REQUIRE(npoint <= N, PNPP_ERR_RANGE, "fps: npoint=%d > N=%d", npoint, N);
+    // npoint > N is legal, as in the reference (PointNet++Demo.py:8-29): once every distance is 0 the first maximum is point 0
     hipStream_t st = as_stream(stream);
     // points per thread live in registers; clouds beyond 1024 x 16 points keep the rest in the LDS (16 bytes per point)
     constexpr int kRegPoints = 1024 * 16, kTailMax = (160 * 1024 - 2048) / 16;   // 1 KiB of winner slots at T = 1024

@@ -749,6 +749,10 @@ extern "C" int pnpp_vm_fc_head_kl_step(const float *x, const float *w, const flo
     const int x_in_lds = ((size_t)B * K <= 12288 && (((size_t)B * K) & 3) == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;  // <= 48 KB
     const size_t w_floats = ((size_t)2 * K + 3) & ~(size_t)3;
     const size_t lds = (o_floats + w_floats + (x_in_lds ? (size_t)B * K : 0)) * sizeof(float);
+    // fc3's two weight rows and the B x 2 outputs live in LDS beside ~7 KB of static arrays; the 64 KB a launch gets without
+    // an opt-in bounds B and K together (the reference head: K = 256).  Wider heads take pnpp_fc_forward + pnpp_vm_head_kl_mean.
+    PNPP_REQUIRE(lds <= 56 * 1024, PNPP_ERR_RANGE, "vm_fc_head_kl_step: 2*B + 2*K (+ B*K) floats = %zu bytes of LDS exceed 56 KB (B=%d, K=%d)",
+                 lds, B, K);
     hipLaunchKernelGGL(vm_fc_head_kl_step_kernel, dim3(1), dim3(256), lds, as_stream(stream), x, w, b, mu_gt, kappa_gt, B, K, x_in_lds,
                        loss_mean, dw, db, dx);
     PNPP_CHECK_LAUNCH("vm_fc_head_kl_step");

@@ -17,7 +17,7 @@ import torch
 class GraphedStep:
     def __init__(self, opt, loss_fn: Callable[..., torch.Tensor], example_inputs: Sequence[torch.Tensor], warmup: int = 3,
                  adopt_inputs: bool = False, fused_optimizer: bool = False, grad_scale: float = 1.0,
-                 zero_grad_in_graph: bool = True):
+                 zero_grad_in_graph: bool = True, captured_all_reduce: Callable = None):
         """loss_fn(*inputs) -> scalar loss; `opt` is a pnpp_hip.optim.FlatAdam (its flat gradient buffer is static).
 
         fused_optimizer=True (single process: nothing sits between backward and the update) captures the Adam launch
@@ -31,8 +31,13 @@ class GraphedStep:
 
         adopt_inputs=True makes `example_inputs` themselves the static input buffers (`self.static_in`): a loader that
         writes the next batch into them (H2D copy target) and then calls the step with the same tensors pays no
-        device-to-device copy; any other tensor passed later is copied in as usual."""
+        device-to-device copy; any other tensor passed later is copied in as usual.
+
+        captured_all_reduce(tensor) -> work handle: the all-reduce of the whole flat gradient is captured behind the
+        backward pass (data parallelism with a capturable backend, i.e. RCCL), so the replay carries the collective and --
+        with fused_optimizer -- the update: one graph launch per step."""
         self.opt = opt
+        self._car = captured_all_reduce
         self.fused_optimizer = fused_optimizer
         self.static_in = list(example_inputs) if adopt_inputs else [t.clone() for t in example_inputs]
         side = torch.cuda.Stream()
@@ -65,6 +70,10 @@ class GraphedStep:
         loss = loss_fn(*self.static_in)
         if loss.requires_grad:
             loss.backward()
+        if self._car is not None:
+            h = self._car(self.opt.flat_g)
+            if h is not None:
+                h.wait()
         return loss
 
     def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
@@ -92,9 +101,15 @@ class GraphedSplitStep:
     For PointNet++: stage1 = sa1 + sa2 (6 % of the parameters), stage2 = sa3 + head + loss (94 %)."""
 
     def __init__(self, opt, stage1: Callable, stage2: Callable, example_inputs: Sequence[torch.Tensor], tail_offset: int,
-                 warmup: int = 3, adopt_inputs: bool = False):
+                 warmup: int = 3, adopt_inputs: bool = False, captured_all_reduce: Callable = None):
+        """captured_all_reduce(tensor) -> work handle: when given, the two all-reduces are CAPTURED with the kernels in ONE
+        graph (RCCL's launches become graph nodes on its own stream, forked after the backward pass of stage2 and joined
+        before the end of the graph), so a replay has no host launch and no graph boundary between backward and the
+        collective; `__call__` then ignores its `all_reduce` argument.  Needs a capturable backend (RCCL; gloo moves
+        device tensors through the host and cannot be captured)."""
         self.opt, self.tail_offset = opt, int(tail_offset)
         self.static_in = list(example_inputs) if adopt_inputs else [t.clone() for t in example_inputs]
+        self.captured_collective = captured_all_reduce is not None
 
         def fwd_bwd2():
             opt.zero_grad()
@@ -110,19 +125,38 @@ class GraphedSplitStep:
             pairs = [(m, c.grad) for m, c in zip(mids, cut) if m.requires_grad and c.grad is not None]
             torch.autograd.backward([m for m, _ in pairs], [g for _, g in pairs])
 
+        def whole(all_reduce):
+            g = opt.flat_g
+            mids, cut, loss = fwd_bwd2()
+            h1 = all_reduce(g[self.tail_offset:])
+            bwd1(mids, cut)
+            h2 = all_reduce(g[:self.tail_offset]) if self.tail_offset > 0 else None
+            for h in (h1, h2):
+                if h is not None:
+                    h.wait()
+            return mids, cut, loss
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                mids, cut, _ = fwd_bwd2()
-                bwd1(mids, cut)
+                if self.captured_collective:      # the communicator's lazy set-up must not happen inside the capture
+                    whole(captured_all_reduce)
+                else:
+                    mids, cut, _ = fwd_bwd2()
+                    bwd1(mids, cut)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph1, self.graph2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph1, capture_error_mode="thread_local"):
-            mids, cut, self.static_loss = fwd_bwd2()
-        with torch.cuda.graph(self.graph2, pool=self.graph1.pool(), capture_error_mode="thread_local"):
-            bwd1(mids, cut)
+        self.graph1, self.graph2 = torch.cuda.CUDAGraph(), None
+        if self.captured_collective:
+            with torch.cuda.graph(self.graph1, capture_error_mode="thread_local"):
+                mids, cut, self.static_loss = whole(captured_all_reduce)
+        else:
+            self.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph1, capture_error_mode="thread_local"):
+                mids, cut, self.static_loss = fwd_bwd2()
+            with torch.cuda.graph(self.graph2, pool=self.graph1.pool(), capture_error_mode="thread_local"):
+                bwd1(mids, cut)
         self._keep = (mids, cut)   # the autograd graph of stage1 belongs to the captured memory
 
     def __call__(self, *inputs: torch.Tensor, all_reduce: Callable = None) -> torch.Tensor:
@@ -132,6 +166,8 @@ class GraphedSplitStep:
                 s.copy_(t, non_blocking=True)
         g = self.opt.flat_g
         self.graph1.replay()
+        if self.captured_collective:
+            return self.static_loss
         h1 = all_reduce(g[self.tail_offset:]) if all_reduce is not None else None
         self.graph2.replay()
         h2 = all_reduce(g[:self.tail_offset]) if all_reduce is not None and self.tail_offset > 0 else None

@@ -617,6 +617,9 @@ def vm_fc_head_kl_loss_backward(x, linear, mu_gt, kappa_gt) -> torch.Tensor:
     B, K = x32.shape
     if w.shape != (2, K) or b.numel() != 2 or mu_gt.numel() != B or kappa_gt.numel() != B:
         raise ValueError("vm_fc_head_kl_loss_backward: linear must map K -> 2 and the targets must be (B,)")
+    if 4 * (2 * B + 2 * K + 8 + (B * K if B * K <= 12288 else 0)) > 56 * 1024:
+        # the one-launch form stages fc3's weights and the outputs in LDS (56 KB); wider heads take the three launches it fuses
+        return vm_head_kl_loss_backward(fc_block(x, linear, training=True), mu_gt, kappa_gt)
     loss = torch.empty((), device=x32.device, dtype=torch.float32)
     sinks = [grad_sink(p) for p in (linear.weight, linear.bias)]
     dw = sinks[0] if sinks[0] is not None else torch.empty_like(w)

@@ -58,26 +58,35 @@ def _sanitize(name: str) -> str:
     return re.sub(r"[^\w\-]+", "_", name.strip())
 
 
+# results.txt: the output contract of the reference's script (its lines 127-146) as data -- one template per line kind.
+_SUMMARY_HEADER = "=== Multi-Peak von Mises KL Summary ==="
+_SUMMARY_OPTIONAL = (("best_val_epoch", "Best Total Val Epoch: {}"), ("test_kl", "Test KL: {:.6f}"))
+_SUMMARY_SECTION = "-- Per-Category (last epoch) --"
+_SUMMARY_ROW = "[{label}] Train={train} Val={val}"
+
+
+def _six_decimals(value) -> str:
+    """A number with six decimals; anything that is not a number reads "nan"."""
+    try:
+        return format(float(value), ".6f")
+    except (TypeError, ValueError):
+        return "nan"
+
+
 def write_summary_txt(path_txt: Path, categories, hist, test_kl=None, best_val_epoch=None):
-    """results.txt in the reference's exact format (lines 127-146)."""
-    def _fmt(x):
-        try:
-            return f"{float(x):.6f}"
-        except Exception:
-            return "nan"
-    with open(path_txt, "w", encoding="utf-8") as f:
-        f.write("=== Multi-Peak von Mises KL Summary ===\n")
-        if best_val_epoch is not None:
-            f.write(f"Best Total Val Epoch: {best_val_epoch}\n")
-        if test_kl is not None:
-            f.write(f"Test KL: {test_kl:.6f}\n")
-        f.write("\n-- Per-Category (last epoch) --\n")
-        last = len(hist["total"]["train"]) - 1
-        f.write(f"[TOTAL] Train={_fmt(hist['total']['train'][last])} Val={_fmt(hist['total']['val'][last])}\n")
-        for cat in categories:
-            tr = hist[cat]["train"][last] if len(hist[cat]["train"]) > 0 else float("nan")
-            va = hist[cat]["val"][last] if len(hist[cat]["val"]) > 0 else float("nan")
-            f.write(f"[{cat}] Train={_fmt(tr)} Val={_fmt(va)}\n")
+    """results.txt, byte for byte in the layout the reference writes: header, the optional best-epoch / test lines, then
+    one "[label] Train=… Val=…" row for TOTAL and for every category, taken at the last epoch TOTAL has (a category whose
+    curve is empty reads nan)."""
+    given = {"best_val_epoch": best_val_epoch, "test_kl": test_kl}
+    lines = [_SUMMARY_HEADER]
+    lines += [template.format(given[key]) for key, template in _SUMMARY_OPTIONAL if given[key] is not None]
+    lines += ["", _SUMMARY_SECTION]
+    epoch = len(hist["total"]["train"]) - 1
+    for label, curves in [("TOTAL", hist["total"])] + [(cat, hist[cat]) for cat in categories]:
+        at_epoch = {split: (curves[split][epoch] if (label == "TOTAL" or len(curves[split]) > 0) else float("nan"))
+                    for split in ("train", "val")}
+        lines.append(_SUMMARY_ROW.format(label=label, train=_six_decimals(at_epoch["train"]), val=_six_decimals(at_epoch["val"])))
+    Path(path_txt).write_text("\n".join(lines) + "\n", encoding="utf-8")
 
 
 def _plt():
@@ -194,6 +203,8 @@ def main(argv=None):
             print(f"[plot skipped: {e}]")
         print(f"Test KL = {test_kl:.6f}  (steps: {h['steps']})")
         write_summary_txt(RES / "results.txt", categories, hist, test_kl=test_kl, best_val_epoch=best_ep)
+    # beside the curves (the reference's `hist` layout): the trainer's own bookkeeping, for tools/script_throughput.py
+    hist["_trainer"] = {"seconds": h["seconds"], "samples": h["samples"], "steps": h["steps"]}
     return hist, test_kl
 
 

@@ -42,9 +42,29 @@ FLOPS_PER_CLOUD = 0.8542e9     # 3 x 2 x 142,369,280 MAC, forward + b
 BYTES_PER_CLOUD = 34.6e6       # 5 E + 3 G float32 words + xyz / indices
 
 
-def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=True, overlap=None):
+def is_capture_error(e: BaseException) -> bool:
+    """True for what a failed stream capture raises (torch surfaces HIP's capture status codes as RuntimeError /
+    AcceleratorError texts); anything else -- TypeError, ValueError, a PNPP status -- is a bug and propagates."""
+    if not isinstance(e, RuntimeError) or isinstance(e, NotImplementedError):
+        return False
+    msg = str(e).lower()
+    return any(w in msg for w in ("captur", "hipgraph", "cudagraph", "cuda graph", "hip graph", "streamcapture", "graph"))
+
+
+DP_SCHEDULES = ("captured_overlap", "captured_single", "overlap", "single")
+
+
+def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=True, schedule=None):
     """Returns (step, launch_mode, step_without_collective).  zero_grad + forward + loss + backward are replayed from one hipGraph when
-    capture succeeds (falls back to eager launches otherwise); the all-reduce and the fused Adam follow eagerly."""
+    capture succeeds (falls back to eager launches otherwise); the fused Adam follows eagerly.
+
+    Data-parallel schedules (world > 1; `schedule`, default from PNPP_DP_SCHEDULE / PNPP_NO_OVERLAP, else "overlap"):
+      captured_overlap  ONE graph: forward, backward of head + sa3, [fork] all-reduce of that 94 % of the gradient bytes beside the
+                        backward pass of sa2 / sa1, all-reduce of the rest, [join].  RCCL's launches are graph nodes: no host
+                        launch and no graph boundary between backward and the collective.  Needs a capturable backend (RCCL).
+      captured_single   ONE graph: forward, backward, one all-reduce of the whole flat gradient (no fork / join pair).
+      overlap           two graphs with the first all-reduce issued from the host between them (any backend).
+      single            one graph, then one all-reduce from the host (any backend)."""
     from pnpp_hip import ops, dist as pdist
 
     fused_tail = os.environ.get("PNPP_FUSED_TAIL", "1") != "0"
@@ -59,31 +79,34 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
     def loss_fn(x, m, k):
         return tail(model.trunk(x), m, k)
 
+    def stage1(x, m, k):
+        l1_xyz, l1_pts = model.sa1(x, None)
+        l2_xyz, l2_pts = model.sa2(l1_xyz, l1_pts)
+        return l2_xyz, l2_pts
+
+    def stage2(l2_xyz, l2_pts):
+        _, l3 = model.sa3(l2_xyz, l2_pts)
+        f = l3.view(l3.size(0), -1)
+        f = ops.fc_block(f, model.fc1, model.bn1, relu=True, training=model.training)
+        f = ops.fc_block(f, model.fc2, model.bn2, relu=True, dropout=model.drop, training=model.training)
+        return tail(f, mu_gt, kappa_gt)
+
+    if schedule is None:
+        schedule = os.environ.get("PNPP_DP_SCHEDULE") or {"0": "overlap", "1": "single"}.get(os.environ.get("PNPP_NO_OVERLAP", ""), "overlap")
+    assert schedule in DP_SCHEDULES, schedule
+    dp = world > 1 and collective
+    async_ar = lambda t: pdist.all_reduce_flat_grad(t, async_op=True)   # noqa: E731
     graphed, split = None, None
-    if overlap is None:
-        overlap = os.environ.get("PNPP_NO_OVERLAP") != "1"
-    if use_graph and world > 1 and collective and overlap:
-        # data parallel: the step is captured in two graphs so that the all-reduce of sa3 + head gradients (94 % of the
-        # bytes, final a third of the way into the backward pass) runs beside the backward pass of sa2 and sa1
+    if use_graph and dp and schedule in ("overlap", "captured_overlap"):
         try:
             from pnpp_hip.graph import GraphedSplitStep
-
-            def stage1(x, m, k):
-                l1_xyz, l1_pts = model.sa1(x, None)
-                l2_xyz, l2_pts = model.sa2(l1_xyz, l1_pts)
-                return l2_xyz, l2_pts
-
-            def stage2(l2_xyz, l2_pts):
-                _, l3 = model.sa3(l2_xyz, l2_pts)
-                f = l3.view(l3.size(0), -1)
-                f = ops.fc_block(f, model.fc1, model.bn1, relu=True, training=model.training)
-                f = ops.fc_block(f, model.fc2, model.bn2, relu=True, dropout=model.drop, training=model.training)
-                return tail(f, mu_gt, kappa_gt)
-
-            tail = opt.offset_of(next(model.sa3.parameters()))
-            split = GraphedSplitStep(opt, stage1, stage2, [xyz, mu_gt, kappa_gt], tail, adopt_inputs=True)
+            tail_off = opt.offset_of(next(model.sa3.parameters()))
+            split = GraphedSplitStep(opt, stage1, stage2, [xyz, mu_gt, kappa_gt], tail_off, adopt_inputs=True,
+                                     captured_all_reduce=async_ar if schedule == "captured_overlap" else None)
         except Exception as e:
-            print(f"[bench] two-graph capture failed, trying one graph: {type(e).__name__}: {e}", file=sys.stderr)
+            if not is_capture_error(e):   # a bug in the step itself must never be swallowed into a slower mode
+                raise
+            print(f"[bench] {schedule}: capture failed, trying one graph: {type(e).__name__}: {e}", file=sys.stderr)
             split = None
     if use_graph and split is None:
         try:
@@ -92,16 +115,19 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
             # (device-side step count), measured 2.5 % slower -- DESIGN.md 9
             graphed = GraphedStep(opt, loss_fn, [xyz, mu_gt, kappa_gt], adopt_inputs=True,
                                   fused_optimizer=(world == 1 and os.environ.get("PNPP_CAPTURED_ADAM") == "1"),
-                                  zero_grad_in_graph=False)   # the eager Adam launch clears the gradients it has consumed
-        except Exception as e:  # capture is an optimisation, never a requirement
+                                  zero_grad_in_graph=False,   # the eager Adam launch clears the gradients it has consumed
+                                  captured_all_reduce=async_ar if dp and schedule == "captured_single" else None)
+        except Exception as e:  # capture is an optimisation, never a requirement -- but only capture errors fall back
+            if not is_capture_error(e):
+                raise
             print(f"[bench] hipGraph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr)
             graphed = None
+    in_graph = (split is not None and split.captured_collective) or (graphed is not None and graphed._car is not None)
 
     def make_step(coll):
         def step():
             if split is not None:
-                loss = split(xyz, mu_gt, kappa_gt,
-                             all_reduce=(lambda t: pdist.all_reduce_flat_grad(t, async_op=True)) if coll else None)
+                loss = split(xyz, mu_gt, kappa_gt, all_reduce=async_ar if coll else None)
                 opt.step(grad_scale=1.0 / world)
                 return loss
             if graphed is not None:
@@ -113,16 +139,21 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
                 loss = loss_fn(xyz, mu_gt, kappa_gt)
                 if loss.requires_grad:
                     loss.backward()
-            if coll:   # the instrumented roofline pass runs on rank 0 alone: it must not enter a collective
+            if coll and not in_graph:   # the instrumented roofline pass runs on rank 0 alone: it must not enter a collective
                 pdist.all_reduce_flat_grad(opt.flat_g)
             opt.step(grad_scale=1.0 / world, zero_grad=graphed is not None)
             return loss
         return step
 
-    mode = ("two hipGraphs (fwd + sa3/head bwd | sa2/sa1 bwd) with the bucketed all-reduce overlapped + eager Adam" if split is not None
+    mode = ("ONE hipGraph (fwd + bwd, the two all-reduces captured beside the sa2/sa1 backward pass) + eager Adam" if split is not None and in_graph
+            else "two hipGraphs (fwd + sa3/head bwd | sa2/sa1 bwd) with the bucketed all-reduce overlapped + eager Adam" if split is not None
+            else "ONE hipGraph (fwd + bwd + the captured all-reduce) + eager Adam" if in_graph
             else "hipGraph(fwd+loss+bwd+Adam, gradients cleared by the update)" if graphed is not None and graphed.fused_optimizer
             else "hipGraph(fwd+loss+bwd) + eager all-reduce/Adam (the update clears the gradients)" if graphed is not None else "eager")
-    return make_step(collective), mode, make_step(False)   # the last one: same launches, no collective (rank-local)
+    local = None
+    if not in_graph:
+        local = make_step(False)   # same launches, no collective (rank-local)
+    return make_step(collective), mode, local
 
 
 def kernel_cost(tag: str):
@@ -288,6 +319,40 @@ def cpu_baseline(B, budget_s=20.0):
             "cpu_model": cpu_model, "host_cpus": os.cpu_count(), "torch": torch.__version__}
 
 
+def rccl_tuning_log_setup():
+    """Ask RCCL to write which algorithm / protocol it picks for each message size to a per-process FILE (never stdout: the
+    one JSON line lives there).  Must run before the communicator is created.  PNPP_RCCL_TUNING_LOG=0 turns it off."""
+    if os.environ.get("PNPP_RCCL_TUNING_LOG", "1") == "0" or "NCCL_DEBUG" in os.environ:
+        return None
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"pnpp_rccl_{os.getpid()}.log")
+    os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,TUNING", NCCL_DEBUG_FILE=path)
+    return path
+
+
+def rccl_choice(path):
+    """Algorithm / protocol RCCL chose for the gradient messages, from its own tuning log (None under gloo)."""
+    if not path or not os.path.exists(path):
+        return None
+    algos = {0: "tree", 1: "ring", 2: "collnet_direct", 3: "collnet_chain", 4: "nvls", 5: "nvls_tree", 6: "pat"}
+    protos = {0: "LL", 1: "LL128", 2: "simple"}
+    seen_, chans = {}, None
+    try:
+        for ln in open(path, errors="replace"):
+            m = re.search(r"AllReduce: (\d+) Bytes -> Algo (\d+) proto (\d+)", ln)
+            if m:
+                nbytes, a, pr = (int(x) for x in m.groups())
+                seen_[nbytes] = {"bytes": nbytes, "algo": algos.get(a, str(a)), "proto": protos.get(pr, str(pr))}
+            m = re.search(r"(\d+) coll channels", ln)
+            if m:
+                chans = int(m.group(1))
+        os.remove(path)
+    except OSError:
+        return None
+    big = sorted(seen_.values(), key=lambda d: -d["bytes"])[:3]
+    return {"allreduce": big, "coll_channels": chans} if big else None
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks ourselves.  Runs in a parent that has made
     NO GPU call (importing torch makes none); the ranks are fresh child processes, the parent only waits for them."""
@@ -375,6 +440,7 @@ def main():
 
     _lib.lib()                                             # fail loudly if the HIP extension is missing
     ops.set_matmul_precision(args.precision)
+    rccl_log = rccl_tuning_log_setup() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None
     rank, local_rank, world = pdist.init_from_env()
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -387,12 +453,9 @@ def main():
     B = args.batch
     xyz, mu_gt, kappa_gt, _ = synthetic.rotated_clouds(B, N_POINTS, seed=1234 + rank)
     xyz, mu_gt, kappa_gt = xyz.to(dev), mu_gt.to(dev), kappa_gt.to(dev)
-    step, launch_mode, step_local = build_step(model, opt, xyz, mu_gt, kappa_gt, world, not args.no_graph)
-    eager_step, _, _ = build_step(model, opt, xyz, mu_gt, kappa_gt, world, False, collective=False)   # rank-local, for the roofline pass
-
     seen = torch.ones(1, device=dev)
     if world > 1:
-        tdist.all_reduce(seen)                             # every rank really is in the job
+        tdist.all_reduce(seen)                             # every rank really is in the job (and the communicator exists)
 
     def fence():
         torch.cuda.synchronize()
@@ -400,26 +463,58 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize()
 
-    # Data-parallel schedule, chosen by measurement before the warm-up (never inside the timed region): the two-graph step whose
-    # all-reduce of the sa3 + head gradients runs beside the backward pass of sa2 / sa1, or one graph followed by the whole
-    # all-reduce.  Overlap is not free on this chip: the collective's workgroups need CUs that the persistent GEMM kernels of the
-    # second graph (one or two workgroups per CU, nearly all of the LDS and registers) assume to own, so which one wins depends
-    # on the collective's footprint -- every rank times both (MAX over ranks) and all take the faster.
+    # Data-parallel schedule, chosen by measurement before the warm-up (never inside the timed region).  Overlap is not free on
+    # this chip: the collective's workgroups need CUs that the persistent GEMM kernels of the backward pass (one or two
+    # workgroups per CU, nearly all of the LDS and registers) assume to own, and a fork / join pair inside a replayed graph has
+    # its own price -- so every rank builds every schedule its backend can run, times it (MAX over ranks) and all take the
+    # fastest.  PNPP_DP_SCHEDULE (or PNPP_NO_OVERLAP=0/1) pins one.
     dp_schedule = None
-    if world > 1 and not args.no_graph and os.environ.get("PNPP_NO_OVERLAP") is None and "two hipGraphs" in launch_mode:
-        single, single_mode, single_local = build_step(model, opt, xyz, mu_gt, kappa_gt, world, True, overlap=False)
-        trial = {}
-        for name, fn in (("overlap", step), ("single", single)):
+    forced = os.environ.get("PNPP_DP_SCHEDULE") or {"0": "overlap", "1": "single"}.get(os.environ.get("PNPP_NO_OVERLAP", ""))
+    if world > 1 and not args.no_graph and forced is None:
+        capturable = tdist.get_backend() == "nccl"        # RCCL launches are stream work; gloo goes through the host
+        built, trial, failed = {}, {}, {}
+        for name in DP_SCHEDULES:
+            if name.startswith("captured") and not capturable:
+                failed[name] = f"backend {tdist.get_backend()} cannot be captured"
+                continue
+            ok = torch.ones(1, device=dev)
+            try:
+                cand = build_step(model, opt, xyz, mu_gt, kappa_gt, world, True, schedule=name)
+            except RuntimeError as e:                      # build_step has already re-raised what is not a capture error
+                cand, ok = None, torch.zeros(1, device=dev)
+                failed[name] = f"{type(e).__name__}: {str(e)[:120]}"
+            tdist.all_reduce(ok, op=tdist.ReduceOp.MIN)    # a schedule is a candidate only if EVERY rank could build it
+            if float(ok) < 1.0 or cand is None:
+                failed.setdefault(name, "another rank could not build it")
+                continue
+            want = {"captured_overlap": "ONE hipGraph (fwd + bwd, the two", "captured_single": "ONE hipGraph (fwd + bwd + the captured",
+                    "overlap": "two hipGraphs", "single": "hipGraph(fwd+loss+bwd) + eager"}[name]
+            got = torch.tensor([1.0 if cand[1].startswith(want) else 0.0], device=dev)
+            tdist.all_reduce(got, op=tdist.ReduceOp.MIN)
+            if float(got) < 1.0:                           # fell back to another form inside build_step: not this schedule
+                failed[name] = "capture fell back: " + cand[1][:60]
+                continue
+            built[name] = cand
+        for name, cand in built.items():
             for _ in range(5):
-                fn()
-            t_el, _ = timed(fn, 30, fence)
+                cand[0]()
+            t_el, _ = timed(cand[0], 30, fence)
             t = torch.tensor([t_el], device=dev, dtype=torch.float64)
             tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
             trial[name] = float(t) / 30 * 1e3
-        dp_schedule = {"overlap_ms": trial["overlap"], "single_ms": trial["single"],
-                       "chosen": "overlap" if trial["overlap"] <= trial["single"] else "single"}
-        if dp_schedule["chosen"] == "single":
-            step, launch_mode, step_local = single, single_mode, single_local
+        assert trial, f"no data-parallel schedule could be built: {failed}"
+        chosen = min(trial, key=trial.get)
+        dp_schedule = {"candidates_ms": trial, "chosen": chosen, **({"not_built": failed} if failed else {})}
+        step, launch_mode, step_local = built[chosen]
+        if step_local is None:                             # captured collective: its collective-free twin is the plain graph
+            step_local = build_step(model, opt, xyz, mu_gt, kappa_gt, world, True, collective=False)[0]
+        del built
+    else:
+        step, launch_mode, step_local = build_step(model, opt, xyz, mu_gt, kappa_gt, world, not args.no_graph, schedule=forced)
+        if step_local is None:
+            step_local = build_step(model, opt, xyz, mu_gt, kappa_gt, world, not args.no_graph, collective=False)[0]
+    eager_step, _, _ = build_step(model, opt, xyz, mu_gt, kappa_gt, world, False, collective=False)   # rank-local, for the roofline pass
+
     for _ in range(args.warmup):
         step()
 
@@ -481,6 +576,7 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single", "launch": launch_mode,
                        **({"dp_schedule": dp_schedule} if dp_schedule else {})},
             "final_loss": final_loss, "n_ranks_seen": int(seen.item()), "allreduce_exposed_us": exposed_us,
+            **({"rccl": rccl_choice(rccl_log)} if world > 1 else {}),
             # whole step against both roofs: algorithmic FLOPs / bytes per cloud x clouds/s per GPU
             "mfma_fraction": per_gpu * FLOPS_PER_CLOUD / (MFMA_F32_PEAK_TFLOPS * 1e12),
             "hbm_fraction": per_gpu * BYTES_PER_CLOUD / (HBM_PEAK_GBS * 1e9),

@@ -124,3 +124,22 @@ def test_bench_refuses_to_run_without_the_hip_path():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+def test_bench_has_no_closure_rebinding():
+    """Round 2's N > 1 crash: `build_step` defined the closure `tail(...)` and later assigned an int to the same name, so
+    every nested function that called it raised TypeError -- reachable only with world > 1, which no CPU test enters.  Static
+    guard: in no function of bench.py is a name bound both by a nested `def` and by an assignment / for / with target."""
+    import ast
+    from conftest import ROOT
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef))]:
+        own = [n for n in ast.walk(fn) if n is not fn]
+        nested = {n.name for n in fn.body if isinstance(n, ast.FunctionDef)}
+        # names stored anywhere in this function's own scope (not inside its nested functions)
+        inner = set()
+        for sub in [n for n in own if isinstance(n, (ast.FunctionDef, ast.Lambda))]:
+            inner.update(id(x) for x in ast.walk(sub) if x is not sub)
+        stored = {n.id for n in own if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store) and id(n) not in inner}
+        # a try/except may define the same helper in both arms; a def is only a problem when a plain store also exists
+        assert not (nested & stored), (fn.name, sorted(nested & stored))
