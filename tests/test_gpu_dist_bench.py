@@ -80,10 +80,10 @@ def stage2(a, b):
     f = ops.fc_block(f, m1.fc2, m1.bn2, relu=True, dropout=m1.drop, training=True)
     return ops.vm_fc_head_kl_loss_backward(f, m1.fc3, mu, kappa)
 tail = o1.offset_of(next(m1.sa3.parameters()))
-snap = sampling.snapshot()
 res = {}
 g = GraphedSplitStep(o1, stage1, stage2, [xyz, mu, kappa], tail, adopt_inputs=True, captured_all_reduce=ar)
 assert g.captured_collective and g.graph2 is None
+snap = sampling.snapshot()      # the device-side counters exist once a forward pass has run
 for p, q in zip(m1.buffers(), m2.buffers()):
     p.copy_(q)
 sampling.restore(snap)
