@@ -97,7 +97,10 @@ fc_bwd_cols_kernel(const float *__restrict__ dy, const float *__restrict__ z, co
                    float drop_scale, int relu, int bn, const float *__restrict__ scale, const float *__restrict__ shift,
                    const float *__restrict__ mean, const float *__restrict__ istd, const float *__restrict__ bias, int M, int N,
                    int training, float *__restrict__ dz, float *__restrict__ dnw, float *__restrict__ dnb,
-                   float *__restrict__ db) {
+                   float *__restrict__ db, int phase, double *__restrict__ glob, double *__restrict__ local) {
+    // phase 0: sums and dz in one pass (every block holds all rows of its columns).  SyncBN cuts it in two around the exchange
+    // of the sums over the ranks: phase 1 writes this rank's sums (+ row count) to `glob` and `local`, phase 2 applies the
+    // summed `glob` (count at glob[2N]) and takes the parameter gradients from `local`.
     __shared__ double red[8][2][32];
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + cl;
@@ -124,8 +127,16 @@ fc_bwd_cols_kernel(const float *__restrict__ dy, const float *__restrict__ z, co
     s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1 += red[i][0][cl], s2 += red[i][1][cl];
+    if (phase == 1) {
+        if (ok && rl == 0) glob[n] = local[n] = s1, glob[N + n] = local[N + n] = s2;
+        if (blockIdx.x == 0 && threadIdx.x == 0) glob[2 * N] = local[2 * N] = (double)M;
+        return;
+    }
     if (!ok) return;
-    const float c1 = (bn && training) ? (float)(s1 / M) : 0.f, c2 = (bn && training) ? (float)(s2 / M) : 0.f;
+    double count = (double)M;
+    if (phase == 2) s1 = glob[n], s2 = glob[N + n], count = glob[2 * N];
+    const float c1 = (bn && training) ? (float)(s1 / count) : 0.f, c2 = (bn && training) ? (float)(s2 / count) : 0.f;
+    if (phase == 2) s1 = local[n], s2 = local[N + n];
     for (int m = rl; m < M; m += 8) {
         const size_t i = (size_t)m * N + n;
         const float zz = z[i];
@@ -342,8 +353,8 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
     if (d->norm == PNPP_NORM_BATCH) PNPP_REQUIRE(a->rm && a->rv, PNPP_ERR_ARG, "fc_forward: running statistics are null");
     const FcSaved sv = fc_saved_layout(d, a->saved);
     const FcScratch sc = fc_scratch_layout(d, a->scratch);
-    PNPP_REQUIRE(!a->mask_out || (d->norm == PNPP_NORM_BATCH && d->training && d->M <= 32), PNPP_ERR_ARG,
-                 "fc_forward: the in-kernel dropout draw exists for the BatchNorm epilogue (training, M <= 32) only");
+    PNPP_REQUIRE(!a->mask_out || (d->norm == PNPP_NORM_BATCH && d->training && d->M <= 32 && !stats_sync_on()), PNPP_ERR_ARG,
+                 "fc_forward: the in-kernel dropout draw exists for the BatchNorm epilogue (training, M <= 32, no statistics exchange) only");
 
     if (fc_is_small(d)) {
         ProfScope ps(st, "fc_small_fwd_kernel M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -370,7 +381,7 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
     if (d->norm == PNPP_NORM_BATCH) {
         int nslab = 0;
         if (d->training) PNPP_REQUIRE(d->M > 1, PNPP_ERR_ARG, "Expected more than 1 value per channel when training");  // torch's message
-        if (d->training && d->M <= 32) {  // the whole batch fits one tile: statistics, affine, ReLU, dropout in the GEMM epilogue
+        if (d->training && d->M <= 32 && !stats_sync_on()) {  // the whole batch fits one tile: statistics, affine, ReLU, dropout in the GEMM epilogue
             E.mode = E_BN_APPLY;
             BnTail &T = E.bn;
             T.bias = a->b, T.gamma = a->nw, T.beta = a->nb;
@@ -394,8 +405,11 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
             E.mode = E_STORE;
             PNPP_TRY(launch_gemm(A, W, d->M, d->N, d->K, E, nullptr, st));
         }
-        PNPP_TRY(launch_bn_finalize_fwd(sc.slab, nslab, d->N, (double)d->M, a->b, a->nw, a->nb, a->rm, a->rv, (long long *)a->nbt, d->momentum, d->eps,
-                                        d->training, sv.mean, sv.istd, sv.scale, sv.shift, st));
+        StatsView V;
+        V.slab = sc.slab, V.nslab = nslab;
+        if (d->training) PNPP_TRY(stats_exchange(sc.slab, nslab, d->N, (double)d->M, st, &V));
+        PNPP_TRY(launch_bn_finalize_fwd(V.slab, V.nslab, d->N, (double)d->M, a->b, a->nw, a->nb, a->rm, a->rv, (long long *)a->nbt, d->momentum, d->eps,
+                                        d->training, sv.mean, sv.istd, sv.scale, sv.shift, st, V.count_dev));
         hipLaunchKernelGGL(fc_apply_cols_kernel, dim3(grid), dim3(256), 0, st, sv.z, sv.scale, sv.shift, a->mask, d->drop_scale,
                            d->relu, d->M, d->N, a->y);
     } else {
@@ -488,9 +502,21 @@ static int fc_backward_impl(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, hi
         PNPP_TRY(launch_slab_reduce(sc.gbuf, chunks, 1, d->N, d->N, -1, a->db, d->N, st));
     } else {
         const int bn = d->norm == PNPP_NORM_BATCH;
-        hipLaunchKernelGGL(fc_bwd_cols_kernel, dim3(cdiv(d->N, 32)), dim3(256), 0, st, a->dy, sv.z, a->mask, d->drop_scale,
-                           d->relu, bn, sv.scale, sv.shift, sv.mean, sv.istd, a->b, d->M, d->N, d->training, sc.dz, a->dnw,
-                           a->dnb, a->db);
+        if (bn && d->training && stats_sync_on()) {   // SyncBN: sums -> exchange over the ranks -> apply
+            hipLaunchKernelGGL(fc_bwd_cols_kernel, dim3(cdiv(d->N, 32)), dim3(256), 0, st, a->dy, sv.z, a->mask, d->drop_scale,
+                               d->relu, bn, sv.scale, sv.shift, sv.mean, sv.istd, a->b, d->M, d->N, d->training, sc.dz, a->dnw,
+                               a->dnb, a->db, 1, stats_buffer_global(), stats_buffer_local());
+            PNPP_CHECK_LAUNCH("fc_backward(sums)");
+            StatsView V;
+            PNPP_TRY(stats_exchange_inplace(d->N, st, &V));
+            hipLaunchKernelGGL(fc_bwd_cols_kernel, dim3(cdiv(d->N, 32)), dim3(256), 0, st, a->dy, sv.z, a->mask, d->drop_scale,
+                               d->relu, bn, sv.scale, sv.shift, sv.mean, sv.istd, a->b, d->M, d->N, d->training, sc.dz, a->dnw,
+                               a->dnb, a->db, 2, stats_buffer_global(), stats_buffer_local());
+        } else {
+            hipLaunchKernelGGL(fc_bwd_cols_kernel, dim3(cdiv(d->N, 32)), dim3(256), 0, st, a->dy, sv.z, a->mask, d->drop_scale,
+                               d->relu, bn, sv.scale, sv.shift, sv.mean, sv.istd, a->b, d->M, d->N, d->training, sc.dz, a->dnw,
+                               a->dnb, a->db, 0, (double *)nullptr, (double *)nullptr);
+        }
     }
     PNPP_CHECK_LAUNCH("fc_backward");
 

@@ -512,6 +512,19 @@ __device__ int g_stamp_kd;
 #else
 #define PNPP_STAMP(i)
 #endif
+// A/B switches of the tile loop (tools/ab_trace.sh builds one library per setting):
+#ifndef PNPP_WS_DENSE_MINK      // smallest K whose full tiles take the clamp-free staging pass and uniform-pointer streams
+#define PNPP_WS_DENSE_MINK 256
+#endif
+#ifndef PNPP_WS_INTER_MINK      // smallest K whose next-tile loads are issued between the MFMAs of the K loop
+#define PNPP_WS_INTER_MINK 256
+#endif
+#ifndef PNPP_WS_DWTABLE_MINK    // smallest K whose fused dW loop reads its operands through a per-lane address table
+#define PNPP_WS_DWTABLE_MINK 256
+#endif
+#ifndef PNPP_WS_POOL_PREFETCH   // pooled-gradient / arg-max entries of the NEXT tile requested before this tile's stores
+#define PNPP_WS_POOL_PREFETCH 1
+#endif
 template <int KD, int BM, int BN, int WM, int WN, int AMODE, int EMODE, bool FDW>
 __global__ void __launch_bounds__(256, (KD >= 256 ? 1 : 2))  // the K=256 panels leave room for one workgroup per CU anyway
 gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, const Epilogue E) {
@@ -591,7 +604,12 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     // multiply-add, clamp and EXEC branch per 16-byte group were a third of the staging pass, and VALU time is MFMA time
     // (measured: -4.6 % on the K = 256 kernels, which run one wave per SIMD; nothing or a small loss on the K <= 128 kernels with
     // two waves per SIMD, which keep the general path)
-    constexpr bool DENSE_A = (AMODE == A_PLAIN || AMODE == A_BNRELU || AMODE == A_DZ || AMODE == A_DZ_POOL) && KD >= 256;
+    // (round 3 A/B, two traces per variant on one box: for K <= 128 the clamp-free pass alone is +1.4 / +2.2 us on the pooled K = 128
+    // and the K = 64 backward launch; together with the dW address table it is -2.4 us on the pooled K = 128 launch and 0 / +0.3
+    // on the others -- so that one instantiation takes both)
+    constexpr bool TUNED_128 = KD == 128 && AMODE == A_DZ_POOL && FDW;
+    constexpr bool DENSE_A = (AMODE == A_PLAIN || AMODE == A_BNRELU || AMODE == A_DZ || AMODE == A_DZ_POOL) &&
+                             (KD >= PNPP_WS_DENSE_MINK || TUNED_128);
     const bool full_rows = DENSE_A && (M % BM) == 0 && (AMODE != A_DZ_POOL || A.K == 32);
     const unsigned offA = (unsigned)r_base * (unsigned)A.lda + (unsigned)kq;
     auto fetch = [&](int m0) {
@@ -625,6 +643,29 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
             }
         }
         if constexpr (HAS_TAIL) rt = ws_fetch_tail<AMODE>(A, m0 + min(tid, BM - 1), M);
+    };
+    // vmcnt counts loads and stores in issue order on gfx9: a wait for a load issued AFTER a tile's 16 output stores is a wait
+    // for those stores' acknowledgements too.  Everything the next staging pass reads is therefore requested before them.
+    float4 gdm[GPT];
+    int4 garg[GPT];
+    auto fetch_pool = [&](int m0) {
+        if constexpr (AMODE == A_DZ_POOL) {
+            if (full_rows) {
+#pragma unroll
+                for (int g = 0; g < GPT; ++g) {
+                    const size_t gi = (size_t)(m0 / 32 + g) * A.lda + kq;
+                    gdm[g] = *reinterpret_cast<const float4 *>(A.a + gi);
+                    garg[g] = *reinterpret_cast<const int4 *>(A.arg + gi);
+                }
+            } else if (pool_fast) {
+#pragma unroll
+                for (int g = 0; g < GPT; ++g) {
+                    const size_t gi = (size_t)min(m0 / 32 + g, (M - 1) / 32) * A.lda + kq;
+                    gdm[g] = *reinterpret_cast<const float4 *>(A.a + gi);
+                    garg[g] = *reinterpret_cast<const int4 *>(A.arg + gi);
+                }
+            }
+        }
     };
     int tile = worker;
     bool fetched = false;
@@ -773,6 +814,9 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
 
     PNPP_STAMP(11)  // prologue: weight panel in LDS
     if (!fetched && tile < tiles) fetch(tile * BM);
+    if constexpr (PNPP_WS_POOL_PREFETCH) {
+        if (tile < tiles) fetch_pool(tile * BM);
+    }
     if constexpr (G4 > 0 && (AMODE == A_DZ || AMODE == A_DZ_POOL)) {
         // dz = g (dy - c1 - (z - mu) istd c2) as two FMAs per element: g dy + (a z + b), a = -g istd c2, b = -g c1 - a mu
         // (c_is keeps a, c_c1 keeps b from here on; six dependent VALU per element otherwise, and VALU time is MFMA time)
@@ -793,31 +837,14 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
         for (int r = 0; r < 16; ++r) dwacc[t][r] = 0.f;
 
     // see the K loop: with `inter` the operand loads of the NEXT tile are issued between this tile's MFMAs
-    const bool inter = DENSE_A && SWZ && EMODE == E_MASK_STATS && !(FDW && NT > 1) && full_rows && n0 + BN <= Nout;
+    const bool inter = DENSE_A && KD >= PNPP_WS_INTER_MINK && SWZ && EMODE == E_MASK_STATS && !(FDW && NT > 1) && full_rows && n0 + BN <= Nout;
     PNPP_STAMP(8)   // prologue, rest: first tile's loads complete
     for (; tile < tiles; tile += nworkers) {
         const int m0 = tile * BM;
         PNPP_STAMP(0)
-        // pooled gradient / arg-max of the tile's neighbour groups at this thread's columns (L2-resident tables)
-        float4 gdm[GPT];
-        int4 garg[GPT];
-        if constexpr (AMODE == A_DZ_POOL) {
-            if (full_rows) {
-#pragma unroll
-                for (int g = 0; g < GPT; ++g) {
-                    const size_t gi = (size_t)(m0 / 32 + g) * A.lda + kq;
-                    gdm[g] = *reinterpret_cast<const float4 *>(A.a + gi);
-                    garg[g] = *reinterpret_cast<const int4 *>(A.arg + gi);
-                }
-            } else if (pool_fast) {
-#pragma unroll
-                for (int g = 0; g < GPT; ++g) {
-                    const size_t gi = (size_t)min(m0 / 32 + g, (M - 1) / 32) * A.lda + kq;
-                    gdm[g] = *reinterpret_cast<const float4 *>(A.a + gi);
-                    garg[g] = *reinterpret_cast<const int4 *>(A.arg + gi);
-                }
-            }
-        }
+        // pooled gradient / arg-max of the tile's neighbour groups at this thread's columns (L2-resident tables): requested one
+        // tile ahead (fetch_pool below), so that no load the staging pass waits for is YOUNGER than the previous tile's stores
+        if constexpr (!PNPP_WS_POOL_PREFETCH) fetch_pool(m0);
         __syncthreads();  // previous tile's operand reads are done (and, first time, the weights are staged)
         PNPP_STAMP(1)
         // two copies of the staging pass, the compile-time flag FULL picking which one runs (full_rows is uniform): the copy for
@@ -896,6 +923,9 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
         // on the previous MFMA, whereas 32 loads issued in front of the loop are ~1k cycles in which the pipe idles
         const bool have_next = tile + nworkers < tiles;
         if (!inter && have_next) fetch((tile + nworkers) * BM);  // next tile's HBM stream flies during the MFMA loop
+        if constexpr (PNPP_WS_POOL_PREFETCH) {
+            if (have_next) fetch_pool((tile + nworkers) * BM);   // (this tile's entries were consumed by the staging pass above)
+        }
 
         // the ReLU-mask operand of the epilogue is fetched now and lands while the MFMA loop runs
         float zp[MT][NT][16];
@@ -1208,7 +1238,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                     for (int t = 0; t < DT; ++t)
                         dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[buf][c][t], db[buf][c], dwacc[t], 0, 0, 0);
             };
-            if constexpr (KD >= 256) {
+            if constexpr (KD >= PNPP_WS_DWTABLE_MINK || TUNED_128) {
                 // one wave per SIMD here, registers to spare: the swizzled operand addresses of the eight F values are a table
                 // built once per tile from this lane's colx, and with t2 unrolled every read of the loop is (table entry) +
                 // (immediate offset) -- no address arithmetic between the MFMAs (it was 45 VALU per 8 MFMAs)
@@ -2616,8 +2646,9 @@ bn_finalize_fwd_kernel(const double *__restrict__ slab, int nslab, int C, double
                        const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ rm,
                        float *__restrict__ rv, long long *__restrict__ nbt, float momentum, float eps, int training,
                        float *__restrict__ mean, float *__restrict__ istd, float *__restrict__ scale,
-                       float *__restrict__ shift) {
+                       float *__restrict__ shift, const double *__restrict__ count_dev) {
     __shared__ double red[32][2][FIN_COLS];
+    if (count_dev) count = *count_dev;   // SyncBN: the row count of ALL ranks, summed with the statistics
     if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;  // num_batches_tracked (nn.BatchNorm forward)
     const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
     // The per-channel parameters are requested BEFORE the slab reduction: at a kernel boundary every line is a cold miss of this
@@ -2668,6 +2699,9 @@ struct BnFinalizeBwdArgs {
     int training;
     const float *gamma, *mean, *istd;
     float *cst, *dgamma, *dbeta, *dbias;
+    // SyncBN: `slab` holds the sums over ALL ranks (one slab), *count_dev their row count; the parameter gradients stay this
+    // rank's own sums (`local`: [2][C]) -- the gradient all-reduce adds the ranks up, as it does for every other parameter
+    const double *count_dev = nullptr, *local = nullptr;
 };
 
 __device__ __forceinline__ void bn_finalize_bwd_block(const BnFinalizeBwdArgs &F, int bid) {
@@ -2684,12 +2718,14 @@ __device__ __forceinline__ void bn_finalize_bwd_block(const BnFinalizeBwdArgs &F
     double s1, s2;
     slab_column_sums(F.slab, F.nslab, C, c, s1, s2, red);
     if (!owner) return;
+    const double count = F.count_dev ? *F.count_dev : F.count;
     float *cst = F.cst;
     cst[c] = g * p_is;
     cst[C + c] = p_mu;
     cst[2 * C + c] = p_is;
-    cst[3 * C + c] = F.training ? (float)(s1 / F.count) : 0.f;
-    cst[4 * C + c] = F.training ? (float)(s2 / F.count) : 0.f;
+    cst[3 * C + c] = F.training ? (float)(s1 / count) : 0.f;
+    cst[4 * C + c] = F.training ? (float)(s2 / count) : 0.f;
+    if (F.local) s1 = F.local[c], s2 = F.local[C + c];
     if (F.dgamma) F.dgamma[c] = (float)s2;
     if (F.dbeta) F.dbeta[c] = (float)s1;
     // a bias in front of a train-mode BatchNorm has exactly zero gradient; with running
@@ -2740,8 +2776,9 @@ __device__ __forceinline__ void dz_fused_block(const BnFinalizeBwdArgs &F, const
             kc[0][cl] = g * F.istd[c];
             kc[1][cl] = F.mean[c];
             kc[2][cl] = F.istd[c];
-            kc[3][cl] = F.training ? (float)(s1 / F.count) : 0.f;
-            kc[4][cl] = F.training ? (float)(s2 / F.count) : 0.f;
+            const double count = F.count_dev ? *F.count_dev : F.count;
+            kc[3][cl] = F.training ? (float)(s1 / count) : 0.f;
+            kc[4][cl] = F.training ? (float)(s2 / count) : 0.f;
         }
         __syncthreads();
     }
@@ -2789,12 +2826,34 @@ __global__ void __launch_bounds__(256) post_gemm_kernel(BnFinalizeBwdArgs F, int
     else slab_reduce_block<EPB>(R, blockIdx.x - nfin - ndz);
 }
 
+// SyncBN: the [nslab][2][C] partials of THIS rank reduced to one [2][C] slab followed by the row count, written twice -- `glob`
+// is summed over the ranks in place by the registered exchange, `local` keeps this rank's own sums for the parameter gradients
+__global__ void __launch_bounds__(256)
+slab_sum_kernel(const double *__restrict__ slab, int nslab, int C, double count, double *__restrict__ glob, double *__restrict__ local) {
+    __shared__ double red[32][2][FIN_COLS];
+    const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
+    double s1, s2;
+    slab_column_sums(slab, nslab, C, c, s1, s2, red);
+    if (threadIdx.x < FIN_COLS && c < C) {
+        glob[c] = s1, glob[C + c] = s2;
+        local[c] = s1, local[C + c] = s2;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) glob[2 * C] = count, local[2 * C] = count;
+}
+
+int launch_slab_sum(const double *slab, int nslab, int C, double count, double *glob, double *local, hipStream_t st) {
+    ProfScope ps(st, "slab_sum_kernel C=%d", C);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, st, slab, nslab, C, count, glob, local);
+    PNPP_CHECK_LAUNCH("slab_sum");
+    return PNPP_OK;
+}
+
 int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, const float *bias, const float *gamma,
                            const float *beta, float *rm, float *rv, long long *nbt, float momentum, float eps, int training,
-                           float *mean, float *istd, float *scale, float *shift, hipStream_t st) {
+                           float *mean, float *istd, float *scale, float *shift, hipStream_t st, const double *count_dev) {
     ProfScope ps(st, "bn_finalize_fwd_kernel C=%d", C);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, st, slab, nslab, C, count, bias, gamma, beta,
-                       rm, rv, nbt, momentum, eps, training, mean, istd, scale, shift);
+                       rm, rv, nbt, momentum, eps, training, mean, istd, scale, shift, count_dev);
     PNPP_CHECK_LAUNCH("bn_finalize_fwd");
     return PNPP_OK;
 }
@@ -2810,8 +2869,8 @@ static DzJob make_dz_job(const AOperand *dz, int M, int C, float *out) {
 
 int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, int training, const float *gamma,
                            const float *mean, const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias,
-                           hipStream_t st, const AOperand *dz, int M, float *dz_out) {
-    const BnFinalizeBwdArgs F{slab, nslab, C, count, training, gamma, mean, istd, cst, dgamma, dbeta, dbias};
+                           hipStream_t st, const AOperand *dz, int M, float *dz_out, const double *count_dev, const double *local) {
+    const BnFinalizeBwdArgs F{slab, nslab, C, count, training, gamma, mean, istd, cst, dgamma, dbeta, dbias, count_dev, local};
     const DzJob J = make_dz_job(dz, M, C, dz_out);
     const int nfin = cdiv(C, FIN_COLS), ndz = dz_job_blocks(J, C);
     ProfScope ps(st, "bn_finalize_bwd_kernel C=%d%s", C, ndz ? " +dZ" : "");
@@ -2823,8 +2882,8 @@ int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, i
 int launch_post_gemm(const double *slab, int nslab, int C, double count, int training, const float *gamma, const float *mean,
                      const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias, const float *dwslab, int nsplit,
                      int Nc, int kp_pad, int Kvalid, int perm_D, float *dw, int ldo, hipStream_t st, const AOperand *dz, int M,
-                     float *dz_out) {
-    const BnFinalizeBwdArgs F{slab, nslab, C, count, training, gamma, mean, istd, cst, dgamma, dbeta, dbias};
+                     float *dz_out, const double *count_dev, const double *local) {
+    const BnFinalizeBwdArgs F{slab, nslab, C, count, training, gamma, mean, istd, cst, dgamma, dbeta, dbias, count_dev, local};
     const SlabReduceArgs R{dwslab, nsplit, Nc, kp_pad, Kvalid, perm_D, dw, ldo};
     const DzJob J = make_dz_job(dz, M, C, dz_out);
     const int total = Nc * Kvalid, nfin = cdiv(C, FIN_COLS), ndz = dz_job_blocks(J, C), nf = nfin + ndz;

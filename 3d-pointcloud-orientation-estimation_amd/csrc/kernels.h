@@ -131,17 +131,35 @@ int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kv
 
 int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, const float *bias, const float *gamma,
                            const float *beta, float *rm, float *rv, long long *nbt, float momentum, float eps, int training,
-                           float *mean, float *istd, float *scale, float *shift, hipStream_t st);
+                           float *mean, float *istd, float *scale, float *shift, hipStream_t st, const double *count_dev = nullptr);
 int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, int training, const float *gamma,
                            const float *mean, const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias,
-                           hipStream_t st, const AOperand *dz = nullptr, int M = 0, float *dz_out = nullptr);
+                           hipStream_t st, const AOperand *dz = nullptr, int M = 0, float *dz_out = nullptr,
+                           const double *count_dev = nullptr, const double *local = nullptr);
 
 // bn_finalize_bwd of one layer and the weight-gradient slab reduction of the layer above it, in one launch
 // dz / M / dz_out (optional): also materialise dZ = BN-backward(dz operand) of the layer being finalised (small-M levels)
 int launch_post_gemm(const double *slab, int nslab, int C, double count, int training, const float *gamma, const float *mean,
                      const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias, const float *dwslab, int nsplit,
                      int Nc, int kp_pad, int Kvalid, int perm_D, float *dw, int ldo, hipStream_t st, const AOperand *dz = nullptr, int M = 0,
-                     float *dz_out = nullptr);
+                     float *dz_out = nullptr, const double *count_dev = nullptr, const double *local = nullptr);
+
+// ---- SyncBN (off unless pnpp_set_stats_exchange has registered a callback; sa_api.hip) ----
+// What a BatchNorm finalisation reads: the partial slabs of this rank, or -- after stats_exchange -- one slab of sums over all
+// ranks with their row count in device memory, plus this rank's own sums for the parameter gradients.
+struct StatsView {
+    const double *slab = nullptr;
+    int nslab = 0;
+    const double *count_dev = nullptr, *local = nullptr;
+};
+bool stats_sync_on();
+int launch_slab_sum(const double *slab, int nslab, int C, double count, double *glob, double *local, hipStream_t st);
+// training-mode statistics of one BatchNorm layer: reduce, exchange over the ranks (stream-ordered), return the view to finalise from
+int stats_exchange(const double *slab, int nslab, int C, double count, hipStream_t st, StatsView *out);
+// the same for sums that are already one [2][C] slab in the exchange buffer's global half (fully connected head)
+int stats_exchange_inplace(int C, hipStream_t st, StatsView *out);
+double *stats_buffer_global();
+double *stats_buffer_local();
 
 // part (optional): workspace of pool_fwd_splits(G, K, C) * G * C * 8 bytes; with it, pooling over whole clouds (K >= 512)
 // is split over K into partial maxima that a second launch merges (first maximum wins, as in the one-launch form)

@@ -60,6 +60,42 @@ bool prof_take_events(hipEvent_t *a, hipEvent_t *b) {
     return true;
 }
 
+// ---- SyncBN: optional cross-rank exchange of the BatchNorm sums (off by default) ----------------------------
+// The callback sums a device buffer of doubles over the ranks, stream-ordered (RCCL: an all-reduce enqueued behind `stream`).
+// The buffer is the caller's (this library never allocates): [0, half) is exchanged, [half, 2 half) keeps this rank's sums.
+struct StatsExchange {
+    pnpp_stats_exchange_fn fn = nullptr;
+    void *user = nullptr;
+    double *buf = nullptr;
+    size_t half = 0;   // doubles per half
+};
+static StatsExchange g_sx;
+
+bool stats_sync_on() { return g_sx.fn != nullptr; }
+double *stats_buffer_global() { return g_sx.buf; }
+double *stats_buffer_local() { return g_sx.buf + g_sx.half; }
+
+int stats_exchange_inplace(int C, hipStream_t st, StatsView *out) {
+    PNPP_REQUIRE((size_t)(2 * C + 1) <= g_sx.half, PNPP_ERR_ARG, "stats exchange: buffer of %zu doubles per half is too small for C=%d",
+                 g_sx.half, C);
+    const int rc = g_sx.fn(g_sx.buf, (size_t)(2 * C + 1), (void *)st, g_sx.user);
+    PNPP_REQUIRE(rc == 0, PNPP_ERR_LAUNCH, "stats exchange: the registered callback returned %d", rc);
+    out->slab = g_sx.buf, out->nslab = 1, out->count_dev = g_sx.buf + 2 * C, out->local = g_sx.buf + g_sx.half;
+    return PNPP_OK;
+}
+
+int stats_exchange(const double *slab, int nslab, int C, double count, hipStream_t st, StatsView *out) {
+    if (!g_sx.fn) {
+        out->slab = slab, out->nslab = nslab, out->count_dev = nullptr, out->local = nullptr;
+        return PNPP_OK;
+    }
+    PNPP_REQUIRE((size_t)(2 * C + 1) <= g_sx.half, PNPP_ERR_ARG, "stats exchange: buffer of %zu doubles per half is too small for C=%d",
+                 g_sx.half, C);
+    int rc = launch_slab_sum(slab, nslab, C, count, g_sx.buf, g_sx.buf + g_sx.half, st);
+    if (rc != PNPP_OK) return rc;
+    return stats_exchange_inplace(C, st, out);
+}
+
 #define PNPP_TRY(expr)                 \
     do {                               \
         int rc_ = (expr);              \
@@ -253,17 +289,21 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
             PNPP_TRY(launch_gemm(F, Wf, d->B * d->N, d->C[0], d->D, Ep, nullptr, st));
             PNPP_TRY(launch_gather_rel_stats(sc.src, A, a->conv_w[0], g.Cin[0], g.M, d->C[0], sv.z[0],
                                              d->training ? sc.slab : nullptr, &nslab, st));
-            PNPP_TRY(launch_bn_finalize_fwd(d->training ? sc.slab : nullptr, d->training ? nslab : 0, d->C[0], (double)g.M, a->conv_b[0],
+            StatsView V;
+            if (d->training) PNPP_TRY(stats_exchange(sc.slab, nslab, d->C[0], (double)g.M, st, &V));
+            PNPP_TRY(launch_bn_finalize_fwd(V.slab, V.nslab, d->C[0], (double)g.M, a->conv_b[0],
                                             a->bn_w[0], a->bn_b[0], a->bn_rm[0], a->bn_rv[0],
                                             d->training ? (long long *)a->bn_nbt[0] : nullptr, d->momentum, d->eps, d->training ? 1 : 0,
-                                            sv.mean[0], sv.istd[0], sv.scale[0], sv.shift[0], st));
+                                            sv.mean[0], sv.istd[0], sv.scale[0], sv.shift[0], st, V.count_dev));
         } else if (d->training) {
             E.mode = E_STORE_STATS;
             E.slab = sc.slab;
             PNPP_TRY(launch_gemm(A, W, g.M, d->C[l], g.Kd[l], E, &nslab, st));
-            PNPP_TRY(launch_bn_finalize_fwd(sc.slab, nslab, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
+            StatsView V;
+            PNPP_TRY(stats_exchange(sc.slab, nslab, d->C[l], (double)g.M, st, &V));
+            PNPP_TRY(launch_bn_finalize_fwd(V.slab, V.nslab, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
                                             a->bn_rm[l], a->bn_rv[l], (long long *)a->bn_nbt[l], d->momentum, d->eps, 1, sv.mean[l], sv.istd[l],
-                                            sv.scale[l], sv.shift[l], st));
+                                            sv.scale[l], sv.shift[l], st, V.count_dev));
         } else {
             E.mode = E_STORE;
             PNPP_TRY(launch_bn_finalize_fwd(nullptr, 0, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
@@ -314,9 +354,14 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
         return dz;
     };
     const AOperand dz_top = dz_operand(Lm, 0);
-    PNPP_TRY(launch_bn_finalize_bwd(sc.slab, nslab, d->C[Lm], (double)g.M, d->training, a->bn_w[Lm], sv.mean[Lm], sv.istd[Lm],
-                                    sc.cst, a->d_bn_w[Lm], a->d_bn_b[Lm], a->d_conv_b[Lm], st, small ? &dz_top : nullptr, g.M,
-                                    small ? sc.dzbuf : nullptr));
+    {
+        StatsView V;
+        V.slab = sc.slab, V.nslab = nslab;
+        if (d->training) PNPP_TRY(stats_exchange(sc.slab, nslab, d->C[Lm], (double)g.M, st, &V));
+        PNPP_TRY(launch_bn_finalize_bwd(V.slab, V.nslab, d->C[Lm], (double)g.M, d->training, a->bn_w[Lm], sv.mean[Lm], sv.istd[Lm],
+                                        sc.cst, a->d_bn_w[Lm], a->d_bn_b[Lm], a->d_conv_b[Lm], st, small ? &dz_top : nullptr, g.M,
+                                        small ? sc.dzbuf : nullptr, V.count_dev, V.local));
+    }
     bool dz_ready = small;  // sc.dzbuf holds dZ of the layer about to be processed
     bool dpoints_done = false;
     for (int l = Lm; l >= 0; --l) {
@@ -441,11 +486,14 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
         if (l > 0) {  // reduce dW_l's partials and finalise layer l-1's BatchNorm-backward sums in one launch
             const int Cp = d->C[l - 1];
             const AOperand dz_next = dz_operand(l - 1, cur ^ 1);  // dY_{l-1} was just written to sc.dy[cur ^ 1]
-            PNPP_TRY(launch_post_gemm(sc.slab, nslab_next, Cp, (double)g.M, d->training, a->bn_w[l - 1], sv.mean[l - 1],
+            StatsView V;
+            V.slab = sc.slab, V.nslab = nslab_next;
+            if (d->training) PNPP_TRY(stats_exchange(sc.slab, nslab_next, Cp, (double)g.M, st, &V));
+            PNPP_TRY(launch_post_gemm(V.slab, V.nslab, Cp, (double)g.M, d->training, a->bn_w[l - 1], sv.mean[l - 1],
                                       sv.istd[l - 1], sc.cst, a->d_bn_w[l - 1], a->d_bn_b[l - 1],
                                       a->d_conv_b[l - 1], sc.dwslab, fused_slabs > 0 ? fused_slabs : nsplit, C,
                                       fused_slabs > 0 ? Cp : kp_pad, g.Cin[l], -1, a->d_conv_w[l], g.Cin[l], st,
-                                      small ? &dz_next : nullptr, g.M, small ? sc.dzbuf : nullptr));
+                                      small ? &dz_next : nullptr, g.M, small ? sc.dzbuf : nullptr, V.count_dev, V.local));
             dz_ready = small;
         } else {
             PNPP_TRY(launch_slab_reduce(sc.dwslab, nsplit, C, kp_pad, g.Cin[l], d->D, a->d_conv_w[l], g.Cin[l], st));
@@ -481,7 +529,18 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
 using namespace pnpp;
 
 extern "C" const char *pnpp_last_error(void) { return g_err; }
-extern "C" int pnpp_abi_version(void) { return 2; }
+extern "C" int pnpp_abi_version(void) { return 3; }
+
+extern "C" int pnpp_set_stats_exchange(pnpp_stats_exchange_fn fn, void *user, double *buf, size_t buf_doubles) {
+    if (!fn) {
+        g_sx = StatsExchange();
+        return PNPP_OK;
+    }
+    PNPP_REQUIRE(buf && buf_doubles >= 2 * (2 * 32 + 1), PNPP_ERR_ARG, "set_stats_exchange: a device buffer of doubles is required");
+    g_sx.fn = fn, g_sx.user = user, g_sx.buf = buf, g_sx.half = buf_doubles / 2;
+    return PNPP_OK;
+}
+extern "C" int pnpp_stats_exchange_enabled(void) { return g_sx.fn ? 1 : 0; }
 
 extern "C" int pnpp_profile_enable(int on) {
     for (auto &r : g_recs) {

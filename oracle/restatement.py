@@ -269,6 +269,60 @@ def dir8_forward(xyz32, P, centres, drop_mask=None, training=True, bn_state=None
     return bn_head_forward(backbone_forward(xyz32, P, centres, training, bn_state, **bk), P, drop_mask, training, bn_state)
 
 
+# --------------------------------------------------------------------------------------
+# The same step through the STOCK ATen ops the reference's modules call (cpu_baseline of bench.py only)
+# --------------------------------------------------------------------------------------
+# The functions above spell BatchNorm as elementwise tensor expressions and the 1x1 convolution as a matmul so that they
+# run in any dtype and expose every intermediate; on a CPU that costs several passes over each activation.  The reference
+# itself runs nn.Conv2d / nn.BatchNorm2d / F.relu / torch.max on a (B,C,npoint,nsample) tensor and dist.topk for the
+# neighbour search, i.e. ATen's fused kernels.  These two functions are that: the representative CPU baseline.
+def sa_forward_aten(xyz, points, P, prefix, centre_idx, nsample, group_all, momentum=0.1, eps=1e-5):
+    """PointNetSetAbstraction.forward with the reference's own op sequence (models/pointnet_pp_8dir.py:21-43, models/base.py:4-35):
+    matmul-form square_distance + topk(sorted=False), advanced-indexing gathers, permute to (B,C,S,K), F.conv2d (1x1) ->
+    F.batch_norm(training=True) -> F.relu per layer, torch.max over nsample.  Running statistics are updated in place on clones
+    (the reference's modules own theirs); float32 only; centre_idx replaces the randperm draw of line 28."""
+    B, N, _ = xyz.shape
+    if group_all:
+        new_xyz = torch.zeros(B, 1, 3)
+        g = xyz.unsqueeze(1)
+        new_points = g if points is None else torch.cat([g, points.unsqueeze(1)], -1)
+    else:
+        new_xyz = index_points(xyz, centre_idx)
+        dist = -2 * torch.matmul(new_xyz, xyz.transpose(2, 1))                     # models/base.py:24-26
+        dist += torch.sum(new_xyz ** 2, dim=-1).unsqueeze(-1)
+        dist += torch.sum(xyz ** 2, dim=-1).unsqueeze(1)
+        _, idx = dist.topk(nsample, dim=-1, largest=False, sorted=False)           # models/base.py:33-34
+        normed = index_points(xyz, idx) - new_xyz.unsqueeze(2)
+        new_points = normed if points is None else torch.cat([normed, index_points(points, idx)], -1)
+    x = new_points.permute(0, 3, 1, 2)
+    li = 0
+    while f"{prefix}.convs.{li}.weight" in P:
+        W, b = P[f"{prefix}.convs.{li}.weight"], P[f"{prefix}.convs.{li}.bias"]
+        x = F.conv2d(x, W.reshape(W.shape[0], -1, 1, 1), b)
+        rm = P[f"{prefix}.bns.{li}.running_mean"].detach().clone()
+        rv = P[f"{prefix}.bns.{li}.running_var"].detach().clone()
+        x = F.relu(F.batch_norm(x, rm, rv, P[f"{prefix}.bns.{li}.weight"], P[f"{prefix}.bns.{li}.bias"], True, momentum, eps))
+        li += 1
+    x = torch.max(x, 3)[0]
+    return new_xyz, x.permute(0, 2, 1)
+
+
+def vonmises_forward_aten(xyz, P, centres, drop_mask=None, p_drop=0.5):
+    """PointNetPPVonMises.forward in train mode with stock ops (models/pointnet_pp_vonMises.py:26-38): float32 -> (mu, kappa)."""
+    l1_xyz, l1 = sa_forward_aten(xyz, None, P, "sa1", centres[0], 32, False)
+    l2_xyz, l2 = sa_forward_aten(l1_xyz, l1, P, "sa2", centres[1], 32, False)
+    _, l3 = sa_forward_aten(l2_xyz, l2, P, "sa3", None, None, True)
+    x = l3.reshape(l3.shape[0], -1)
+    for fc, bn in (("fc1", "bn1"), ("fc2", "bn2")):
+        x = F.linear(x, P[f"{fc}.weight"], P[f"{fc}.bias"])
+        x = F.relu(F.batch_norm(x, P[f"{bn}.running_mean"].detach().clone(), P[f"{bn}.running_var"].detach().clone(),
+                                P[f"{bn}.weight"], P[f"{bn}.bias"], True, 0.1, 1e-5))
+    if drop_mask is not None:
+        x = x * drop_mask.to(x.dtype) / (1.0 - p_drop)
+    out = F.linear(x, P["fc3.weight"], P["fc3.bias"])
+    return torch.tanh(out[:, 0]) * math.pi, F.softplus(out[:, 1])
+
+
 def l2_normalize(x, eps=1e-12):
     """F.normalize(x, p=2, dim=1, eps) (pointnet_pp_Fwd.py:98)."""
     return x / x.norm(dim=1, keepdim=True).clamp_min(eps)
