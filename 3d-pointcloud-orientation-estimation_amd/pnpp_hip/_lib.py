@@ -57,6 +57,8 @@ class FcBwdArgs(C.Structure):
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 _i, _f, _u64, _sz = C.c_int, C.c_float, C.c_uint64, C.c_size_t
+# int fn(double *buf, size_t n_doubles, void *stream, void *user): sums buf over the ranks in place (SyncBN, pnpp_set_stats_exchange)
+STATS_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
 SIGNATURES = {
     "pnpp_last_error": (C.c_char_p, []),
     "pnpp_abi_version": (_i, []),
@@ -111,6 +113,8 @@ SIGNATURES = {
     "pnpp_add_layernorm_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _fp, _fp, _fp, _fp]),
     "pnpp_mean_points_bwd": (_i, [_fp, _i, _i, _i, _fp, _fp]),
     "pnpp_set_matmul_precision": (_i, [_i]),
+    "pnpp_set_stats_exchange": (_i, [STATS_EXCHANGE_FN, C.c_void_p, C.c_void_p, _sz]),
+    "pnpp_stats_exchange_enabled": (_i, []),
     "pnpp_get_matmul_precision": (_i, []),
     "pnpp_adam_step": (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _f, _f, _f, _f, _fp]),
     "pnpp_adam_step_zero": (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _f, _f, _f, _f, _fp]),
@@ -143,7 +147,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.pnpp_abi_version() != 2:
+        if h.pnpp_abi_version() != 3:
             raise HipExtensionMissing("libpnpp_hip.so ABI version mismatch; rebuild it")
         _lib = h
     return _lib

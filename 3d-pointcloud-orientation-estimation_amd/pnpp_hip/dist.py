@@ -64,3 +64,61 @@ def world_size() -> int:
 
 def rank() -> int:
     return dist.get_rank() if dist.is_initialized() else 0
+
+
+# ------------------------------------------------------------------------------------------------
+# SyncBN (off by default): train-mode BatchNorm statistics summed over the ranks
+# ------------------------------------------------------------------------------------------------
+_sync_state = {"cb": None, "buf": None, "calls": 0}
+
+
+def sync_batchnorm_enabled() -> bool:
+    return _sync_state["cb"] is not None
+
+
+def sum_over_ranks(t: torch.Tensor) -> torch.Tensor:
+    """In-place sum of `t` over the ranks (identity in a single process): what a BatchNorm layer does with its
+    (sum, sum of squares, row count) forward and (sum dy, sum dy*xhat, row count) backward under SyncBN.  The HIP library's
+    exchange callback goes through here (and so do the tests' CPU checks of the same exchange)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def enable_sync_batchnorm(max_channels: int = 4096) -> None:
+    """torch.nn.SyncBatchNorm.convert_sync_batchnorm for this path: from now on every training-mode BatchNorm of the HIP
+    library exchanges its per-channel sums over the ranks (pnpp_set_stats_exchange), so a global batch split over the ranks
+    normalises like the single process on the concatenated batch (the reference's nn.BatchNorm2d / BatchNorm1d,
+    models/pointnet_pp_8dir.py:40-41).  22 small all-reduces per step for PointNetPPVonMises; the BatchNorm head takes its
+    unfused route and dropout masks are drawn by torch (ops.fc_block).  Gradients of the BatchNorm parameters stay rank-local
+    sums: average them with the usual flat-gradient all-reduce."""
+    from . import _lib as L
+    if _sync_state["cb"] is not None:
+        return
+    dev = torch.device("cuda", torch.cuda.current_device())
+    buf = torch.zeros(2 * (2 * int(max_channels) + 1), device=dev, dtype=torch.float64)
+
+    def _exchange(ptr, n, stream, user):
+        try:
+            if ptr != buf.data_ptr() or n > buf.numel() // 2:
+                return -2
+            if stream is not None and int(stream or 0) != int(torch.cuda.current_stream().cuda_stream or 0):
+                return -3   # the library enqueues on the stream it was given: it must be torch's current one
+            sum_over_ranks(buf[:n])
+            _sync_state["calls"] += 1
+            return 0
+        except Exception as e:  # an exception must not cross the C ABI
+            print(f"[pnpp_hip.dist] statistics exchange failed: {type(e).__name__}: {e}", flush=True)
+            return -1
+
+    cb = L.STATS_EXCHANGE_FN(_exchange)
+    L.check(L.lib().pnpp_set_stats_exchange(cb, None, buf.data_ptr(), buf.numel()))
+    _sync_state["cb"], _sync_state["buf"] = cb, buf          # keep both alive: the library holds raw pointers
+
+
+def disable_sync_batchnorm() -> None:
+    from . import _lib as L
+    if _sync_state["cb"] is None:
+        return
+    L.check(L.lib().pnpp_set_stats_exchange(L.STATS_EXCHANGE_FN(0), None, None, 0))
+    _sync_state["cb"], _sync_state["buf"] = None, None

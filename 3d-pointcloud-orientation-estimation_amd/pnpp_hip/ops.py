@@ -469,7 +469,9 @@ def fc_block(x, linear, norm=None, relu=False, dropout=None, training=True, mask
     drop_scale = 1.0
     draw = None
     if training and mask is None and dropout is not None and dropout.p > 0:
-        if kind == L.NORM_BATCH and x.shape[0] <= 32 and x.is_cuda:   # the BatchNorm epilogue draws it in the kernel
+        from . import dist as _pdist
+        if kind == L.NORM_BATCH and x.shape[0] <= 32 and x.is_cuda and not _pdist.sync_batchnorm_enabled():
+            # the BatchNorm epilogue draws it in the kernel (SyncBN takes the unfused route: the mask comes from torch)
             draw = (dropout.p, torch.initial_seed(), _dropout_counter(x.device))
             drop_scale = 1.0 / (1.0 - dropout.p)
         else:

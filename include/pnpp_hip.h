@@ -17,7 +17,8 @@
  *     synchronises, allocates or frees.  Outputs and workspaces are caller-owned.
  *   - Return value: PNPP_OK or a negative pnpp_status; pnpp_last_error() gives the text.
  *     No exception crosses the ABI.  Functions are re-entrant; the only global state is
- *     the thread-local last-error string and an immutable device-property cache.
+ *     the thread-local last-error string, an immutable device-property cache and the two
+ *     process-wide switches (matmul precision, BatchNorm statistics exchange).
  */
 #ifndef PNPP_HIP_H
 #define PNPP_HIP_H
@@ -336,6 +337,24 @@ int pnpp_mean_points_bwd(const float *dy, int B, int N, int E, float *dx, void *
  * ---------------------------------------------------------------------------------------- */
 int pnpp_set_matmul_precision(int bf16_operands);
 int pnpp_get_matmul_precision(void);
+
+/* ------------------------------------------------------------------------------------------
+ * SyncBN (ABI 3; off by default): cross-rank exchange of the train-mode BatchNorm sums under data parallelism, so that a
+ * global batch split over ranks normalises exactly like the reference's single process on the concatenated batch
+ * (nn.BatchNorm2d / nn.BatchNorm1d in training mode: models/pointnet_pp_8dir.py:40-41, models/pointnet_pp_vonMises.py:32-33).
+ * Once a callback is registered, every training-mode BatchNorm of pnpp_sa_forward / pnpp_sa_backward / pnpp_fc_forward /
+ * pnpp_fc_backward reduces this rank's per-channel sums -- forward (sum z, sum z^2, rows), backward (sum dy, sum dy*xhat, rows) --
+ * into buf[0 .. 2C], calls fn(buf, 2C + 1, stream, user), which must replace those doubles by their SUM OVER ALL RANKS,
+ * stream-ordered behind `stream` (RCCL: an all-reduce enqueued on it; gloo: a blocking all-reduce), and finalises from the
+ * summed values.  Parameter gradients of the BatchNorm layers stay rank-local sums (the gradient all-reduce adds them up like
+ * every other parameter's); running statistics become the global ones on every rank.  buf: caller-owned device memory of
+ * buf_doubles >= 2 * (2 * C_max + 1) doubles (second half: the rank's own sums).  fn == NULL unregisters.
+ * The head's fused BatchNorm epilogue and its in-kernel dropout draw need the whole batch in one tile and are bypassed while a
+ * callback is registered (pass an explicit mask).  Process-wide, like the matmul precision.
+ * ---------------------------------------------------------------------------------------- */
+typedef int (*pnpp_stats_exchange_fn)(double *buf, size_t n_doubles, void *stream, void *user);
+int pnpp_set_stats_exchange(pnpp_stats_exchange_fn fn, void *user, double *buf, size_t buf_doubles);
+int pnpp_stats_exchange_enabled(void);
 
 /* ------------------------------------------------------------------------------------------
  * Step glue on one flat parameter / gradient buffer

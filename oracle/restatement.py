@@ -141,11 +141,59 @@ class BNState:
         self.updates: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
 
 
+class _SumOverRanks(torch.autograd.Function):
+    """y = sum over ranks of x (every rank gets y); backward: the incoming gradients summed over the ranks -- what
+    torch.nn.SyncBatchNorm does with its (sum, sum of squares, count) forward and (sum dy, sum dy xhat) backward."""
+
+    @staticmethod
+    def forward(ctx, x, fn):
+        ctx.fn = fn
+        return fn(x.detach().clone())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.fn(g.detach().clone()), None
+
+
+_STATS_SYNC = None   # callable(tensor) -> tensor summed over the ranks in place, or None (per-rank statistics, DDP's default)
+
+
+class stats_sync:
+    """with stats_sync(fn): every train-mode BatchNorm below pools its statistics over the ranks (SyncBN): a batch
+    split over ranks then normalises like the reference's single process on the concatenated batch."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        global _STATS_SYNC
+        self.prev, _STATS_SYNC = _STATS_SYNC, self.fn
+
+    def __exit__(self, *exc):
+        global _STATS_SYNC
+        _STATS_SYNC = self.prev
+
+
 def _bn_train(z: torch.Tensor, gamma, beta, dims, eps: float):
-    mean = z.mean(dim=dims)
-    var = z.var(dim=dims, unbiased=False)
+    if _STATS_SYNC is None:
+        mean = z.mean(dim=dims)
+        var = z.var(dim=dims, unbiased=False)
+    else:   # biased variance from pooled (sum, sum of squares, rows): E[z^2] - E[z]^2 over the rows of every rank
+        rows = z.numel() // z.shape[-1]
+        packed = torch.cat([z.sum(dim=dims), (z * z).sum(dim=dims), torch.full((1,), float(rows), dtype=z.dtype)])
+        packed = _SumOverRanks.apply(packed, _STATS_SYNC)
+        C = z.shape[-1]
+        mean = packed[:C] / packed[2 * C]
+        var = (packed[C:2 * C] / packed[2 * C] - mean * mean).clamp_min(0.0)
     zh = (z - mean) / torch.sqrt(var + eps)
     return zh * gamma + beta, mean, var
+
+
+def _pooled_rows(rows: int) -> int:
+    """Rows behind a BatchNorm's statistics: this rank's, or every rank's under stats_sync."""
+    if _STATS_SYNC is None:
+        return rows
+    return int(_STATS_SYNC(torch.tensor([float(rows)], dtype=torch.float64)).item())
 
 
 def _bn_eval(z, gamma, beta, rm, rv, eps):
@@ -193,7 +241,7 @@ def sa_forward(xyz32: torch.Tensor, points: Optional[torch.Tensor], P: Dict[str,
         if training:
             y, mean, var = _bn_train(z, g_, b_, (0, 1, 2), eps)
             if bn_state is not None:
-                m = z.numel() // z.shape[-1]
+                m = _pooled_rows(z.numel() // z.shape[-1])
                 rm, rv = P[f"{prefix}.bns.{li}.running_mean"], P[f"{prefix}.bns.{li}.running_var"]
                 bn_state.updates[f"{prefix}.bns.{li}"] = (
                     ((1 - momentum) * rm + momentum * mean).detach(),
@@ -231,7 +279,7 @@ def _bn1d(x, P, name, training, bn_state, eps=1e-5, momentum=0.1):
     if training:
         y, mean, var = _bn_train(x, g_, b_, (0,), eps)
         if bn_state is not None:
-            m = x.shape[0]
+            m = _pooled_rows(x.shape[0])
             bn_state.updates[name] = (
                 ((1 - momentum) * P[f"{name}.running_mean"] + momentum * mean).detach(),
                 ((1 - momentum) * P[f"{name}.running_var"] + momentum * var * (m / max(m - 1, 1))).detach())

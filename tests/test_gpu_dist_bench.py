@@ -124,3 +124,96 @@ def test_rccl_all_reduce_captured_inside_the_step_graph():
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
     assert all(res.values()), res
+
+
+_SYNCBN_CHILD = r'''
+import os, sys, json
+import torch, torch.distributed as tdist
+ROOT = sys.argv[1]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "3d-pointcloud-orientation-estimation_amd")]
+from pnpp_hip import dist as pdist, ops
+from models.pointnet_pp_vonMises import PointNetPPVonMises
+from oracle import restatement as R
+rank, _, world = pdist.init_from_env()           # PNPP_DIST_BACKEND=gloo: both ranks share the one GPU of the test box
+torch.manual_seed(42)
+model = PointNetPPVonMises()
+state = {k: v.clone() for k, v in model.state_dict().items()}
+model = model.cuda().train()
+B, N = 16, 1024
+xyz, mu_gt, kappa_gt, _ = R.synthetic_clouds(B, N, seed=1234)
+torch.manual_seed(4242)
+c1, c2 = R.replay_centres(B)
+mask = (torch.rand(B, 256, generator=torch.Generator().manual_seed(8)) < 0.5).to(torch.uint8)
+lo, hi = pdist.shard_bounds(B, rank, world)
+sl = slice(lo, hi)
+
+def hip_step():
+    model.zero_grad()
+    mu, kappa = model(xyz[sl].cuda(), centres=[c1[sl].cuda(), c2[sl].cuda()], drop_mask=mask[sl].cuda())
+    loss = ops.kl_von_mises_single(mu, kappa, mu_gt[sl].cuda(), kappa_gt[sl].cuda()).mean()
+    loss.backward()
+    names = [n for n, p in model.named_parameters() if not (".convs." in n and n.endswith("bias"))]
+    g = torch.cat([dict(model.named_parameters())[n].grad.reshape(-1) for n in names]).double()
+    tdist.all_reduce(g)
+    l = loss.detach().double().reshape(1)
+    tdist.all_reduce(l)
+    return float(l) / world, (g / world).cpu(), names
+
+sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+loss_local, g_local, names = hip_step()          # per-rank statistics (DDP's default)
+model.load_state_dict(sd0)
+pdist.enable_sync_batchnorm()
+loss_sync, g_sync, _ = hip_step()                # statistics pooled over the ranks
+calls = pdist._sync_state["calls"]
+pdist.disable_sync_batchnorm()
+res = None
+if rank == 0:
+    P = R.cast_params(state, torch.float64)
+    st = R.BNState()
+    mu64, k64 = R.vonmises_forward(xyz, P, (c1, c2), mask.float(), True, st)      # the single process on the whole batch
+    l64 = R.kl_single(mu64, k64, mu_gt.double(), kappa_gt.double()).mean()
+    l64.backward()
+    g64 = torch.cat([P[n].grad.reshape(-1) for n in names])
+    head = [i for i, n in enumerate(names)]
+    def rel(a, b): return float((a - b).norm() / b.norm())
+    off, per = 0, {}
+    for n in names:
+        k = P[n].numel()
+        per[n] = rel(g_sync[off:off + k], g64[off:off + k])
+        off += k
+    sd = model.state_dict()
+    rs = max(float((sd[k + ".running_mean"].cpu().double() - v[0]).abs().max()) for k, v in st.updates.items())
+    res = {"dloss_sync": abs(loss_sync - float(l64)), "dloss_local": abs(loss_local - float(l64)), "grad_sync": rel(g_sync, g64),
+           "grad_local": rel(g_local, g64), "head": {n: per[n] for n in ("fc1.weight", "fc2.weight", "fc3.weight", "bn1.weight", "bn2.bias")},
+           "running_mean": rs, "exchanges": calls}
+    print("RESULT " + json.dumps(res))
+tdist.barrier()
+tdist.destroy_process_group()
+'''
+
+
+def test_syncbn_hip_two_ranks(tmp_path):
+    """SyncBN on the HIP path (pnpp_set_stats_exchange): two ranks with half the batch each and pooled BatchNorm sums give the loss,
+    gradient and running statistics of the reference's single process on the concatenated batch (float64 oracle), to the gates of
+    the single-process tests -- while per-rank statistics (the default) measurably do not.  The ranks share the GPU and exchange
+    through gloo; with RCCL the callback enqueues the same all-reduce on the stream."""
+    import socket
+    from conftest import ROOT
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"PNPP_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "4"})
+    child = tmp_path / "syncbn_child.py"
+    child.write_text(_SYNCBN_CHILD)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(child), ROOT], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    print(res)
+    assert res["exchanges"] == 22                                   # 11 BatchNorm layers, forward and backward
+    assert res["dloss_sync"] <= 1e-5 and res["grad_sync"] <= 1e-2   # G3; the flat gradient within one arg-max flip (see test_gpu_e2e)
+    assert all(v <= 1e-3 for v in res["head"].values()), res["head"]   # behind no arg-max: tight
+    assert res["running_mean"] <= 1e-4
+    assert res["dloss_local"] > 10 * max(res["dloss_sync"], 1e-6)   # per-rank statistics are a different function of the batch
