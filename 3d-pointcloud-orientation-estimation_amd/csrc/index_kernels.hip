@@ -87,20 +87,42 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 
 // centre != nullptr: the query of (b, q) is xyz[b, centre[b, q]] and the kernel also writes it to out_a / out_b (the
 // caller's new_xyz and the copy kept for backward) -- the set-abstraction forward then needs no separate gather launch.
-__global__ void __launch_bounds__(256) knn_kernel(const float *__restrict__ new_xyz, const float *__restrict__ xyz, int S,
-                                                  int N, int k, int32_t *__restrict__ idx, const int32_t *__restrict__ centre,
-                                                  float *__restrict__ out_a, float *__restrict__ out_b) {
+// gather != nullptr: the "cloud" of (b) is itself a gathered subset of xyz -- candidate p is xyz[b, gather[b, p]] (the centres
+// of the level below, xyz holding Nsrc points per cloud): the neighbour search of a stacked level then needs neither the level
+// below's output nor a launch of its own (knn_pair_kernel).
+struct KnnJob {
+    const float *new_xyz;      // explicit queries, or nullptr with `centre`
+    const float *xyz;
+    const int32_t *gather;     // (B, N) rows of xyz that form the candidate cloud, or nullptr (the cloud is xyz itself)
+    int Nsrc;                  // points per cloud in xyz (== N without gather)
+    int S, N, k;
+    int32_t *idx;
+    const int32_t *centre;
+    float *out_a, *out_b;
+};
+
+__device__ __forceinline__ void knn_body(const KnnJob &J, const int bx, const int b) {
+    const float *__restrict__ new_xyz = J.new_xyz;
+    const float *__restrict__ xyz = J.xyz;
+    const int32_t *__restrict__ centre = J.centre;
+    const int32_t *__restrict__ gather = J.gather ? J.gather + (size_t)b * J.N : nullptr;
+    int32_t *__restrict__ idx = J.idx;
+    float *__restrict__ out_a = J.out_a, *__restrict__ out_b = J.out_b;
+    const int S = J.S, N = J.N, k = J.k;
     __shared__ float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE], sn[KNN_TILE];
     __shared__ unsigned long long best[4][2][KNN_KMAX];
     __shared__ unsigned long long pool[4][KNN_POOL];
 
-    const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + wave;
+    const int q = bx * 4 + wave;
     const bool active = q < S;  // wave-uniform
     float ax = 0.f, ay = 0.f, az = 0.f, sa = 0.f;
     if (active) {
-        const float *a = centre ? xyz + ((size_t)b * N + centre[(size_t)b * S + q]) * 3 : new_xyz + ((size_t)b * S + q) * 3;
+        const float *a = new_xyz + ((size_t)b * S + q) * 3;
+        if (centre) {
+            const int c = centre[(size_t)b * S + q];
+            a = xyz + ((size_t)b * J.Nsrc + (gather ? gather[c] : c)) * 3;
+        }
         ax = a[0], ay = a[1], az = a[2];
         sa = sq3_exact(ax, ay, az);
         if (centre && lane < 3) {
@@ -113,14 +135,14 @@ __global__ void __launch_bounds__(256) knn_kernel(const float *__restrict__ new_
     bool have = false;   // best[cur][0..k) is valid (wave-uniform)
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    const float *cloud = xyz + (size_t)b * N * 3;
+    const float *cloud = xyz + (size_t)b * J.Nsrc * 3;
     for (int t0 = 0; t0 < N; t0 += KNN_TILE) {
         __syncthreads();  // previous tile fully consumed
         const int cnt = min(KNN_TILE, N - t0);
-        // coalesced stage: 3*cnt consecutive floats, de-interleaved into SoA
+        // coalesced stage: 3*cnt consecutive floats, de-interleaved into SoA (gathered clouds: three floats per listed row)
         for (int i = threadIdx.x; i < cnt * 3; i += 256) {
-            float v = cloud[(size_t)t0 * 3 + i];
             int p = i / 3, c = i - p * 3;
+            float v = gather ? cloud[(size_t)gather[t0 + p] * 3 + c] : cloud[(size_t)t0 * 3 + i];
             (c == 0 ? sx : c == 1 ? sy : sz)[p] = v;
         }
         __syncthreads();
@@ -203,6 +225,15 @@ __global__ void __launch_bounds__(256) knn_kernel(const float *__restrict__ new_
         int32_t *o = idx + ((size_t)b * S + q) * k;
         for (int j = lane; j < k; j += 64) o[j] = (int32_t)(unsigned)(best[wave][cur][j] & 0xffffffffu);
     }
+}
+
+__global__ void __launch_bounds__(256) knn_kernel(const KnnJob J) { knn_body(J, blockIdx.x, blockIdx.y); }
+
+// The neighbour searches of two stacked levels in ONE launch (they are independent once both levels' centre indices are drawn:
+// level 2 searches among level 1's centres, which are rows of the same cloud).  blockIdx.x < nb1: level 1, else level 2.
+__global__ void __launch_bounds__(256) knn_pair_kernel(const KnnJob J1, const KnnJob J2, int nb1) {
+    if ((int)blockIdx.x < nb1) knn_body(J1, blockIdx.x, blockIdx.y);
+    else knn_body(J2, blockIdx.x - nb1, blockIdx.y);
 }
 
 // Wave-wide maximum of a 64-bit key, result in every lane.  Six dependent ds_bpermute round trips (what __shfl_xor compiles
@@ -638,8 +669,8 @@ int launch_knn(const float *new_xyz, const float *xyz, int B, int S, int N, int 
     PNPP_REQUIRE(k <= KNN_KMAX, PNPP_ERR_ARG, "knn: nsample=%d exceeds the supported maximum %d", k, KNN_KMAX);
     PNPP_REQUIRE(B <= 65535, PNPP_ERR_ARG, "knn: batch %d exceeds grid limit", B);
     ProfScope ps(st, "knn_kernel B=%d S=%d N=%d k=%d", B, S, N, k);
-    hipLaunchKernelGGL(knn_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, st, new_xyz, xyz, S, N, k, idx, (const int32_t *)nullptr,
-                       (float *)nullptr, (float *)nullptr);
+    const KnnJob J{new_xyz, xyz, nullptr, N, S, N, k, idx, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(knn_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, st, J);
     PNPP_CHECK_LAUNCH("knn");
     return PNPP_OK;
 }
@@ -653,9 +684,28 @@ int launch_knn_centres(const float *xyz, const int32_t *centre, int B, int S, in
     PNPP_REQUIRE(k <= KNN_KMAX, PNPP_ERR_ARG, "knn: nsample=%d exceeds the supported maximum %d", k, KNN_KMAX);
     PNPP_REQUIRE(B <= 65535, PNPP_ERR_ARG, "knn: batch %d exceeds grid limit", B);
     ProfScope ps(st, "knn_kernel B=%d S=%d N=%d k=%d", B, S, N, k);
-    hipLaunchKernelGGL(knn_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, st, (const float *)nullptr, xyz, S, N, k, idx, centre, out_a,
-                       out_b);
+    const KnnJob J{nullptr, xyz, nullptr, N, S, N, k, idx, centre, out_a, out_b};
+    hipLaunchKernelGGL(knn_kernel, dim3(cdiv(S, 4), B), dim3(256), 0, st, J);
     PNPP_CHECK_LAUNCH("knn");
+    return PNPP_OK;
+}
+
+// Both levels' searches in one launch: level 1 = S1 centres (rows centre1 of the N-point cloud), k1 neighbours among the N
+// points; level 2 = S2 of those centres (positions centre2 in 0..S1-1), k2 neighbours among the S1 centres.
+int launch_knn_pair(const float *xyz, int B, int N, const int32_t *centre1, int S1, int k1, int32_t *idx1, float *a1, float *b1,
+                    const int32_t *centre2, int S2, int k2, int32_t *idx2, float *a2, float *b2, hipStream_t st) {
+    PNPP_REQUIRE(xyz && centre1 && centre2 && idx1 && idx2 && a1 && a2, PNPP_ERR_ARG, "knn_pair: null pointer");
+    PNPP_REQUIRE(B > 0 && N > 0 && S1 > 0 && S2 > 0 && k1 > 0 && k2 > 0, PNPP_ERR_ARG, "knn_pair: non-positive size");
+    PNPP_REQUIRE(k1 <= N && k2 <= S1, PNPP_ERR_RANGE, "selected index k out of range (k=%d > N=%d)", k1 <= N ? k2 : k1, k1 <= N ? S1 : N);
+    PNPP_REQUIRE(S1 <= N && S2 <= S1, PNPP_ERR_RANGE, "knn_pair: more centres than points");
+    PNPP_REQUIRE(k1 <= KNN_KMAX && k2 <= KNN_KMAX, PNPP_ERR_ARG, "knn: nsample exceeds the supported maximum %d", KNN_KMAX);
+    PNPP_REQUIRE(B <= 65535, PNPP_ERR_ARG, "knn: batch %d exceeds grid limit", B);
+    ProfScope ps(st, "knn_pair_kernel B=%d | S=%d N=%d k=%d | S=%d N=%d k=%d", B, S1, N, k1, S2, S1, k2);
+    const KnnJob J1{nullptr, xyz, nullptr, N, S1, N, k1, idx1, centre1, a1, b1};
+    const KnnJob J2{nullptr, xyz, centre1, N, S2, S1, k2, idx2, centre2, a2, b2};
+    const int nb1 = cdiv(S1, 4);
+    hipLaunchKernelGGL(knn_pair_kernel, dim3(nb1 + cdiv(S2, 4), B), dim3(256), 0, st, J1, J2, nb1);
+    PNPP_CHECK_LAUNCH("knn_pair");
     return PNPP_OK;
 }
 

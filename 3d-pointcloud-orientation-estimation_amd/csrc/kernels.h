@@ -8,6 +8,8 @@ namespace pnpp {
 int launch_knn(const float *new_xyz, const float *xyz, int B, int S, int N, int k, int32_t *idx, hipStream_t st);
 int launch_knn_centres(const float *xyz, const int32_t *centre, int B, int S, int N, int k, int32_t *idx, float *out_a,
                        float *out_b, hipStream_t st);
+int launch_knn_pair(const float *xyz, int B, int N, const int32_t *centre1, int S1, int k1, int32_t *idx1, float *a1, float *b1,
+                    const int32_t *centre2, int S2, int k2, int32_t *idx2, float *a2, float *b2, hipStream_t st);
 int launch_gather_centres(const float *xyz, const int32_t *centre, int B, int N, int S, float *out_a, float *out_b, hipStream_t st);
 int launch_scatter_rows_bwd(const float *dout, const int32_t *idx, int B, int N, int C, int M, float *dpoints, hipStream_t st);
 

@@ -242,7 +242,9 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
         // the centres are the origin: written by the pooling launch that ends this forward (nothing in between reads them)
     } else {
         PNPP_REQUIRE(d->S <= d->N, PNPP_ERR_RANGE, "sa_forward: npoint=%d > N=%d", d->S, d->N);
-        if (a->neighbour_idx) {
+        if (a->neighbour_idx == sv.idx) {
+            // grouped ahead of time by pnpp_sa_group_pair: neighbours, saved centres and new_xyz are already in place
+        } else if (a->neighbour_idx) {
             PNPP_TRY(launch_gather_centres(a->xyz, a->centre_idx, d->B, d->N, d->S, a->new_xyz, sv.new_xyz, st));
             hipError_t e = hipMemcpyAsync(sv.idx, a->neighbour_idx, (size_t)g.M * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
             PNPP_REQUIRE(e == hipSuccess, PNPP_ERR_LAUNCH, "sa_forward: neighbour copy failed: %s", hipGetErrorString(e));
@@ -599,6 +601,20 @@ extern "C" const int32_t *pnpp_sa_saved_argmax(const pnpp_sa_desc *d, const void
     if (sa_geom(d, &g) != PNPP_OK) return nullptr;
     return sa_saved_layout(d, g, const_cast<void *>(saved)).arg;
 }
+extern "C" int pnpp_sa_group_pair(const pnpp_sa_desc *d1, const pnpp_sa_desc *d2, const float *xyz, const int32_t *centre1,
+                                  const int32_t *centre2, void *saved1, float *new_xyz1, void *saved2, float *new_xyz2, void *stream) {
+    SaGeom g1, g2;
+    PNPP_TRY(sa_geom(d1, &g1));
+    PNPP_TRY(sa_geom(d2, &g2));
+    PNPP_REQUIRE(!d1->group_all && !d2->group_all, PNPP_ERR_ARG, "sa_group_pair: both levels must group neighbourhoods");
+    PNPP_REQUIRE(d1->B == d2->B && d2->N == d1->S, PNPP_ERR_ARG, "sa_group_pair: level 2 must take level 1's %d centres (got N=%d)",
+                 d1->S, d2->N);
+    PNPP_REQUIRE(xyz && centre1 && centre2 && saved1 && saved2 && new_xyz1 && new_xyz2, PNPP_ERR_ARG, "sa_group_pair: null pointer");
+    const SaSaved s1 = sa_saved_layout(d1, g1, saved1), s2 = sa_saved_layout(d2, g2, saved2);
+    return launch_knn_pair(xyz, d1->B, d1->N, centre1, d1->S, d1->K, s1.idx, new_xyz1, s1.new_xyz, centre2, d2->S, d2->K, s2.idx,
+                           new_xyz2, s2.new_xyz, as_stream(stream));
+}
+
 extern "C" int pnpp_sa_forward(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, void *stream) {
     return sa_forward_impl(d, a, as_stream(stream));
 }

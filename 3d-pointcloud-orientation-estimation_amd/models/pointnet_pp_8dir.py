@@ -62,11 +62,14 @@ class PointNetSetAbstraction(nn.Module):
             return ops.farthest_point_sample(xyz, self.npoint)
         raise ValueError(f"unknown sampler '{self.sampler}'")
 
-    def forward(self, xyz, points, centre_idx=None):
+    def forward(self, xyz, points, centre_idx=None, pre=None):
         """xyz (B,N,3), points (B,N,D) or None -> new_xyz (B,S,3), new_points (B,S,C_out).
-        centre_idx (B,S) optionally injects the centres (tests, parity runs)."""
+        centre_idx (B,S) optionally injects the centres (tests, parity runs); pre = this level's workspace from
+        ops.group_pair (centres gathered and neighbours found ahead of time, together with the level above / below)."""
         if self.group_all:
             return ops.set_abstraction(xyz, points, None, None, True, self.training, self.convs, self.bns)
+        if pre is not None:
+            return ops.set_abstraction(xyz, points, centre_idx, self.nsample, False, self.training, self.convs, self.bns, pre=pre)
         if centre_idx is None:
             centre_idx = self._centres(xyz)
         nbr = None
@@ -78,6 +81,29 @@ class PointNetSetAbstraction(nn.Module):
             nbr = ops.ball_query(float(radius), self.nsample, xyz, new_xyz)
         return ops.set_abstraction(xyz, points, centre_idx, self.nsample, False, self.training, self.convs, self.bns,
                                    neighbour_idx=nbr)
+
+
+def stacked_levels(sa1, sa2, xyz, c1=None, c2=None):
+    """sa1 on the cloud, then sa2 on sa1's centres (the first two lines of every pointnet_pp_* forward, e.g.
+    models/pointnet_pp_vonMises.py:28-29) -> l1_xyz, l1_points, l2_xyz, l2_points.  When both levels group by kNN and both
+    centre draws are known before sa1 runs (injected, or any sampler but 'fps', whose second draw needs sa1's centres), the
+    two neighbour searches go out as ONE launch ahead of the MLPs (ops.group_pair); the draws happen in the reference's
+    order (all of sa1's, then all of sa2's), so the CPU generator's sequence is unchanged."""
+    pair_ok = (not sa1.group_all and not sa2.group_all and sa1.grouper == "knn" and sa2.grouper == "knn" and xyz.is_cuda
+               and (c1 is not None or sa1.sampler != "fps") and (c2 is not None or sa2.sampler != "fps")
+               and sa1.npoint <= xyz.shape[1] and sa2.npoint <= sa1.npoint and sa1.nsample <= xyz.shape[1] and sa2.nsample <= sa1.npoint)
+    if not pair_ok:
+        l1_xyz, l1_pts = sa1(xyz, None, c1)
+        l2_xyz, l2_pts = sa2(l1_xyz, l1_pts, c2)
+        return l1_xyz, l1_pts, l2_xyz, l2_pts
+    if c1 is None:
+        c1 = sa1._centres(xyz)
+    if c2 is None:
+        c2 = sa2._centres(xyz[:, :sa1.npoint])     # only the shape (B, npoint1, 3) enters a random draw
+    pre1, pre2 = ops.group_pair(xyz, c1, c2, sa1.nsample, sa1.convs, sa2.nsample, sa2.convs, training=sa1.training)
+    l1_xyz, l1_pts = sa1(xyz, None, c1, pre=pre1)
+    l2_xyz, l2_pts = sa2(l1_xyz, l1_pts, c2, pre=pre2)
+    return l1_xyz, l1_pts, l2_xyz, l2_pts
 
 
 # the 8 horizontal directions (0, 45, ... 315 degrees), clockwise from the canonical forward axis [0,0,-1]
@@ -112,17 +138,22 @@ class BackboneBNHead(nn.Module):
         self.bn2 = nn.BatchNorm1d(256)
         self.drop = nn.Dropout(0.5)
 
-    def trunk(self, xyz, centres=None, drop_mask=None):
-        """(B,N,3) -> (B,256): everything up to and including the dropout in front of the output layers.
-        centres = (sa1 centre indices, sa2 centre indices) and drop_mask (B,256) inject the random draws (parity runs)."""
+    def levels12(self, xyz, centres=None):
+        """sa1 + sa2 -> (l2_xyz, l2_points); centres = (sa1 centre indices, sa2 centre indices) injects the draws."""
         B = xyz.size(0)
         c1, c2 = centres if centres is not None else (None, None)
         if (centres is None and self.sa1.sampler == "device" and self.sa2.sampler == "device" and not self.sa1.group_all
                 and not self.sa2.group_all):
             # neither draw depends on data: both levels' centres from one launch (same centres as the per-level draws)
             c1, c2 = sampling.device_random_centres_pair(B, xyz.size(1), self.sa1.npoint, self.sa1.npoint, self.sa2.npoint, xyz.device)
-        l1_xyz, l1_pts = self.sa1(xyz, None, c1)
-        l2_xyz, l2_pts = self.sa2(l1_xyz, l1_pts, c2)
+        _, _, l2_xyz, l2_pts = stacked_levels(self.sa1, self.sa2, xyz, c1, c2)
+        return l2_xyz, l2_pts
+
+    def trunk(self, xyz, centres=None, drop_mask=None):
+        """(B,N,3) -> (B,256): everything up to and including the dropout in front of the output layers.
+        centres = (sa1 centre indices, sa2 centre indices) and drop_mask (B,256) inject the random draws (parity runs)."""
+        B = xyz.size(0)
+        l2_xyz, l2_pts = self.levels12(xyz, centres)
         _, l3_pts = self.sa3(l2_xyz, l2_pts)
         x = l3_pts.view(B, -1)
         x = ops.fc_block(x, self.fc1, self.bn1, relu=True, training=self.training)

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from pnpp_hip import ops
-from .pointnet_pp_8dir import PointNetSetAbstraction
+from .pointnet_pp_8dir import PointNetSetAbstraction, stacked_levels
 
 _BACKBONE = ((128, 32, 0, (64, 64, 128), False), (32, 32, 128, (128, 128, 256), False), (None, None, 256, (256, 512, 1024), True))
 
@@ -50,8 +50,7 @@ class PointNetPPMvM(nn.Module):
 
     def _global_feat(self, pts: torch.Tensor, centres=None, drop_masks=(None, None)) -> torch.Tensor:
         c1, c2 = centres if centres is not None else (None, None)
-        l1_xyz, l1_pts = self.sa1(pts, None, c1)
-        l2_xyz, l2_pts = self.sa2(l1_xyz, l1_pts, c2)
+        _, _, l2_xyz, l2_pts = stacked_levels(self.sa1, self.sa2, pts, c1, c2)
         feat = self.sa3(l2_xyz, l2_pts)[1].flatten(1)
         for fc, ln, mask in ((self.fc1, self.ln1, drop_masks[0]), (self.fc2, self.ln2, drop_masks[1])):
             feat = ops.fc_block(feat, fc, ln, relu=True, dropout=self.drop, training=self.training, mask=mask)

@@ -79,6 +79,7 @@ SIGNATURES = {
     "pnpp_sa_forward": (_i, [C.POINTER(SaDesc), C.POINTER(SaFwdArgs), _fp]),
     "pnpp_sa_backward": (_i, [C.POINTER(SaDesc), C.POINTER(SaBwdArgs), _fp]),
     "pnpp_sa_saved_neighbours": (_fp, [C.POINTER(SaDesc), _fp]),
+    "pnpp_sa_group_pair": (_i, [C.POINTER(SaDesc), C.POINTER(SaDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "pnpp_sa_saved_argmax": (_fp, [C.POINTER(SaDesc), _fp]),
     "pnpp_fc_saved_bytes": (_sz, [C.POINTER(FcDesc)]),
     "pnpp_fc_scratch_bytes": (_sz, [C.POINTER(FcDesc)]),

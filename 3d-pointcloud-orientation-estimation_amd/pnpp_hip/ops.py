@@ -268,7 +268,7 @@ class _SetAbstraction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, points, centre_idx, neighbour_idx, cfg, running, *params):
         # params: L x (conv_w, conv_b, bn_w, bn_b); running: L x (running_mean, running_var)
-        K, group_all, training, eps, momentum, sinks, nbt = cfg
+        K, group_all, training, eps, momentum, sinks, nbt, pre = cfg
         Lh = len(params) // 4
         xyz = _f32(xyz, "xyz")
         B, N, _ = xyz.shape
@@ -293,14 +293,21 @@ class _SetAbstraction(torch.autograd.Function):
         sb = lib.pnpp_sa_saved_bytes(C.byref(desc))
         if sb == 0:
             L.check(L.PNPP_ERR_ARG if L.last_error() else L.PNPP_ERR_ARG)
-        saved = torch.empty(sb, dtype=torch.uint8, device=xyz.device)
+        if pre is not None:   # grouped ahead of time (group_pair): neighbours and centres already sit in this call's workspace
+            saved, new_xyz = pre["saved"], pre["new_xyz"]
+            if saved.numel() != sb or tuple(new_xyz.shape) != (B, S, 3) or neighbour_idx is not None:
+                raise ValueError("set_abstraction: the pre-grouped workspace does not belong to this call")
+        else:
+            saved = torch.empty(sb, dtype=torch.uint8, device=xyz.device)
+            new_xyz = torch.empty(B, S, 3, device=xyz.device, dtype=torch.float32)
         scratch = _scratch(lib.pnpp_sa_scratch_bytes(C.byref(desc)), xyz.device)
-        new_xyz = torch.empty(B, S, 3, device=xyz.device, dtype=torch.float32)
         out = torch.empty(B, S, channels[-1], device=xyz.device, dtype=torch.float32)
         a = L.SaFwdArgs()
         a.xyz, a.points = xyz.data_ptr(), _p(points)
         a.centre_idx = None if group_all else centre_idx.data_ptr()
         a.neighbour_idx = _p(neighbour_idx)
+        if pre is not None:   # "already in place": the neighbour argument IS the workspace's own index block
+            a.neighbour_idx = lib.pnpp_sa_saved_neighbours(C.byref(desc), saved.data_ptr())
         a.conv_w, a.conv_b, a.bn_w, a.bn_b = _ptr_array(conv_w), _ptr_array(conv_b), _ptr_array(bn_w), _ptr_array(bn_b)
         a.bn_rm = _ptr_array([running[2 * l] for l in range(Lh)])
         a.bn_rv = _ptr_array([running[2 * l + 1] for l in range(Lh)])
@@ -360,8 +367,34 @@ class _SetAbstraction(torch.autograd.Function):
         return (None, dpoints, None, None, None, None, *grads)
 
 
+def group_pair(xyz, centre1, centre2, nsample1, convs1, nsample2, convs2, training=True):
+    """Centre gather + neighbour search of two stacked set-abstraction levels (sa1 on the cloud, sa2 on sa1's centres) in ONE
+    launch, ahead of both forward passes (models/pointnet_pp_8dir.py:28-31 of each level): level 2 searches among level 1's
+    centres, which are rows of the same cloud, so it does not wait for level 1's MLP.  centre1 (B,S1) rows of xyz, centre2
+    (B,S2) positions among level 1's centres.  Returns the two `pre=` workspaces for set_abstraction; the neighbour sets are
+    those the per-level search finds (same coordinates, same arithmetic)."""
+    xyz = _f32(xyz, "xyz")
+    B, N, _ = xyz.shape
+    c1, c2 = _i32(centre1, "centre_idx"), _i32(centre2, "centre_idx")
+    S1, S2 = c1.shape[1], c2.shape[1]
+    ch1, ch2 = [c.weight.shape[0] for c in convs1], [c.weight.shape[0] for c in convs2]
+    d1 = _sa_desc(B, N, S1, int(nsample1), 0, ch1, False, training, 1e-5, 0.1)
+    d2 = _sa_desc(B, S1, S2, int(nsample2), ch1[-1], ch2, False, training, 1e-5, 0.1)
+    lib = L.lib()
+    pres = []
+    for d, S in ((d1, S1), (d2, S2)):
+        sb = lib.pnpp_sa_saved_bytes(C.byref(d))
+        if sb == 0:
+            L.check(L.PNPP_ERR_ARG)
+        pres.append({"saved": torch.empty(sb, dtype=torch.uint8, device=xyz.device),
+                     "new_xyz": torch.empty(B, S, 3, device=xyz.device, dtype=torch.float32)})
+    L.check(lib.pnpp_sa_group_pair(C.byref(d1), C.byref(d2), xyz.data_ptr(), c1.data_ptr(), c2.data_ptr(), pres[0]["saved"].data_ptr(),
+                                   pres[0]["new_xyz"].data_ptr(), pres[1]["saved"].data_ptr(), pres[1]["new_xyz"].data_ptr(), _stream()))
+    return pres[0], pres[1]
+
+
 def set_abstraction(xyz, points, centre_idx, nsample, group_all, training, convs, bns, neighbour_idx=None,
-                    return_neighbours=False):
+                    return_neighbours=False, pre=None):
     """Functional form used by models.pointnet_pp_8dir.PointNetSetAbstraction.
 
     convs / bns are the nn.Conv2d / nn.BatchNorm2d containers (their tensors are used in place:
@@ -376,7 +409,7 @@ def set_abstraction(xyz, points, centre_idx, nsample, group_all, training, convs
     momentum = bns[0].momentum if bns[0].momentum is not None else 0.1
     sinks = [grad_sink(p) for p in params]
     nbt = [_nbt(bn) for bn in bns] if training else None   # bumped by the statistics kernels themselves
-    cfg = (nsample, bool(group_all), bool(training), eps, momentum, sinks if any(s is not None for s in sinks) else None, nbt)
+    cfg = (nsample, bool(group_all), bool(training), eps, momentum, sinks if any(s is not None for s in sinks) else None, nbt, pre)
     new_xyz, out, nbr = _SetAbstraction.apply(xyz, points, centre_idx, neighbour_idx, cfg, running, *params)
     if return_neighbours:
         return new_xyz, out, (None if group_all else nbr)

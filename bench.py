@@ -80,9 +80,7 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
         return tail(model.trunk(x), m, k)
 
     def stage1(x, m, k):
-        l1_xyz, l1_pts = model.sa1(x, None)
-        l2_xyz, l2_pts = model.sa2(l1_xyz, l1_pts)
-        return l2_xyz, l2_pts
+        return model.levels12(x)
 
     def stage2(l2_xyz, l2_pts):
         _, l3 = model.sa3(l2_xyz, l2_pts)

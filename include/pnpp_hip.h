@@ -160,6 +160,14 @@ size_t pnpp_sa_saved_bytes(const pnpp_sa_desc *d);
 size_t pnpp_sa_scratch_bytes(const pnpp_sa_desc *d);
 int pnpp_sa_forward(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, void *stream);
 int pnpp_sa_backward(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, void *stream);
+/* Grouping of two stacked levels ahead of their forward passes, in ONE launch (models/pointnet_pp_8dir.py:28-31 of sa1 and of
+ * sa2: index_points + query_ball_point twice).  Level 2 searches among level 1's centres, which are rows of the same cloud, so
+ * once both levels' centre indices are drawn neither search waits for anything: d1 / d2 describe the two levels (d2->N == d1->S),
+ * centre1 (B,S1) rows of xyz, centre2 (B,S2) positions among level 1's centres.  Writes the neighbour indices and centre
+ * coordinates into saved1 / saved2 (sized by pnpp_sa_saved_bytes) and new_xyz1 (B,S1,3) / new_xyz2 (B,S2,3); pnpp_sa_forward then
+ * takes them as already grouped when its neighbour_idx argument IS pnpp_sa_saved_neighbours(d, saved) (and new_xyz is that buffer). */
+int pnpp_sa_group_pair(const pnpp_sa_desc *d1, const pnpp_sa_desc *d2, const float *xyz, const int32_t *centre1,
+                       const int32_t *centre2, void *saved1, float *new_xyz1, void *saved2, float *new_xyz2, void *stream);
 /* read-only view of the neighbour indices kept in `saved` ((B,S,K) int32; NULL when group_all) */
 const int32_t *pnpp_sa_saved_neighbours(const pnpp_sa_desc *d, const void *saved);
 /* read-only view of the max-pool routing kept in `saved`: (B*S, C_last) int32, the position 0..K-1 inside its group of the

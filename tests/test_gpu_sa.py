@@ -221,3 +221,49 @@ def test_sa_layer0_convolved_before_the_gather(oracle, c0, npoint, nsample, n):
         if name.startswith("convs") and name.endswith("bias"):
             continue
         assert _rel(p.grad.cpu(), P["sa." + name].grad.reshape(p.shape)) < 5e-5, name
+
+
+@pytest.mark.parametrize("B,N,S1,K1,S2,K2", [(32, 1024, 128, 32, 32, 32), (3, 777, 96, 24, 40, 16), (2, 2048, 128, 32, 32, 32)])
+def test_two_levels_grouped_in_one_launch_equal_the_per_level_path(B, N, S1, K1, S2, K2):
+    """ops.group_pair (pnpp_sa_group_pair): the centre gathers and neighbour searches of sa1 and sa2 as ONE launch ahead of both
+    MLPs -- level 2 searches among level 1's centres, rows of the same cloud -- must give, bit for bit, what the two
+    per-level searches give (models/pointnet_pp_8dir.py:28-31 twice): neighbour indices, centre coordinates, both outputs and
+    the gradients that flow back through them."""
+    from models.pointnet_pp_8dir import PointNetSetAbstraction, stacked_levels
+    from pnpp_hip import ops
+    torch.manual_seed(3)
+    sa1 = PointNetSetAbstraction(S1, K1, 0, [32, 32, 64]).cuda().train()
+    sa2 = PointNetSetAbstraction(S2, K2, 64, [64, 64, 128]).cuda().train()
+    g = torch.Generator().manual_seed(N)
+    xyz = (torch.rand(B, N, 3, generator=g) * 2 - 1).cuda()
+    c1 = torch.stack([torch.randperm(N, generator=g)[:S1] for _ in range(B)]).cuda()
+    c2 = torch.stack([torch.randperm(S1, generator=g)[:S2] for _ in range(B)]).cuda()
+
+    def run(paired):
+        for m in (sa1, sa2):
+            m.zero_grad()
+        ops.sa_tap = []
+        try:
+            if paired:
+                l1_xyz, l1, l2_xyz, l2 = stacked_levels(sa1, sa2, xyz, c1, c2)
+            else:
+                l1_xyz, l1 = sa1(xyz, None, c1)
+                l2_xyz, l2 = sa2(l1_xyz, l1, c2)
+            taps = [{k: (v.clone() if v is not None else None) for k, v in t.items()} for t in ops.sa_tap]
+        finally:
+            ops.sa_tap = None
+        (l2 * torch.linspace(-1, 1, l2.numel(), device=l2.device).view_as(l2)).sum().backward()
+        grads = [p.grad.clone() for m in (sa1, sa2) for p in m.parameters()]
+        return l1_xyz, l1, l2_xyz, l2, taps, grads
+
+    sd = [{k: v.clone() for k, v in m.state_dict().items()} for m in (sa1, sa2)]
+    a = run(False)
+    for m, s in zip((sa1, sa2), sd):
+        m.load_state_dict(s)
+    b = run(True)
+    for i in range(4):
+        assert torch.equal(a[i], b[i]), i
+    for ta, tb in zip(a[4], b[4]):
+        assert torch.equal(ta["neighbours"], tb["neighbours"]) and torch.equal(ta["argmax"], tb["argmax"])
+    for ga, gb in zip(a[5], b[5]):
+        assert torch.equal(ga, gb)
