@@ -13,9 +13,21 @@
 // MFMA operand maps (wave64, 32x32x2 f32):  A: lane l holds A[i=l&31][k=l>>5]
 //                                           B: lane l holds B[k=l>>5][j=l&31]
 //                                           D: lane l, reg r: col j=l&31, row i=(r&3)+8*(r>>2)+4*(l>>5)
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace pnpp {
+
+// A/B switch read once per process (PNPP_NO_MID=1: the group_all level stays on the 32 x 32 split-K kernels)
+static bool mid_tiles_on() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char *v = getenv("PNPP_NO_MID");
+        cached = (v && atoi(v) != 0) ? 0 : 1;
+    }
+    return cached != 0;
+}
 
 constexpr int KC = 32;       // reduction-dim chunk staged in LDS per step
 constexpr int APITCH = KC + 1;  // odd pitch: the 32 rows a half-wave reads land on 32 different banks
@@ -525,6 +537,19 @@ __device__ int g_stamp_kd;
 #ifndef PNPP_WS_POOL_PREFETCH   // pooled-gradient / arg-max entries of the NEXT tile requested before this tile's stores
 #define PNPP_WS_POOL_PREFETCH 1
 #endif
+// timing experiments only (results are WRONG with either on; never in a shipped build): what is left of a launch without its
+// matrix instructions, or without its output stores
+#ifndef PNPP_WS_EXP_NO_MFMA
+#define PNPP_WS_EXP_NO_MFMA 0
+#endif
+#ifndef PNPP_WS_EXP_NO_STORE
+#define PNPP_WS_EXP_NO_STORE 0
+#endif
+#if PNPP_WS_EXP_NO_MFMA
+#define PNPP_WS_MFMA(a, b, c) ((c)[0] += (a) + (b), (c))
+#else
+#define PNPP_WS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#endif
 template <int KD, int BM, int BN, int WM, int WN, int AMODE, int EMODE, bool FDW>
 __global__ void __launch_bounds__(256, (KD >= 256 ? 1 : 2))  // the K=256 panels leave room for one workgroup per CU anyway
 gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, const Epilogue E) {
@@ -1010,10 +1035,10 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < NT; ++j) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][c][i].x, rb[buf][c][j].x, acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][c][i].y, rb[buf][c][j].y, acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][c][i].z, rb[buf][c][j].z, acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][c][i].w, rb[buf][c][j].w, acc[i][j], 0, 0, 0);
+                            acc[i][j] = PNPP_WS_MFMA(ra[buf][c][i].x, rb[buf][c][j].x, acc[i][j]);
+                            acc[i][j] = PNPP_WS_MFMA(ra[buf][c][i].y, rb[buf][c][j].y, acc[i][j]);
+                            acc[i][j] = PNPP_WS_MFMA(ra[buf][c][i].z, rb[buf][c][j].z, acc[i][j]);
+                            acc[i][j] = PNPP_WS_MFMA(ra[buf][c][i].w, rb[buf][c][j].w, acc[i][j]);
                         }
             };
             if constexpr (FDW && NT > 1) {  // no second operand buffer: the fused dW instantiations with two column tiles per
@@ -1097,7 +1122,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                         for (int i = 0; i < MT; ++i)
     #pragma unroll
                             for (int j = 0; j < NT; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[buf][u][i], rb[buf][u][j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = PNPP_WS_MFMA(ra[buf][u][i], rb[buf][u][j], acc[i][j]);
                 };
                 ld(0, 0);
     #pragma unroll 1
@@ -1130,7 +1155,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                         for (int r = 0; r < 16; ++r) {
                             const float v = acc[i][j][r];
                             float *tr = tb + (size_t)((r & 3) + 8 * (r >> 2)) * E.ldc;
-                            tr[lo] = v;
+                            if (!PNPP_WS_EXP_NO_STORE) tr[lo] = v;
                             t1 += v;
                             t2 = fmaf(v, v, t2);
                         }
@@ -1157,7 +1182,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                             const float a0 = fmaf(z0, sc, sh);
                             const float v = a0 > 0.f ? acc[i][j][r] : 0.f;
                             float *tr = tb + (size_t)((r & 3) + 8 * (r >> 2)) * E.ldc;
-                            tr[lo] = v;
+                            if (!PNPP_WS_EXP_NO_STORE) tr[lo] = v;
                             t1 += v;
                             t2 = fmaf(v, (z0 - mu) * is, t2);
                             if constexpr (FDW) apb[((r & 3) + 8 * (r >> 2)) * BN] = fmaxf(a0, 0.f);
@@ -1236,7 +1261,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                 for (int c = 0; c < MC; ++c)
 #pragma unroll
                     for (int t = 0; t < DT; ++t)
-                        dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[buf][c][t], db[buf][c], dwacc[t], 0, 0, 0);
+                        dwacc[t] = PNPP_WS_MFMA(da[buf][c][t], db[buf][c], dwacc[t]);
             };
             if constexpr (KD >= PNPP_WS_DWTABLE_MINK || TUNED_128) {
                 // one wave per SIMD here, registers to spare: the swizzled operand addresses of the eight F values are a table
@@ -1748,6 +1773,7 @@ int launch_gemm(const AOperand &A, const BOperand &Bin, int M, int Nout, int Kd,
         int rc = PNPP_OK;
         if (try_launch_ws_bf16(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;   // only in the opt-in bf16-operand mode
         if (try_launch_ws(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;
+        if (mid_tiles_on() && try_launch_mid_gemm(A, B, M, Nout, Kd, E, nslab, st, &rc)) return rc;
     }
     const bool a_aligned = (A.mode == A_CONCAT || A.mode == A_GATHER) || (A.lda % 4 == 0 && ((uintptr_t)A.a & 15) == 0);
     if (M <= 4096 && cdiv(M, 32) <= kMaxStatBlocks && a_aligned && A.mode != A_GATHER) {
@@ -2427,8 +2453,11 @@ bool try_launch_fc_dx_dw(const float *dz, const float *w, const float *x, int M,
 // dA (+ its epilogue) and dW of one small-M backward layer in one launch; returns false (nothing launched) when the
 // pair does not fit that form, and the caller launches the two separately.
 bool try_launch_da_dw(const AOperand &dz, const BOperand &Win, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,
-                      int Kp, float *slab, int nsplit, int kp_pad, hipStream_t st, int *rc) {
+                      int Kp, float *slab, int *nsplit_io, int *kp_pad_io, hipStream_t st, int *rc) {
     *rc = PNPP_OK;
+    if (mid_tiles_on() && try_launch_mid_da_dw(dz, Win, M, Nout, Kd, E, nslab, a2, Kp, slab, nsplit_io, kp_pad_io, st, rc))
+        return true;   // wide layers of a group_all level: 64 x 64 tiles over the whole reduction, no 64-row partials
+    const int nsplit = *nsplit_io, kp_pad = *kp_pad_io;
     const int Nc = Kd;  // dZ is M x Nc; dA = dZ W contracts over Nc, dW is Nc x Kp
     if (!(M > 32 && M <= 4096 && cdiv(M, 32) <= kMaxStatBlocks && dz.mode == A_PLAIN && (dz.lda & 3) == 0 && ((uintptr_t)dz.a & 15) == 0))
         return false;

@@ -1,0 +1,367 @@
+// gemm_mid_kernels.hip -- the group_all level's wide layers (M = 32 * batch rows, K and N in the hundreds): 64 x 64 output tiles,
+// one per workgroup, 64-deep reduction chunks double-buffered through LDS.
+//
+// Reference: models/pointnet_pp_8dir.py:23-26,40-42 (the group_all PointNetSetAbstraction: 1 x 1 conv -> BatchNorm -> ReLU on
+// B x 32 rows) and its autograd backward (dA = dZ W, dW = dZ^T a).
+//
+// Why a third GEMM form.  The weights-stationary kernel needs tens of thousands of rows to amortise its panel; the 32 x 32 split-K
+// kernel (gemm_smallm_kernel) re-reads both operands from L2 once per 32 x 32 tile -- 131 MB of L2 reads for the 512 -> 1024 layer
+// of a 1,024-row level, 0.33 of the float32 MFMA roof -- and the 128 x 128 dW blocks it was paired with went out as sixteen 64-row
+// splits whose partial sums were 7.5 x the launch's compulsory HBM traffic.  Here a workgroup owns a 64 x 64 tile over the WHOLE
+// reduction (no partial sums at all for dA and the forward product, at most two row ranges for dW), a tile's operands are read
+// from L2 once per 64 x 64 outputs, and the loop is  [MFMAs of chunk c | LDS image of chunk c+1 from registers | global loads
+// of chunk c+2] with ONE barrier per chunk.
+//
+// Operand images.  Every operand tile is 64 rows x 64 contiguous floats of a row-major matrix, fetched as four 16-byte loads per
+// thread (thread -> column group tid % 16, rows tid / 16 + 16 i).  What differs is how an MFMA consumes it:
+//   row operand   (MFMA index = tile row, reduction = tile column): pitch 68 floats, lane (l31, lh) reads k = 8 t + 4 lh + {0..3}
+//                 of its row with one ds_read_b128 per four MFMA steps (eight lanes of a read cycle land on eight different
+//                 4-bank groups: 68 r mod 32 = 4 r);
+//   column operand (MFMA index = tile column, reduction = tile row): pitch 64, one conflict-free ds_read_b32 per MFMA step
+//                 (32 consecutive floats per half-wave).
+// forward  Z = a W^T : a row operand, W [n][k] row operand.     dA = dZ W : dZ row operand, W [k][n] column operand.
+// dW = dZ^T a        : both column operands (reduction over rows).
+// Both operands of an MFMA step must carry the same reduction index in the same lane half; k(t, lh, u) = 8 t + 4 lh + u for all.
+#include "kernels.h"
+
+namespace pnpp {
+
+constexpr int MID_T = 64;            // tile edge and chunk depth
+constexpr int MID_RP = 68;           // pitch of a row-operand image
+constexpr int MID_IMG = MID_T * MID_RP;          // floats per operand image (column operands use the first 64 * 64)
+constexpr int MID_STAGE = 2 * MID_IMG;           // A image + B image
+constexpr size_t MID_LDS_BYTES = (size_t)2 * MID_STAGE * sizeof(float);   // two stages: 69,632 bytes
+
+struct MidGemm {
+    const float *a;      // [M][K] activations (row operand)
+    int lda;
+    const float *scale, *shift;   // A_BNRELU: per reduction index
+    const float *b;      // weights: BT ? [N][K] : [K][N]
+    int ldb;
+    int M, N, K;
+    Epilogue E;
+};
+
+struct MidDw {
+    const float *dz;     // [M][Nc]
+    int ldz;
+    const float *a2;     // [M][Kp]
+    int lda2;
+    const float *scale, *shift;   // A_BNRELU on a2: per column of a2
+    int M, Nc, Kp;
+    int nsplit, rps;     // row ranges (multiples of 64)
+    float *out;          // [nsplit][Nc][ldo]
+    int ldo;
+};
+
+// ---- C tile (64 x 64) = a'[64 x K] * W, one workgroup --------------------------------------------------------------------
+template <int AX, bool BT, int EM>
+__device__ __forceinline__ void mid_gemm_tile(const MidGemm &G, const int tm, const int tn, float *__restrict__ lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int q4 = 4 * (tid & 15), rb = tid >> 4;
+    const int m0 = tm * MID_T, n0 = tn * MID_T, nc = G.K / MID_T;
+    const Epilogue &E = G.E;
+
+    float4 ra[4], rw[4], sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *pa = G.a + (size_t)(m0 + rb) * G.lda + q4;
+    const float *pw = BT ? G.b + (size_t)(n0 + rb) * G.ldb + q4 : G.b + (size_t)rb * G.ldb + n0 + q4;
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const float4 *>(pa + (size_t)(16 * i) * G.lda + c * MID_T);
+            rw[i] = BT ? *reinterpret_cast<const float4 *>(pw + (size_t)(16 * i) * G.ldb + c * MID_T)
+                       : *reinterpret_cast<const float4 *>(pw + (size_t)(c * MID_T + 16 * i) * G.ldb);
+        }
+        if constexpr (AX == A_BNRELU) {
+            sc = *reinterpret_cast<const float4 *>(G.scale + c * MID_T + q4);
+            sh = *reinterpret_cast<const float4 *>(G.shift + c * MID_T + q4);
+        }
+    };
+    auto lstore = [&](int stage) {
+        float *As = lds + stage * MID_STAGE, *Bs = As + MID_IMG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = ra[i];
+            if constexpr (AX == A_BNRELU) {
+                v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+                v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f), v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+            }
+            *reinterpret_cast<float4 *>(As + (rb + 16 * i) * MID_RP + q4) = v;
+            *reinterpret_cast<float4 *>(Bs + (rb + 16 * i) * (BT ? MID_RP : MID_T) + q4) = rw[i];
+        }
+    };
+
+    // E_MASK_STATS reads the previous layer's z at the output positions: requested while the last chunk is being multiplied
+    float zp[16];
+    float e_sc = 0.f, e_sh = 0.f, e_mu = 0.f, e_is = 0.f;
+    const int col = n0 + wn * 32 + l31;
+    if constexpr (EM == E_MASK_STATS) e_sc = E.scale[col], e_sh = E.shift[col], e_mu = E.mu[col], e_is = E.istd[col];
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    gload(0);
+    lstore(0);
+    if (nc > 1) gload(1);
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+        const float *As = lds + (c & 1) * MID_STAGE, *Bs = As + MID_IMG;
+        if constexpr (EM == E_MASK_STATS) {
+            if (c == nc - 1) {
+                const float *pz = E.zp + (size_t)(m0 + wm * 32 + 4 * lh) * E.ldc + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zp[r] = pz[(size_t)((r & 3) + 8 * (r >> 2)) * E.ldc];
+            }
+        }
+        const float *arow = As + (wm * 32 + l31) * MID_RP + 4 * lh;
+        const float *brow = BT ? Bs + (wn * 32 + l31) * MID_RP + 4 * lh : Bs + (4 * lh) * MID_T + wn * 32 + l31;
+        float4 fa[2], fb[2];
+        auto ld = [&](int buf, int t) {
+            fa[buf] = *reinterpret_cast<const float4 *>(arow + 8 * t);
+            if constexpr (BT) {
+                fb[buf] = *reinterpret_cast<const float4 *>(brow + 8 * t);
+            } else {
+                const float *p = brow + 8 * t * MID_T;
+                fb[buf] = make_float4(p[0], p[MID_T], p[2 * MID_T], p[3 * MID_T]);
+            }
+        };
+        auto mm = [&](int buf) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].x, fb[buf].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].y, fb[buf].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].z, fb[buf].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].w, fb[buf].w, acc, 0, 0, 0);
+        };
+        ld(0, 0);
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) {
+            ld(1, t + 1);
+            mm(0);
+            if (t + 2 < 8) ld(0, t + 2);
+            mm(1);
+        }
+        if (c + 1 < nc) lstore((c + 1) & 1);   // the registers hold chunk c + 1 (requested one iteration ago)
+        if (c + 2 < nc) gload(c + 2);
+        __syncthreads();
+    }
+
+    // epilogue: a lane holds 16 rows of one column; a half-wave store is 32 consecutive floats
+    float *tb = E.c + (size_t)(m0 + wm * 32 + 4 * lh) * E.ldc + col;
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = acc[r];
+        if constexpr (EM == E_STORE_STATS) {
+            t1 += v;
+            t2 = fmaf(v, v, t2);
+        } else if constexpr (EM == E_MASK_STATS) {
+            const float z0 = zp[r];
+            v = fmaf(z0, e_sc, e_sh) > 0.f ? v : 0.f;
+            t1 += v;
+            t2 = fmaf(v, (z0 - e_mu) * e_is, t2);
+        }
+        tb[(size_t)((r & 3) + 8 * (r >> 2)) * E.ldc] = v;
+    }
+    if constexpr (EM != E_STORE) {
+        // column sums of the tile: the two row halves of a wave, then the two waves of a column, in fixed order
+        double *red = reinterpret_cast<double *>(lds);   // [2 wm][2][64]; every operand read of the last chunk is behind the barrier
+        const double a = (double)t1 + shfl_xor_f64((double)t1, 32), b = (double)t2 + shfl_xor_f64((double)t2, 32);
+        if (lh == 0) red[(wm * 2 + 0) * MID_T + wn * 32 + l31] = a, red[(wm * 2 + 1) * MID_T + wn * 32 + l31] = b;
+        __syncthreads();
+        if (tid < 2 * MID_T) {
+            const int which = tid >> 6, cl = tid & 63;
+            E.slab[((size_t)tm * 2 + which) * G.N + n0 + cl] = red[(0 * 2 + which) * MID_T + cl] + red[(1 * 2 + which) * MID_T + cl];
+        }
+    }
+}
+
+// ---- dW tile (64 x 64) = dZ^T a2 over one row range, one workgroup -------------------------------------------------------
+template <int A2X>
+__device__ __forceinline__ void mid_dw_tile(const MidDw &D, const int tc, const int tk, const int split, float *__restrict__ lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5, wc = wave >> 1, wk = wave & 1;
+    const int q4 = 4 * (tid & 15), rb = tid >> 4;
+    const int c0 = tc * MID_T, k0 = tk * MID_T;
+    const int r0 = split * D.rps, r1 = min(D.M, r0 + D.rps), nc = (r1 - r0) / MID_T;
+
+    float4 rd[4], ra[4], sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (A2X == A_BNRELU) {   // this thread's four a2 columns never change
+        sc = *reinterpret_cast<const float4 *>(D.scale + k0 + q4);
+        sh = *reinterpret_cast<const float4 *>(D.shift + k0 + q4);
+    }
+    const float *pd = D.dz + (size_t)(r0 + rb) * D.ldz + c0 + q4, *pa = D.a2 + (size_t)(r0 + rb) * D.lda2 + k0 + q4;
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rd[i] = *reinterpret_cast<const float4 *>(pd + (size_t)(c * MID_T + 16 * i) * D.ldz);
+            ra[i] = *reinterpret_cast<const float4 *>(pa + (size_t)(c * MID_T + 16 * i) * D.lda2);
+        }
+    };
+    auto lstore = [&](int stage) {
+        float *Ds = lds + stage * MID_STAGE, *As = Ds + MID_IMG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = ra[i];
+            if constexpr (A2X == A_BNRELU) {
+                v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+                v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f), v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+            }
+            *reinterpret_cast<float4 *>(Ds + (rb + 16 * i) * MID_T + q4) = rd[i];
+            *reinterpret_cast<float4 *>(As + (rb + 16 * i) * MID_T + q4) = v;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (nc > 0) {
+        gload(0);
+        lstore(0);
+        if (nc > 1) gload(1);
+    }
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+        const float *Ds = lds + (c & 1) * MID_STAGE, *As = Ds + MID_IMG;
+        const float *dcol = Ds + lh * MID_T + wc * 32 + l31, *acol = As + lh * MID_T + wk * 32 + l31;
+        float fd[2][4], fa[2][4];
+        auto ld = [&](int buf, int s4) {   // four reduction steps: rows 2 (4 s4 + u) + lh
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                fd[buf][u] = dcol[(8 * s4 + 2 * u) * MID_T];
+                fa[buf][u] = acol[(8 * s4 + 2 * u) * MID_T];
+            }
+        };
+        auto mm = [&](int buf) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[buf][u], fa[buf][u], acc, 0, 0, 0);
+        };
+        ld(0, 0);
+#pragma unroll
+        for (int s4 = 0; s4 < 8; s4 += 2) {
+            ld(1, s4 + 1);
+            mm(0);
+            if (s4 + 2 < 8) ld(0, s4 + 2);
+            mm(1);
+        }
+        if (c + 1 < nc) lstore((c + 1) & 1);
+        if (c + 2 < nc) gload(c + 2);
+        __syncthreads();
+    }
+    float *o = D.out + ((size_t)split * D.Nc + c0 + wc * 32 + 4 * lh) * D.ldo + k0 + wk * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * D.ldo] = acc[r];
+}
+
+// ---- kernels ---------------------------------------------------------------------------------------------------------------
+template <int AX, bool BT, int EM>
+__global__ void __launch_bounds__(256) gemm_mid_kernel(const MidGemm G, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // XCD-aware order: the eight workgroups that share an XCD's L2 (b, b + 8, ...) take neighbouring column tiles of one row block
+    mid_gemm_tile<AX, BT, EM>(G, blockIdx.x / tiles_n, blockIdx.x % tiles_n, lds);
+}
+
+// dA (+ ReLU mask and BatchNorm-backward sums) and dW of one backward layer only share dZ: one launch, the first g1 workgroups
+// take the dA tiles, the rest the dW tiles
+template <int EM, int A2X>
+__global__ void __launch_bounds__(256) da_dw_mid_kernel(const MidGemm G, int tiles_n, int g1, const MidDw D, int tiles_c, int tiles_k) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x < g1) {
+        mid_gemm_tile<A_PLAIN, false, EM>(G, blockIdx.x / tiles_n, blockIdx.x % tiles_n, lds);
+    } else {
+        const int b = blockIdx.x - g1, per = tiles_c * tiles_k;
+        mid_dw_tile<A2X>(D, (b % per) / tiles_k, (b % per) % tiles_k, b / per, lds);
+    }
+}
+
+static bool mid_ptr_ok(const float *p, int ld) { return p && (ld & 3) == 0 && ((uintptr_t)p & 15) == 0; }
+
+template <typename K>
+static void mid_grant_lds(K kfn) {
+    static bool done = false;   // per instantiation
+    if (!done) {
+        (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MID_LDS_BYTES);
+        done = true;
+    }
+}
+
+// forward product of a group_all layer: Z = relu(bn(z_prev)) W^T (+ column statistics).  false: the shape stays on the 32 x 32 kernel.
+bool try_launch_mid_gemm(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st,
+                         int *rc) {
+    *rc = PNPP_OK;
+    if (M < 512 || M > 8192 || M % MID_T || Nout % MID_T || Kd % MID_T) return false;
+    if ((M / MID_T) * (Nout / MID_T) < 192) return false;   // fewer tiles than compute units: many small workgroups win
+    if (!(A.mode == A_PLAIN || A.mode == A_BNRELU) || !B.trans || B.perm_D >= 0 || B.rows != Kd) return false;
+    if (!(E.mode == E_STORE || E.mode == E_STORE_STATS)) return false;
+    if (!mid_ptr_ok(A.a, A.lda) || !mid_ptr_ok(B.b, B.ldb) || !mid_ptr_ok(E.c, E.ldc)) return false;
+    if (M / MID_T > kMaxStatBlocks) return false;
+    MidGemm G{A.a, A.lda, A.scale, A.shift, B.b, B.ldb, M, Nout, Kd, E};
+    const int tn = Nout / MID_T, grid = (M / MID_T) * tn;
+    if (nslab) *nslab = M / MID_T;
+    ProfScope ps(st, "gemm_mid_kernel<A%d,E%d,T1> M=%d N=%d K=%d grid=%d", A.mode, E.mode, M, Nout, Kd, grid);
+#define PNPP_MID(AX, EMV)                                                                              \
+    {                                                                                                  \
+        mid_grant_lds(gemm_mid_kernel<AX, true, EMV>);                                                 \
+        hipLaunchKernelGGL((gemm_mid_kernel<AX, true, EMV>), dim3(grid), dim3(256), MID_LDS_BYTES, st, G, tn); \
+    }
+    if (A.mode == A_BNRELU) {
+        if (E.mode == E_STORE_STATS) PNPP_MID(A_BNRELU, E_STORE_STATS) else PNPP_MID(A_BNRELU, E_STORE)
+    } else {
+        if (E.mode == E_STORE_STATS) PNPP_MID(A_PLAIN, E_STORE_STATS) else PNPP_MID(A_PLAIN, E_STORE)
+    }
+#undef PNPP_MID
+    if (hipGetLastError() != hipSuccess) {
+        set_error("gemm_mid: launch failed");
+        *rc = PNPP_ERR_LAUNCH;
+    }
+    return true;
+}
+
+// rows per dW partial for the paired launch (a multiple of 64); the caller sizes the slab for *nsplit partials of Nc x Kp
+bool mid_da_dw_plan(int M, int Nout, int Nc, int Kp, int *nsplit) {
+    if (M < 512 || M > 8192 || M % MID_T || Nout % MID_T || Nc % MID_T || Kp % MID_T) return false;
+    const int ta = (M / MID_T) * (Nout / MID_T), tw = (Nc / MID_T) * (Kp / MID_T);
+    if (ta + tw < 192) return false;
+    // the dA tiles run the whole reduction (Nc / 64 chunks); a dW tile runs M / 64 chunks per split: balance the two
+    int s = 1;
+    while (s < 4 && (M / MID_T) / (2 * s) >= (Nc / MID_T) && (M / (2 * s)) % MID_T == 0) s *= 2;
+    *nsplit = s;
+    return true;
+}
+
+bool try_launch_mid_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,
+                          int Kp, float *slab, int *nsplit_out, int *kp_pad_out, hipStream_t st, int *rc) {
+    *rc = PNPP_OK;
+    const int Nc = Kd;
+    int nsplit = 1;
+    if (!mid_da_dw_plan(M, Nout, Nc, Kp, &nsplit)) return false;
+    if (dz.mode != A_PLAIN || W.trans || W.perm_D >= 0 || (W.rows > 0 && W.rows != Kd)) return false;
+    if (!(E.mode == E_STORE || E.mode == E_MASK_STATS) || !(a2.mode == A_PLAIN || a2.mode == A_BNRELU)) return false;
+    if (!mid_ptr_ok(dz.a, dz.lda) || !mid_ptr_ok(W.b, W.ldb) || !mid_ptr_ok(E.c, E.ldc) || !mid_ptr_ok(a2.a, a2.lda) || !slab) return false;
+    if (E.mode == E_MASK_STATS && !mid_ptr_ok(E.zp, E.ldc)) return false;
+    if (M / MID_T > kMaxStatBlocks) return false;
+    MidGemm G{dz.a, dz.lda, nullptr, nullptr, W.b, W.ldb, M, Nout, Kd, E};
+    MidDw D{dz.a, dz.lda, a2.a, a2.lda, a2.scale, a2.shift, M, Nc, Kp, nsplit, M / nsplit, slab, Kp};
+    const int tn = Nout / MID_T, g1 = (M / MID_T) * tn, tc = Nc / MID_T, tk = Kp / MID_T, g2 = tc * tk * nsplit;
+    if (nslab) *nslab = M / MID_T;
+    *nsplit_out = nsplit, *kp_pad_out = Kp;
+    ProfScope ps(st, "da_dw_mid_kernel<E%d,A%d> M=%d | dA N=%d K=%d grid=%d | dW N=%d K=%d split=%d grid=%d", E.mode, a2.mode, M, Nout, Kd, g1,
+                 Nc, Kp, nsplit, g2);
+#define PNPP_MIDP(EMV, AX)                                                                                         \
+    {                                                                                                              \
+        mid_grant_lds(da_dw_mid_kernel<EMV, AX>);                                                                  \
+        hipLaunchKernelGGL((da_dw_mid_kernel<EMV, AX>), dim3(g1 + g2), dim3(256), MID_LDS_BYTES, st, G, tn, g1, D, tc, tk); \
+    }
+    if (E.mode == E_STORE) {
+        if (a2.mode == A_BNRELU) PNPP_MIDP(E_STORE, A_BNRELU) else PNPP_MIDP(E_STORE, A_PLAIN)
+    } else {
+        if (a2.mode == A_BNRELU) PNPP_MIDP(E_MASK_STATS, A_BNRELU) else PNPP_MIDP(E_MASK_STATS, A_PLAIN)
+    }
+#undef PNPP_MIDP
+    if (hipGetLastError() != hipSuccess) {
+        set_error("da_dw_mid: launch failed");
+        *rc = PNPP_ERR_LAUNCH;
+    }
+    return true;
+}
+
+}  // namespace pnpp

@@ -124,8 +124,14 @@ int launch_dw_xyz(const AOperand &dz, int Nc, const AOperand &a2, int M, float *
 // out[c][perm(k)] = sum_s slab[s][c][k]; perm_D < 0: identity; else feature-first -> xyz-first column order.
 bool try_launch_fc_dx_dw(const float *dz, const float *w, const float *x, int M, int N, int K, float *dx, float *dw, hipStream_t st,
                          int *rc);
+// *nsplit / *kp_pad: in = what dw_plan chose (the slab is sized for it); out = the partial count and pitch actually written
 bool try_launch_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,
-                      int Kp, float *slab, int nsplit, int kp_pad, hipStream_t st, int *rc);
+                      int Kp, float *slab, int *nsplit, int *kp_pad, hipStream_t st, int *rc);
+// gemm_mid_kernels.hip: 64 x 64 tiles over the whole reduction for the group_all level's wide layers
+bool try_launch_mid_gemm(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st,
+                         int *rc);
+bool try_launch_mid_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,
+                          int Kp, float *slab, int *nsplit_out, int *kp_pad_out, hipStream_t st, int *rc);
 int launch_slab_reduce2(const float *slab1, int nsplit1, int Nc1, int kp_pad1, int Kvalid1, float *out1, int ldo1, const float *slab2,
                         int nsplit2, int Nc2, int kp_pad2, int Kvalid2, float *out2, int ldo2, hipStream_t st);
 int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kvalid, int perm_D, float *out, int ldo,

@@ -412,7 +412,7 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             W.ldb = d->C[l - 1];
             W.rows = C;
             int dw_slabs = 0, rc = PNPP_OK;
-            if (try_launch_da_dw(dz, W, g.M, d->C[l - 1], C, E, &nslab_next, a2, g.Cin[l], sc.dwslab, nsplit, kp_pad, st, &rc)) {
+            if (try_launch_da_dw(dz, W, g.M, d->C[l - 1], C, E, &nslab_next, a2, g.Cin[l], sc.dwslab, &nsplit, &kp_pad, st, &rc)) {
                 PNPP_TRY(rc);  // small-M level: dA and dW of this layer went out as one launch
                 pair_done = true;
             } else {
@@ -443,7 +443,7 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
                 W.ldb = g.Cin[0];
                 W.rows = C;
                 int rc = PNPP_OK;
-                paired = try_launch_da_dw(G, W, R, d->D, C, E, nullptr, F, d->D, sc.dwslab, nsplit, kp_pad, st, &rc);
+                paired = try_launch_da_dw(G, W, R, d->D, C, E, nullptr, F, d->D, sc.dwslab, &nsplit, &kp_pad, st, &rc);
                 if (paired) PNPP_TRY(rc);
             }
             if (!paired) PNPP_TRY(launch_dw(G, C, F, d->D, R, sc.dwslab, nsplit, kp_pad, st));
@@ -479,7 +479,7 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
                 W.ldb = g.Cin[0];
                 W.rows = C;
                 int rc = PNPP_OK;
-                paired0 = try_launch_da_dw(dz, W, g.M, d->D, C, E, nullptr, a2, g.Cin[0], sc.dwslab, nsplit, kp_pad, st, &rc);
+                paired0 = try_launch_da_dw(dz, W, g.M, d->D, C, E, nullptr, a2, g.Cin[0], sc.dwslab, &nsplit, &kp_pad, st, &rc);
                 if (paired0) PNPP_TRY(rc);
                 dpoints_done = paired0;
             }
