@@ -854,6 +854,14 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     double s1[NT], s2[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) s1[i] = s2[i] = 0.0;
+    float pool_sg[NT];   // sign of gamma at this lane's columns (pooling in the epilogue: max z or min z)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        pool_sg[j] = 1.f;
+        if constexpr (EMODE == E_STORE_STATS) {
+            if (E.pool_ext && E.pool_gamma) pool_sg[j] = E.pool_gamma[min(n0 + wn * TN + j * 32 + l31, Nout - 1)] >= 0.f ? 1.f : -1.f;
+        }
+    }
 
     f32x16 dwacc[DT];  // FDW: this wave's (32 x 32) tiles of dW, accumulated over every row tile of the worker
 #pragma unroll
@@ -1160,6 +1168,24 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                             t2 = fmaf(v, v, t2);
                         }
                         if constexpr (EMODE == E_STORE_STATS) s1[j] += (double)t1, s2[j] += (double)t2;
+                        if constexpr (EMODE == E_STORE_STATS) {
+                            if (E.pool_ext) {   // (uniform) this 32 x 32 tile is one neighbourhood: its extreme row per column
+                                const float sg = pool_sg[j];
+                                float mx = sg * acc[i][j][0];
+#pragma unroll
+                                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sg * acc[i][j][r]);
+                                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));        // the other 16 rows of the column sit in lane ^ 32
+                                int a = 64;
+#pragma unroll
+                                for (int r = 15; r >= 0; --r) a = (sg * acc[i][j][r] == mx) ? (r & 3) + 8 * (r >> 2) + 4 * lh : a;
+                                a = min(a, __shfl_xor(a, 32, 64));             // first row attaining it
+                                if (lh == 0) {
+                                    const size_t gi = (size_t)((m0 + wm * TM + i * 32) >> 5) * E.ldc + (n0 + wn * TN + j * 32 + l31);
+                                    E.pool_ext[gi] = sg * mx;
+                                    E.pool_arg[gi] = a;
+                                }
+                            }
+                        }
                     }
             }
         }
@@ -1759,6 +1785,16 @@ static int launch_gemm_cfg(const AOperand &A, const BOperand &B, int M, int Nout
 #undef PNPP_LAUNCH
     PNPP_CHECK_LAUNCH("gemm");
     return PNPP_OK;
+}
+
+// Epilogue::pool_ext is honoured by the interior epilogue of the float32 weights-stationary kernel with one column tile per wave
+// (every dense launch of try_launch_ws); the caller asks before it relies on it
+bool gemm_pools_in_epilogue(const AOperand &A, int M, int Nout, int Kd, int nsample) {
+    if (matmul_precision() != 0) return false;
+    if (nsample != 32 || M < 8192 || M % 64 != 0 || Nout % 64 != 0) return false;
+    if (!(A.mode == A_PLAIN || A.mode == A_BNRELU)) return false;
+    if (A.lda % 4 != 0 || ((uintptr_t)A.a & 15) != 0) return false;
+    return Kd == 64 || Kd == 128 || Kd == 256;
 }
 
 int launch_gemm(const AOperand &A, const BOperand &Bin, int M, int Nout, int Kd, const Epilogue &E, int *nslab,
@@ -2675,10 +2711,16 @@ bn_finalize_fwd_kernel(const double *__restrict__ slab, int nslab, int C, double
                        const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ rm,
                        float *__restrict__ rv, long long *__restrict__ nbt, float momentum, float eps, int training,
                        float *__restrict__ mean, float *__restrict__ istd, float *__restrict__ scale,
-                       float *__restrict__ shift, const double *__restrict__ count_dev) {
+                       float *__restrict__ shift, const double *__restrict__ count_dev, const float *__restrict__ pool_ext,
+                       float *__restrict__ pool_out, int G) {
     __shared__ double red[32][2][FIN_COLS];
+    __shared__ float pool_cs[2][FIN_COLS];
     if (count_dev) count = *count_dev;   // SyncBN: the row count of ALL ranks, summed with the statistics
-    if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;  // num_batches_tracked (nn.BatchNorm forward)
+    // pooling in the producer's epilogue (Epilogue::pool_ext): gridDim.y row blocks each redo the slab reduction for their 8
+    // channels (identical sums, identical order) and turn their rows of the extreme pre-BN values into the pooled output;
+    // the statistics themselves are written by row block 0 only
+    const bool writer = blockIdx.y == 0;
+    if (training && nbt && blockIdx.x == 0 && writer && threadIdx.x == 0) *nbt += 1;  // num_batches_tracked (nn.BatchNorm forward)
     const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
     // The per-channel parameters are requested BEFORE the slab reduction: at a kernel boundary every line is a cold miss of this
     // XCD's L2 (~1.5 us), the reduction ends in a barrier the compiler will not move loads across, and a launch this short is
@@ -2706,18 +2748,34 @@ bn_finalize_fwd_kernel(const double *__restrict__ slab, int nslab, int C, double
         mu = (double)p_rm - (double)p_bias;
         var = (double)p_rv;
     }
-    if (!owner) return;
-    const double is = 1.0 / sqrt(var + (double)eps);
-    const double g = (double)p_g, bt = (double)p_b;
-    mean[c] = (float)mu;
-    istd[c] = (float)is;
-    scale[c] = (float)(g * is);
-    shift[c] = (float)(bt - mu * g * is);
-    if (training && rm) {
-        const double bmean = mu + (double)p_bias;  // the conv/linear bias was folded out of z
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        rm[c] = (float)((1.0 - (double)momentum) * (double)p_rm + (double)momentum * bmean);
-        rv[c] = (float)((1.0 - (double)momentum) * (double)p_rv + (double)momentum * unbiased);
+    if (owner) {
+        const double is = 1.0 / sqrt(var + (double)eps);
+        const double g = (double)p_g, bt = (double)p_b;
+        const float sc = (float)(g * is), sh = (float)(bt - mu * g * is);
+        if (pool_out) pool_cs[0][threadIdx.x] = sc, pool_cs[1][threadIdx.x] = sh;
+        if (writer) {
+            mean[c] = (float)mu;
+            istd[c] = (float)is;
+            scale[c] = sc;
+            shift[c] = sh;
+            if (training && rm) {
+                const double bmean = mu + (double)p_bias;  // the conv/linear bias was folded out of z
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                rm[c] = (float)((1.0 - (double)momentum) * (double)p_rm + (double)momentum * bmean);
+                rv[c] = (float)((1.0 - (double)momentum) * (double)p_rv + (double)momentum * unbiased);
+            }
+        }
+    }
+    if (!pool_out) return;
+    __syncthreads();
+    // out[g][c] = relu(scale * ext + shift): 8 consecutive channels (32 bytes) of 32 rows per pass
+    const int cl = threadIdx.x % FIN_COLS, cc = blockIdx.x * FIN_COLS + cl;
+    if (cc >= C) return;
+    const float sc = pool_cs[0][cl], sh = pool_cs[1][cl];
+    const int rows_per = (G + gridDim.y - 1) / gridDim.y, g0 = blockIdx.y * rows_per, g1 = min(G, g0 + rows_per);
+    for (int gg = g0 + threadIdx.x / FIN_COLS; gg < g1; gg += 256 / FIN_COLS) {
+        const size_t i = (size_t)gg * C + cc;
+        pool_out[i] = fmaxf(fmaf(pool_ext[i], sc, sh), 0.f);
     }
 }
 
@@ -2879,10 +2937,19 @@ int launch_slab_sum(const double *slab, int nslab, int C, double count, double *
 
 int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, const float *bias, const float *gamma,
                            const float *beta, float *rm, float *rv, long long *nbt, float momentum, float eps, int training,
-                           float *mean, float *istd, float *scale, float *shift, hipStream_t st, const double *count_dev) {
-    ProfScope ps(st, "bn_finalize_fwd_kernel C=%d", C);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, FIN_COLS)), dim3(256), 0, st, slab, nslab, C, count, bias, gamma, beta,
-                       rm, rv, nbt, momentum, eps, training, mean, istd, scale, shift, count_dev);
+                           float *mean, float *istd, float *scale, float *shift, hipStream_t st, const double *count_dev,
+                           const float *pool_ext, float *pool_out, int G) {
+    const bool pool = pool_ext && pool_out && G > 0 && training;
+    int gy = 1;
+    if (pool) {   // enough row blocks to fill the chip, at least 64 rows each
+        gy = cdiv(256, cdiv(C, FIN_COLS));
+        if (gy > cdiv(G, 64)) gy = cdiv(G, 64);
+        if (gy < 1) gy = 1;
+    }
+    ProfScope ps(st, "bn_finalize_fwd_kernel C=%d%s", C, pool ? " +pool" : "");
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, FIN_COLS), gy), dim3(256), 0, st, slab, nslab, C, count, bias, gamma, beta,
+                       rm, rv, nbt, momentum, eps, training, mean, istd, scale, shift, count_dev, pool ? pool_ext : nullptr,
+                       pool ? pool_out : nullptr, G);
     PNPP_CHECK_LAUNCH("bn_finalize_fwd");
     return PNPP_OK;
 }

@@ -78,6 +78,14 @@ struct Epilogue {
     // partial sums go to dwslab[worker][Kd][dw_ld] and are combined by launch_slab_reduce
     float *dwslab = nullptr;
     int dw_ld = 0;
+    // STORE_STATS of a level's LAST layer, neighbourhoods of 32 rows (one MFMA tile each), optional: the max over the neighbourhood
+    // is taken from the accumulators.  relu(scale z + shift) is monotone in z with the sign of gamma, which is known before the
+    // batch statistics are: the epilogue writes the extreme pre-BN value pool_ext[g][c] (max z for gamma >= 0, min z otherwise)
+    // and its row pool_arg[g][c] (first such row); bn_finalize_fwd then turns pool_ext into the pooled output -- no pooling pass
+    // over Z (models/pointnet_pp_8dir.py:42, torch.max(x, 3)[0]).
+    float *pool_ext = nullptr;
+    int32_t *pool_arg = nullptr;
+    const float *pool_gamma = nullptr;
     BnTail bn;
 };
 
@@ -139,7 +147,10 @@ int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kv
 
 int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, const float *bias, const float *gamma,
                            const float *beta, float *rm, float *rv, long long *nbt, float momentum, float eps, int training,
-                           float *mean, float *istd, float *scale, float *shift, hipStream_t st, const double *count_dev = nullptr);
+                           float *mean, float *istd, float *scale, float *shift, hipStream_t st, const double *count_dev = nullptr,
+                           const float *pool_ext = nullptr, float *pool_out = nullptr, int G = 0);
+// true when launch_gemm will honour Epilogue::pool_ext for this shape (the weights-stationary kernel, 32-row neighbourhoods)
+bool gemm_pools_in_epilogue(const AOperand &A, int M, int Nout, int Kd, int nsample);
 int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, int training, const float *gamma,
                            const float *mean, const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias,
                            hipStream_t st, const AOperand *dz = nullptr, int M = 0, float *dz_out = nullptr,

@@ -7,6 +7,7 @@
 // Everything is stream-ordered: these functions only enqueue work on `stream`; they never allocate,
 // free, copy to the host or synchronise (they can be captured into a hipGraph).
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <map>
 #include <string>
@@ -159,6 +160,16 @@ static SaSaved sa_saved_layout(const pnpp_sa_desc *d, const SaGeom &g, void *bas
     return s;
 }
 
+// A/B switch (PNPP_NO_POOL_FUSION=1: pooling stays a pass of its own over Z)
+static bool pool_fused_on() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char *v = getenv("PNPP_NO_POOL_FUSION");
+        cached = (v && atoi(v) != 0) ? 0 : 1;
+    }
+    return cached != 0;
+}
+
 constexpr int kSmallM = 4096;  // at or below this many rows dZ is materialised once per layer (group_all layers)
 
 struct SaScratch {
@@ -254,6 +265,7 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
     }
 
     // 2. conv -> BN -> ReLU chain; BN apply + ReLU of layer l-1 happen inside layer l's operand loader
+    bool pooled = false;
     for (int l = 0; l < d->L; ++l) {
         AOperand A;
         if (l == 0) {
@@ -300,12 +312,18 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
         } else if (d->training) {
             E.mode = E_STORE_STATS;
             E.slab = sc.slab;
+            // last layer of a level with 32-row neighbourhoods: the max over the neighbourhood is taken from the GEMM's accumulators
+            // and finished by the statistics launch (sc.dm, idle in the forward pass, holds the extreme pre-BN values)
+            const bool pool_here = l == d->L - 1 && !d->group_all && pool_fused_on() && gemm_pools_in_epilogue(A, g.M, d->C[l], g.Kd[l], d->K);
+            if (pool_here) E.pool_ext = sc.dm, E.pool_arg = sv.arg, E.pool_gamma = a->bn_w[l];
             PNPP_TRY(launch_gemm(A, W, g.M, d->C[l], g.Kd[l], E, &nslab, st));
             StatsView V;
             PNPP_TRY(stats_exchange(sc.slab, nslab, d->C[l], (double)g.M, st, &V));
             PNPP_TRY(launch_bn_finalize_fwd(V.slab, V.nslab, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
                                             a->bn_rm[l], a->bn_rv[l], (long long *)a->bn_nbt[l], d->momentum, d->eps, 1, sv.mean[l], sv.istd[l],
-                                            sv.scale[l], sv.shift[l], st, V.count_dev));
+                                            sv.scale[l], sv.shift[l], st, V.count_dev, pool_here ? sc.dm : nullptr,
+                                            pool_here ? a->out : nullptr, g.G));
+            pooled = pool_here;
         } else {
             E.mode = E_STORE;
             PNPP_TRY(launch_bn_finalize_fwd(nullptr, 0, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
@@ -315,9 +333,9 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
         }
     }
 
-    // 3. max over the neighbourhood (pointnet_pp_8dir.py:42-43)
+    // 3. max over the neighbourhood (pointnet_pp_8dir.py:42-43), unless the last layer's launches have taken it
     const int Lm = d->L - 1;
-    PNPP_TRY(launch_pool_fwd(sv.z[Lm], sv.scale[Lm], sv.shift[Lm], g.G, d->K, d->C[Lm], a->out, sv.arg, st,
+    if (!pooled) PNPP_TRY(launch_pool_fwd(sv.z[Lm], sv.scale[Lm], sv.shift[Lm], g.G, d->K, d->C[Lm], a->out, sv.arg, st,
                              d->group_all ? a->new_xyz : nullptr, d->group_all ? sv.new_xyz : nullptr, d->group_all ? g.G * 3 : 0,
                              sc.dy[0]));  // dy[0] (M x C floats) is idle in the forward pass: >= the K/64 partials per (group, channel)
     return PNPP_OK;
