@@ -101,17 +101,24 @@ struct KnnJob {
     float *out_a, *out_b;
 };
 
-__device__ __forceinline__ void knn_body(const KnnJob &J, const int bx, const int b) {
+struct KnnLds {   // one copy per workgroup, shared by the two instantiations of the body a pair kernel contains
+    float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE], sn[KNN_TILE];
+    unsigned long long best[4][2][KNN_KMAX];
+    unsigned long long pool[4][KNN_POOL];
+};
+
+template <bool GATHER>
+__device__ __forceinline__ void knn_body(const KnnJob &J, const int bx, const int b, KnnLds &L) {
     const float *__restrict__ new_xyz = J.new_xyz;
     const float *__restrict__ xyz = J.xyz;
     const int32_t *__restrict__ centre = J.centre;
-    const int32_t *__restrict__ gather = J.gather ? J.gather + (size_t)b * J.N : nullptr;
+    const int32_t *__restrict__ gather = GATHER ? J.gather + (size_t)b * J.N : nullptr;
     int32_t *__restrict__ idx = J.idx;
     float *__restrict__ out_a = J.out_a, *__restrict__ out_b = J.out_b;
     const int S = J.S, N = J.N, k = J.k;
-    __shared__ float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE], sn[KNN_TILE];
-    __shared__ unsigned long long best[4][2][KNN_KMAX];
-    __shared__ unsigned long long pool[4][KNN_POOL];
+    float(&sx)[KNN_TILE] = L.sx, (&sy)[KNN_TILE] = L.sy, (&sz)[KNN_TILE] = L.sz, (&sn)[KNN_TILE] = L.sn;
+    unsigned long long(&best)[4][2][KNN_KMAX] = L.best;
+    unsigned long long(&pool)[4][KNN_POOL] = L.pool;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int q = bx * 4 + wave;
@@ -121,7 +128,7 @@ __device__ __forceinline__ void knn_body(const KnnJob &J, const int bx, const in
         const float *a = new_xyz + ((size_t)b * S + q) * 3;
         if (centre) {
             const int c = centre[(size_t)b * S + q];
-            a = xyz + ((size_t)b * J.Nsrc + (gather ? gather[c] : c)) * 3;
+            a = xyz + ((size_t)b * J.Nsrc + (GATHER ? gather[c] : c)) * 3;
         }
         ax = a[0], ay = a[1], az = a[2];
         sa = sq3_exact(ax, ay, az);
@@ -142,7 +149,9 @@ __device__ __forceinline__ void knn_body(const KnnJob &J, const int bx, const in
         // coalesced stage: 3*cnt consecutive floats, de-interleaved into SoA (gathered clouds: three floats per listed row)
         for (int i = threadIdx.x; i < cnt * 3; i += 256) {
             int p = i / 3, c = i - p * 3;
-            float v = gather ? cloud[(size_t)gather[t0 + p] * 3 + c] : cloud[(size_t)t0 * 3 + i];
+            float v;
+            if constexpr (GATHER) v = cloud[(size_t)gather[t0 + p] * 3 + c];
+            else v = cloud[(size_t)t0 * 3 + i];
             (c == 0 ? sx : c == 1 ? sy : sz)[p] = v;
         }
         __syncthreads();
@@ -227,7 +236,10 @@ __device__ __forceinline__ void knn_body(const KnnJob &J, const int bx, const in
     }
 }
 
-__global__ void __launch_bounds__(256) knn_kernel(const KnnJob J) { knn_body(J, blockIdx.x, blockIdx.y); }
+__global__ void __launch_bounds__(256) knn_kernel(const KnnJob J) {
+    __shared__ KnnLds L;
+    knn_body<false>(J, blockIdx.x, blockIdx.y, L);
+}
 
 // The neighbour searches of two stacked levels in ONE launch (they are independent once both levels' centre indices are drawn:
 // level 2 searches among level 1's centres, which are rows of the same cloud).  blockIdx.x < nb1: level 1, else level 2.
@@ -235,8 +247,9 @@ __global__ void __launch_bounds__(256) knn_kernel(const KnnJob J) { knn_body(J, 
 // CU the last 256 start only when a slot frees up and the launch takes a round and a half (measured: 21.1 us against 12.6 + 7.0 for
 // the two separate launches).  The short level-2 workgroups come first.
 __global__ void __launch_bounds__(256, 5) knn_pair_kernel(const KnnJob J1, const KnnJob J2, int nb2) {
-    if ((int)blockIdx.x < nb2) knn_body(J2, blockIdx.x, blockIdx.y);
-    else knn_body(J1, blockIdx.x - nb2, blockIdx.y);
+    __shared__ KnnLds L;
+    if ((int)blockIdx.x < nb2) knn_body<true>(J2, blockIdx.x, blockIdx.y, L);
+    else knn_body<false>(J1, blockIdx.x - nb2, blockIdx.y, L);
 }
 
 // Wave-wide maximum of a 64-bit key, result in every lane.  Six dependent ds_bpermute round trips (what __shfl_xor compiles
