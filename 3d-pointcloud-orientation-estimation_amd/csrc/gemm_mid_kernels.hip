@@ -54,6 +54,18 @@ struct MidDw {
     int ldo;
 };
 
+// Operand streams are BUFFER loads: (resource descriptor in SGPRs = the tile's uniform base) + (one 32-bit lane offset, computed
+// once) + (the chunk's byte offset in an SGPR).  With global_load and per-load 64-bit addresses the register allocator recycled
+// address registers that were still the DESTINATION of loads in flight -- an s_waitcnt vmcnt in the middle of every batch, one
+// exposed L2 round trip per chunk -- and loop strength reduction defeats a hand-made (uniform pointer + lane offset) form.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mid_rsrc(const float *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), (short)0, 0x7ffffffe, 0x00020000);
+}
+__device__ __forceinline__ f32x4 mid_load4(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned chunk_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)chunk_off, 0));
+}
+
 // ---- C tile (64 x 64) = a'[64 x K] * W, one workgroup --------------------------------------------------------------------
 template <int AX, bool BT, int EM>
 __device__ __forceinline__ void mid_gemm_tile(const MidGemm &G, const int tm, const int tn, float *__restrict__ lds) {
@@ -68,14 +80,24 @@ __device__ __forceinline__ void mid_gemm_tile(const MidGemm &G, const int tm, co
     //  global loads issued in front of them: 2.2 us per chunk for 1.0 us of MFMAs in the first version of this kernel)
     f32x4 ra[4], rw[4];
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float *pa = G.a + (size_t)(m0 + rb) * G.lda + q4;
-    const float *pw = BT ? G.b + (size_t)(n0 + rb) * G.ldb + q4 : G.b + (size_t)rb * G.ldb + n0 + q4;
+    // operand streams = (uniform base, advanced per chunk by scalar arithmetic) + (four 32-bit lane offsets computed once): the
+    // loads take the SGPR-base form and need no 64-bit address registers.  (With per-load 64-bit addresses the allocator recycled
+    // address registers that were still the DESTINATION of loads in flight: an s_waitcnt vmcnt in the middle of every batch, i.e.
+    // one exposed L2 round trip per chunk.)
+    const __amdgpu_buffer_rsrc_t resA = mid_rsrc(G.a + (size_t)m0 * G.lda);
+    const __amdgpu_buffer_rsrc_t resW = mid_rsrc(BT ? G.b + (size_t)n0 * G.ldb : G.b + n0);
+    unsigned oa[4], ow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        oa[i] = 4u * ((unsigned)(rb + 16 * i) * (unsigned)G.lda + (unsigned)q4);
+        ow[i] = 4u * ((unsigned)(rb + 16 * i) * (unsigned)G.ldb + (unsigned)q4);
+    }
+    const unsigned stepA = MID_T * (unsigned)sizeof(float), stepW = BT ? MID_T * (unsigned)sizeof(float) : MID_T * (unsigned)G.ldb * (unsigned)sizeof(float);
     auto gload = [&](int c) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const f32x4 *>(pa + (size_t)(16 * i) * G.lda + c * MID_T);
-            if constexpr (BT) rw[i] = *reinterpret_cast<const f32x4 *>(pw + (size_t)(16 * i) * G.ldb + c * MID_T);
-            else rw[i] = *reinterpret_cast<const f32x4 *>(pw + (size_t)(c * MID_T + 16 * i) * G.ldb);
+            ra[i] = mid_load4(resA, oa[i], (unsigned)c * stepA);
+            rw[i] = mid_load4(resW, ow[i], (unsigned)c * stepW);
         }
         if constexpr (AX == A_BNRELU) {
             sc = *reinterpret_cast<const float4 *>(G.scale + c * MID_T + q4);
@@ -199,12 +221,20 @@ __device__ __forceinline__ void mid_dw_tile(const MidDw &D, const int tc, const 
         sc = *reinterpret_cast<const float4 *>(D.scale + k0 + q4);
         sh = *reinterpret_cast<const float4 *>(D.shift + k0 + q4);
     }
-    const float *pd = D.dz + (size_t)(r0 + rb) * D.ldz + c0 + q4, *pa = D.a2 + (size_t)(r0 + rb) * D.lda2 + k0 + q4;
+    const __amdgpu_buffer_rsrc_t resD = mid_rsrc(D.dz + (size_t)r0 * D.ldz + c0);
+    const __amdgpu_buffer_rsrc_t resA = mid_rsrc(D.a2 + (size_t)r0 * D.lda2 + k0);
+    unsigned od[4], oa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        od[i] = 4u * ((unsigned)(rb + 16 * i) * (unsigned)D.ldz + (unsigned)q4);
+        oa[i] = 4u * ((unsigned)(rb + 16 * i) * (unsigned)D.lda2 + (unsigned)q4);
+    }
+    const unsigned stepD = MID_T * (unsigned)D.ldz * (unsigned)sizeof(float), stepA = MID_T * (unsigned)D.lda2 * (unsigned)sizeof(float);
     auto gload = [&](int c) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            rd[i] = *reinterpret_cast<const f32x4 *>(pd + (size_t)(c * MID_T + 16 * i) * D.ldz);
-            ra[i] = *reinterpret_cast<const f32x4 *>(pa + (size_t)(c * MID_T + 16 * i) * D.lda2);
+            rd[i] = mid_load4(resD, od[i], (unsigned)c * stepD);
+            ra[i] = mid_load4(resA, oa[i], (unsigned)c * stepA);
         }
     };
     auto lstore = [&](int stage) {
