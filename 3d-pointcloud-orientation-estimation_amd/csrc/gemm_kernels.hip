@@ -539,6 +539,9 @@ __device__ int g_stamp_kd;
 #endif
 // timing experiments only (results are WRONG with either on; never in a shipped build): what is left of a launch without its
 // matrix instructions, or without its output stores
+#ifndef PNPP_WS_DEFER_STORES     // forward kernels: a tile's stores are issued behind the NEXT tile's staging pass
+#define PNPP_WS_DEFER_STORES 1
+#endif
 #ifndef PNPP_WS_EXP_NO_MFMA
 #define PNPP_WS_EXP_NO_MFMA 0
 #endif
@@ -869,6 +872,35 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) dwacc[t][r] = 0.f;
 
+    // Forward kernels (one 32 x 32 tile per wave): the tile's output stores are DEFERRED to the next iteration, behind the staging
+    // pass.  vmcnt counts loads and stores in issue order, and the compiler cannot prove how many stores separate the next tile's
+    // operand loads from the wait in front of the staging pass (the first iteration has none), so it waits with vmcnt(0): every
+    // tile then also waits for its predecessor's 16 stores to be ACKNOWLEDGED -- 3 to 6 us per forward launch (a build with the
+    // stores compiled out: 30.0 -> 24.0, 19.4 -> 16.0, 23.7 -> 20.8 us).  Held back until the loads have been consumed, the
+    // stores have a whole tile to drain before anything waits again.
+    constexpr bool DEFER = PNPP_WS_DEFER_STORES && EMODE != E_MASK_STATS && !FDW && MT == 1 && NT == 1;
+    f32x16 held;
+    float held_ext = 0.f;
+    int held_arg = 0, held_m0 = -1;
+    auto flush_held = [&]() {
+        if constexpr (DEFER) {
+            if (held_m0 >= 0) {
+                if constexpr (EMODE == E_STORE_STATS) {
+                    if (E.pool_ext && lh == 0) {
+                        const size_t gi = (size_t)((held_m0 + wm * TM) >> 5) * E.ldc + (n0 + wn * TN + l31);
+                        E.pool_ext[gi] = held_ext;
+                        E.pool_arg[gi] = held_arg;
+                    }
+                }
+                float *tb = E.c + (size_t)(held_m0 + wm * TM) * E.ldc + (n0 + wn * TN);
+                const unsigned lo = (unsigned)(4 * lh) * (unsigned)E.ldc + (unsigned)l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tb[(size_t)((r & 3) + 8 * (r >> 2)) * E.ldc + lo] = held[r];
+                held_m0 = -1;
+            }
+        }
+    };
+
     // see the K loop: with `inter` the operand loads of the NEXT tile are issued between this tile's MFMAs
     const bool inter = DENSE_A && KD >= PNPP_WS_INTER_MINK && SWZ && EMODE == E_MASK_STATS && !(FDW && NT > 1) && full_rows && n0 + BN <= Nout;
     PNPP_STAMP(8)   // prologue, rest: first tile's loads complete
@@ -948,6 +980,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                 As[a_idx(tid, KMAIN + 3)] = 0.f;
             }
         }
+        flush_held();   // the previous tile's output: this tile's operand loads have just been consumed
         PNPP_STAMP(2)
         __syncthreads();
         PNPP_STAMP(3)
@@ -1163,10 +1196,13 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
                         for (int r = 0; r < 16; ++r) {
                             const float v = acc[i][j][r];
                             float *tr = tb + (size_t)((r & 3) + 8 * (r >> 2)) * E.ldc;
-                            if (!PNPP_WS_EXP_NO_STORE) tr[lo] = v;
+                            if constexpr (!DEFER) {
+                                if (!PNPP_WS_EXP_NO_STORE) tr[lo] = v;
+                            }
                             t1 += v;
                             t2 = fmaf(v, v, t2);
                         }
+                        if constexpr (DEFER) held = acc[i][j], held_m0 = m0;
                         if constexpr (EMODE == E_STORE_STATS) s1[j] += (double)t1, s2[j] += (double)t2;
                         if constexpr (EMODE == E_STORE_STATS) {
                             if (E.pool_ext) {   // (uniform) this 32 x 32 tile is one neighbourhood: its extreme row per column
@@ -1179,7 +1215,9 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
 #pragma unroll
                                 for (int r = 15; r >= 0; --r) a = (sg * acc[i][j][r] == mx) ? (r & 3) + 8 * (r >> 2) + 4 * lh : a;
                                 a = min(a, __shfl_xor(a, 32, 64));             // first row attaining it
-                                if (lh == 0) {
+                                if constexpr (DEFER) {   // stored with the tile, behind the next staging pass
+                                    held_ext = sg * mx, held_arg = a;
+                                } else if (lh == 0) {
                                     const size_t gi = (size_t)((m0 + wm * TM + i * 32) >> 5) * E.ldc + (n0 + wn * TN + j * 32 + l31);
                                     E.pool_ext[gi] = sg * mx;
                                     E.pool_arg[gi] = a;
@@ -1332,6 +1370,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
         }
     }
 
+    flush_held();
     PNPP_STAMP(9)       // (nothing: closes the last tile)
     if constexpr (FDW) {  // one partial dW per worker: dwslab[worker][c][n0 + k]
       if (n0 + BN <= Nout) {  // (uniform row pointer) + (one lane offset): scalar address arithmetic, no bounds test per element
