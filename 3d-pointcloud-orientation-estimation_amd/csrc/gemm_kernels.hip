@@ -2751,7 +2751,7 @@ bn_finalize_fwd_kernel(const double *__restrict__ slab, int nslab, int C, double
                        float *__restrict__ rv, long long *__restrict__ nbt, float momentum, float eps, int training,
                        float *__restrict__ mean, float *__restrict__ istd, float *__restrict__ scale,
                        float *__restrict__ shift, const double *__restrict__ count_dev, const float *__restrict__ pool_ext,
-                       float *__restrict__ pool_out, int G) {
+                       float *__restrict__ pool_out, int G, int32_t *__restrict__ pool_arg) {
     __shared__ double red[32][2][FIN_COLS];
     __shared__ float pool_cs[2][FIN_COLS];
     if (count_dev) count = *count_dev;   // SyncBN: the row count of ALL ranks, summed with the statistics
@@ -2814,7 +2814,11 @@ bn_finalize_fwd_kernel(const double *__restrict__ slab, int nslab, int C, double
     const int rows_per = (G + gridDim.y - 1) / gridDim.y, g0 = blockIdx.y * rows_per, g1 = min(G, g0 + rows_per);
     for (int gg = g0 + threadIdx.x / FIN_COLS; gg < g1; gg += 256 / FIN_COLS) {
         const size_t i = (size_t)gg * C + cc;
-        pool_out[i] = fmaxf(fmaf(pool_ext[i], sc, sh), 0.f);
+        const float v = fmaf(pool_ext[i], sc, sh);
+        pool_out[i] = fmaxf(v, 0.f);
+        // a neighbourhood whose activations are all zero routes (no) gradient through its first row, as torch.max over the
+        // post-ReLU values does -- and the backward pass then reads one z row per group instead of a scattered one
+        if (pool_arg && !(v > 0.f)) pool_arg[i] = 0;
     }
 }
 
@@ -2977,7 +2981,7 @@ int launch_slab_sum(const double *slab, int nslab, int C, double count, double *
 int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, const float *bias, const float *gamma,
                            const float *beta, float *rm, float *rv, long long *nbt, float momentum, float eps, int training,
                            float *mean, float *istd, float *scale, float *shift, hipStream_t st, const double *count_dev,
-                           const float *pool_ext, float *pool_out, int G) {
+                           const float *pool_ext, float *pool_out, int G, int32_t *pool_arg) {
     const bool pool = pool_ext && pool_out && G > 0 && training;
     int gy = 1;
     if (pool) {   // enough row blocks to fill the chip, at least 64 rows each
@@ -2988,7 +2992,7 @@ int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, c
     ProfScope ps(st, "bn_finalize_fwd_kernel C=%d%s", C, pool ? " +pool" : "");
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, FIN_COLS), gy), dim3(256), 0, st, slab, nslab, C, count, bias, gamma, beta,
                        rm, rv, nbt, momentum, eps, training, mean, istd, scale, shift, count_dev, pool ? pool_ext : nullptr,
-                       pool ? pool_out : nullptr, G);
+                       pool ? pool_out : nullptr, G, pool ? pool_arg : nullptr);
     PNPP_CHECK_LAUNCH("bn_finalize_fwd");
     return PNPP_OK;
 }

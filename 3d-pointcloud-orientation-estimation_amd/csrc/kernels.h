@@ -148,7 +148,7 @@ int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kv
 int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, const float *bias, const float *gamma,
                            const float *beta, float *rm, float *rv, long long *nbt, float momentum, float eps, int training,
                            float *mean, float *istd, float *scale, float *shift, hipStream_t st, const double *count_dev = nullptr,
-                           const float *pool_ext = nullptr, float *pool_out = nullptr, int G = 0);
+                           const float *pool_ext = nullptr, float *pool_out = nullptr, int G = 0, int32_t *pool_arg = nullptr);
 // true when launch_gemm will honour Epilogue::pool_ext for this shape (the weights-stationary kernel, 32-row neighbourhoods)
 bool gemm_pools_in_epilogue(const AOperand &A, int M, int Nout, int Kd, int nsample);
 int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, int training, const float *gamma,

@@ -322,7 +322,7 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
             PNPP_TRY(launch_bn_finalize_fwd(V.slab, V.nslab, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
                                             a->bn_rm[l], a->bn_rv[l], (long long *)a->bn_nbt[l], d->momentum, d->eps, 1, sv.mean[l], sv.istd[l],
                                             sv.scale[l], sv.shift[l], st, V.count_dev, pool_here ? sc.dm : nullptr,
-                                            pool_here ? a->out : nullptr, g.G));
+                                            pool_here ? a->out : nullptr, g.G, pool_here ? sv.arg : nullptr));
             pooled = pool_here;
         } else {
             E.mode = E_STORE;
