@@ -9,8 +9,10 @@
 // of a 1,024-row level, 0.33 of the float32 MFMA roof -- and the 128 x 128 dW blocks it was paired with went out as sixteen 64-row
 // splits whose partial sums were 7.5 x the launch's compulsory HBM traffic.  Here a workgroup owns a 64 x 64 tile over the WHOLE
 // reduction (no partial sums at all for dA and the forward product, at most two row ranges for dW), a tile's operands are read
-// from L2 once per 64 x 64 outputs, and the loop is  [MFMAs of chunk c | LDS image of chunk c+1 from registers | global loads
-// of chunk c+2] with ONE barrier per chunk.
+// from L2 once per 64 x 64 outputs, and the loop is  [barrier | LDS image of chunk c+1 from registers | loads of chunk c+2 |
+// MFMAs of chunk c] with ONE barrier per chunk.  (A 64 x 32-tile form -- 512 workgroups, two or three per CU, the four waves =
+// (row half) x (reduction half of a chunk) combined through LDS -- measured the same 26 / 15 us as these 256 workgroups, one per
+// CU: DESIGN.md section 9.)
 //
 // Operand images.  Every operand tile is 64 rows x 64 contiguous floats of a row-major matrix, fetched as four 16-byte loads per
 // thread (thread -> column group tid % 16, rows tid / 16 + 16 i).  What differs is how an MFMA consumes it:
@@ -292,249 +294,6 @@ __device__ __forceinline__ void mid_dw_tile(const MidDw &D, const int tc, const 
     for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * D.ldo] = acc[r];
 }
 
-// ---- the same two products on 64 x 32 tiles: twice the workgroups, two or three per CU ----------------------------------------
-// With 64 x 64 tiles the 512 -> 1024 layer of a 1,024-row level is 256 workgroups: one per CU, one wave per SIMD, so the barrier,
-// the LDS image and the wait for the next chunk of every iteration are exposed (1.6 us per chunk for 1.0 us of MFMAs).  A 64 x 32
-// tile whose four waves are (row half) x (reduction half of each chunk) is 512 workgroups of 52 KB: two or three share a CU and fill
-// each other's gaps; the two reduction halves of a tile are added through LDS once, at the end, in fixed order.
-constexpr int MID_N32 = 32;
-constexpr int MID_STAGE32 = MID_IMG + MID_T * MID_N32 + 128;   // A image (64 x 68) + B image (32 x 68 or 64 x 32), floats
-constexpr size_t MID_LDS32_BYTES = (size_t)2 * MID_STAGE32 * sizeof(float);
-
-template <int AX, bool BT, int EM>
-__device__ __forceinline__ void mid_gemm_tile32(const MidGemm &G, const int tm, const int tn, float *__restrict__ lds) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, lh = lane >> 5, wm = wave >> 1, kh = wave & 1;
-    const int q4 = 4 * (tid & 15), rb = tid >> 4;   // A image (and the [n][k] weight image): 16 column groups x 16 rows
-    const int q8 = 4 * (tid & 7), r8 = tid >> 3;    // [k][n] weight image: 8 column groups x 32 rows
-    const int m0 = tm * MID_T, n0 = tn * MID_N32, nc = G.K / MID_T;
-    const Epilogue &E = G.E;
-
-    f32x4 ra[4], rw[2];
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    const __amdgpu_buffer_rsrc_t resA = mid_rsrc(G.a + (size_t)m0 * G.lda);
-    const __amdgpu_buffer_rsrc_t resW = mid_rsrc(BT ? G.b + (size_t)n0 * G.ldb : G.b + n0);
-    unsigned oa[4], ow[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) oa[i] = 4u * ((unsigned)(rb + 16 * i) * (unsigned)G.lda + (unsigned)q4);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-        ow[i] = BT ? 4u * ((unsigned)(rb + 16 * i) * (unsigned)G.ldb + (unsigned)q4) : 4u * ((unsigned)(r8 + 32 * i) * (unsigned)G.ldb + (unsigned)q8);
-    const unsigned stepA = MID_T * (unsigned)sizeof(float), stepW = BT ? MID_T * (unsigned)sizeof(float) : MID_T * (unsigned)G.ldb * (unsigned)sizeof(float);
-    auto gload = [&](int c) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = mid_load4(resA, oa[i], (unsigned)c * stepA);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) rw[i] = mid_load4(resW, ow[i], (unsigned)c * stepW);
-        if constexpr (AX == A_BNRELU) {
-            sc = *reinterpret_cast<const float4 *>(G.scale + c * MID_T + q4);
-            sh = *reinterpret_cast<const float4 *>(G.shift + c * MID_T + q4);
-        }
-    };
-    auto lstore = [&](int stage) {
-        float *As = lds + stage * MID_STAGE32, *Bs = As + MID_IMG;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 v = ra[i];
-            if constexpr (AX == A_BNRELU) {
-                v[0] = fmaxf(fmaf(v[0], sc.x, sh.x), 0.f), v[1] = fmaxf(fmaf(v[1], sc.y, sh.y), 0.f);
-                v[2] = fmaxf(fmaf(v[2], sc.z, sh.z), 0.f), v[3] = fmaxf(fmaf(v[3], sc.w, sh.w), 0.f);
-            }
-            *reinterpret_cast<f32x4 *>(As + (rb + 16 * i) * MID_RP + q4) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if constexpr (BT) *reinterpret_cast<f32x4 *>(Bs + (rb + 16 * i) * MID_RP + q4) = rw[i];
-            else *reinterpret_cast<f32x4 *>(Bs + (r8 + 32 * i) * MID_N32 + q8) = rw[i];
-        }
-    };
-
-    float zp[16];
-    float e_sc = 0.f, e_sh = 0.f, e_mu = 0.f, e_is = 0.f;
-    const int col = n0 + l31;
-    if constexpr (EM == E_MASK_STATS) e_sc = E.scale[col], e_sh = E.shift[col], e_mu = E.mu[col], e_is = E.istd[col];
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    gload(0);
-    lstore(0);
-    if (nc > 1) gload(1);
-    for (int c = 0; c < nc; ++c) {
-        __syncthreads();
-        if (c + 1 < nc) lstore((c + 1) & 1);
-        if (c + 2 < nc) gload(c + 2);
-        const float *As = lds + (c & 1) * MID_STAGE32, *Bs = As + MID_IMG;
-        if constexpr (EM == E_MASK_STATS) {
-            if (c == nc - 1 && kh == 0) {   // (uniform per wave) the epilogue runs on the kh = 0 waves
-                const float *pz = E.zp + (size_t)(m0 + wm * 32 + 4 * lh) * E.ldc + col;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) zp[r] = pz[(size_t)((r & 3) + 8 * (r >> 2)) * E.ldc];
-            }
-        }
-        // this wave's half of the chunk: k = 32 kh + 8 t + 4 lh + u, t = 0..3
-        const float *arow = As + (wm * 32 + l31) * MID_RP + 32 * kh + 4 * lh;
-        const float *brow = BT ? Bs + l31 * MID_RP + 32 * kh + 4 * lh : Bs + (32 * kh + 4 * lh) * MID_N32 + l31;
-        float4 fa[2], fb[2];
-        auto ld = [&](int buf, int t) {
-            fa[buf] = *reinterpret_cast<const float4 *>(arow + 8 * t);
-            if constexpr (BT) {
-                fb[buf] = *reinterpret_cast<const float4 *>(brow + 8 * t);
-            } else {
-                const float *p = brow + 8 * t * MID_N32;
-                fb[buf] = make_float4(p[0], p[MID_N32], p[2 * MID_N32], p[3 * MID_N32]);
-            }
-        };
-        auto mm = [&](int buf) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].x, fb[buf].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].y, fb[buf].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].z, fb[buf].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].w, fb[buf].w, acc, 0, 0, 0);
-        };
-        ld(0, 0);
-        ld(1, 1);
-        mm(0);
-        ld(0, 2);
-        mm(1);
-        ld(1, 3);
-        mm(0);
-        mm(1);
-    }
-    // the two reduction halves of each 32 x 32 block, added in fixed order (kh = 0 + kh = 1)
-    __syncthreads();
-    float *part = lds;   // [2 wm][16][64]
-    if (kh == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) part[(wm * 16 + r) * 64 + lane] = acc[r];
-    }
-    __syncthreads();
-    float t1 = 0.f, t2 = 0.f;
-    if (kh == 0) {
-        float *tb = E.c + (size_t)(m0 + wm * 32 + 4 * lh) * E.ldc + col;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = acc[r] + part[(wm * 16 + r) * 64 + lane];
-            if constexpr (EM == E_STORE_STATS) {
-                t1 += v;
-                t2 = fmaf(v, v, t2);
-            } else if constexpr (EM == E_MASK_STATS) {
-                const float z0 = zp[r];
-                v = fmaf(z0, e_sc, e_sh) > 0.f ? v : 0.f;
-                t1 += v;
-                t2 = fmaf(v, (z0 - e_mu) * e_is, t2);
-            }
-            tb[(size_t)((r & 3) + 8 * (r >> 2)) * E.ldc] = v;
-        }
-    }
-    if constexpr (EM != E_STORE) {
-        __syncthreads();
-        double *red = reinterpret_cast<double *>(lds);   // [2 wm][2][32]
-        if (kh == 0) {
-            const double a = (double)t1 + shfl_xor_f64((double)t1, 32), b = (double)t2 + shfl_xor_f64((double)t2, 32);
-            if (lh == 0) red[(wm * 2 + 0) * 32 + l31] = a, red[(wm * 2 + 1) * 32 + l31] = b;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int which = tid >> 5, cl = tid & 31;
-            E.slab[((size_t)tm * 2 + which) * G.N + n0 + cl] = red[(0 * 2 + which) * 32 + cl] + red[(1 * 2 + which) * 32 + cl];
-        }
-    }
-}
-
-// dW tile: 64 channels of dZ x 32 columns of a2; waves = (channel half) x (row half of each chunk)
-template <int A2X>
-__device__ __forceinline__ void mid_dw_tile32(const MidDw &D, const int tc, const int tk, const int split, float *__restrict__ lds) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, lh = lane >> 5, wc = wave >> 1, mh = wave & 1;
-    const int q4 = 4 * (tid & 15), rb = tid >> 4, q8 = 4 * (tid & 7), r8 = tid >> 3;
-    const int c0 = tc * MID_T, k0 = tk * MID_N32;
-    const int r0 = split * D.rps, r1 = min(D.M, r0 + D.rps), nc = (r1 - r0) / MID_T;
-
-    f32x4 rd[4], ra[2];
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (A2X == A_BNRELU) {
-        sc = *reinterpret_cast<const float4 *>(D.scale + k0 + q8);
-        sh = *reinterpret_cast<const float4 *>(D.shift + k0 + q8);
-    }
-    const __amdgpu_buffer_rsrc_t resD = mid_rsrc(D.dz + (size_t)r0 * D.ldz + c0);
-    const __amdgpu_buffer_rsrc_t resA = mid_rsrc(D.a2 + (size_t)r0 * D.lda2 + k0);
-    unsigned od[4], oa[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) od[i] = 4u * ((unsigned)(rb + 16 * i) * (unsigned)D.ldz + (unsigned)q4);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) oa[i] = 4u * ((unsigned)(r8 + 32 * i) * (unsigned)D.lda2 + (unsigned)q8);
-    const unsigned stepD = MID_T * (unsigned)D.ldz * (unsigned)sizeof(float), stepA = MID_T * (unsigned)D.lda2 * (unsigned)sizeof(float);
-    auto gload = [&](int c) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rd[i] = mid_load4(resD, od[i], (unsigned)c * stepD);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) ra[i] = mid_load4(resA, oa[i], (unsigned)c * stepA);
-    };
-    auto lstore = [&](int stage) {
-        float *Ds = lds + stage * MID_STAGE32, *As = Ds + MID_IMG;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(Ds + (rb + 16 * i) * MID_T + q4) = rd[i];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f32x4 v = ra[i];
-            if constexpr (A2X == A_BNRELU) {
-                v[0] = fmaxf(fmaf(v[0], sc.x, sh.x), 0.f), v[1] = fmaxf(fmaf(v[1], sc.y, sh.y), 0.f);
-                v[2] = fmaxf(fmaf(v[2], sc.z, sh.z), 0.f), v[3] = fmaxf(fmaf(v[3], sc.w, sh.w), 0.f);
-            }
-            *reinterpret_cast<f32x4 *>(As + (r8 + 32 * i) * MID_N32 + q8) = v;
-        }
-    };
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if (nc > 0) {
-        gload(0);
-        lstore(0);
-        if (nc > 1) gload(1);
-    }
-    for (int c = 0; c < nc; ++c) {
-        __syncthreads();
-        if (c + 1 < nc) lstore((c + 1) & 1);
-        if (c + 2 < nc) gload(c + 2);
-        const float *Ds = lds + (c & 1) * MID_STAGE32, *As = Ds + MID_IMG;
-        // this wave's half of the chunk's rows: m = 32 mh + 2 s + lh, s = 0..15
-        const float *dcol = Ds + (32 * mh + lh) * MID_T + wc * 32 + l31, *acol = As + (32 * mh + lh) * MID_N32 + l31;
-        float fd[2][4], fa[2][4];
-        auto ld = [&](int buf, int s4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                fd[buf][u] = dcol[(8 * s4 + 2 * u) * MID_T];
-                fa[buf][u] = acol[(8 * s4 + 2 * u) * MID_N32];
-            }
-        };
-        auto mm = [&](int buf) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[buf][u], fa[buf][u], acc, 0, 0, 0);
-        };
-        ld(0, 0);
-        ld(1, 1);
-        mm(0);
-        ld(0, 2);
-        mm(1);
-        ld(1, 3);
-        mm(0);
-        mm(1);
-    }
-    __syncthreads();
-    float *part = lds;
-    if (mh == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) part[(wc * 16 + r) * 64 + lane] = acc[r];
-    }
-    __syncthreads();
-    if (mh == 0) {
-        float *o = D.out + ((size_t)split * D.Nc + c0 + wc * 32 + 4 * lh) * D.ldo + k0 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * D.ldo] = acc[r] + part[(wc * 16 + r) * 64 + lane];
-    }
-}
-
 // ---- kernels ---------------------------------------------------------------------------------------------------------------
 template <int AX, bool BT, int EM>
 __global__ void __launch_bounds__(256) gemm_mid_kernel(const MidGemm G, int tiles_n) {
@@ -553,42 +312,6 @@ __global__ void __launch_bounds__(256) da_dw_mid_kernel(const MidGemm G, int til
     } else {
         const int b = blockIdx.x - g1, per = tiles_c * tiles_k;
         mid_dw_tile<A2X>(D, (b % per) / tiles_k, (b % per) % tiles_k, b / per, lds);
-    }
-}
-
-template <int AX, bool BT, int EM>
-__global__ void __launch_bounds__(256, 2) gemm_mid32_kernel(const MidGemm G, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    mid_gemm_tile32<AX, BT, EM>(G, blockIdx.x / tiles_n, blockIdx.x % tiles_n, lds);
-}
-
-template <int EM, int A2X>
-__global__ void __launch_bounds__(256, 2) da_dw_mid32_kernel(const MidGemm G, int tiles_n, int g1, const MidDw D, int tiles_c, int tiles_k) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    if ((int)blockIdx.x < g1) {
-        mid_gemm_tile32<A_PLAIN, false, EM>(G, blockIdx.x / tiles_n, blockIdx.x % tiles_n, lds);
-    } else {
-        const int b = blockIdx.x - g1, per = tiles_c * tiles_k;
-        mid_dw_tile32<A2X>(D, (b % per) / tiles_k, (b % per) % tiles_k, b / per, lds);
-    }
-}
-
-// A/B switch: PNPP_MID_BN=64 keeps the 64 x 64 tiles
-static int mid_tile_n() {
-    static int cached = -1;
-    if (cached < 0) {
-        const char *v = getenv("PNPP_MID_BN");
-        cached = (v && atoi(v) == 64) ? 64 : 32;
-    }
-    return cached;
-}
-
-template <typename K>
-static void mid_grant_lds32(K kfn) {
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MID_LDS32_BYTES);
-        done = true;
     }
 }
 
@@ -615,26 +338,6 @@ bool try_launch_mid_gemm(const AOperand &A, const BOperand &B, int M, int Nout, 
     if (M / MID_T > kMaxStatBlocks) return false;
     MidGemm G{A.a, A.lda, A.scale, A.shift, B.b, B.ldb, M, Nout, Kd, E};
     if (nslab) *nslab = M / MID_T;
-    if (mid_tile_n() == 32) {
-        const int tn = Nout / MID_N32, grid = (M / MID_T) * tn;
-        ProfScope ps(st, "gemm_mid32_kernel<A%d,E%d,T1> M=%d N=%d K=%d grid=%d", A.mode, E.mode, M, Nout, Kd, grid);
-#define PNPP_MID32(AX, EMV)                                                                                \
-    {                                                                                                      \
-        mid_grant_lds32(gemm_mid32_kernel<AX, true, EMV>);                                                 \
-        hipLaunchKernelGGL((gemm_mid32_kernel<AX, true, EMV>), dim3(grid), dim3(256), MID_LDS32_BYTES, st, G, tn); \
-    }
-        if (A.mode == A_BNRELU) {
-            if (E.mode == E_STORE_STATS) PNPP_MID32(A_BNRELU, E_STORE_STATS) else PNPP_MID32(A_BNRELU, E_STORE)
-        } else {
-            if (E.mode == E_STORE_STATS) PNPP_MID32(A_PLAIN, E_STORE_STATS) else PNPP_MID32(A_PLAIN, E_STORE)
-        }
-#undef PNPP_MID32
-        if (hipGetLastError() != hipSuccess) {
-            set_error("gemm_mid32: launch failed");
-            *rc = PNPP_ERR_LAUNCH;
-        }
-        return true;
-    }
     const int tn = Nout / MID_T, grid = (M / MID_T) * tn;
     ProfScope ps(st, "gemm_mid_kernel<A%d,E%d,T1> M=%d N=%d K=%d grid=%d", A.mode, E.mode, M, Nout, Kd, grid);
 #define PNPP_MID(AX, EMV)                                                                              \
@@ -682,27 +385,6 @@ bool try_launch_mid_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout
     MidDw D{dz.a, dz.lda, a2.a, a2.lda, a2.scale, a2.shift, M, Nc, Kp, nsplit, M / nsplit, slab, Kp};
     if (nslab) *nslab = M / MID_T;
     *nsplit_out = nsplit, *kp_pad_out = Kp;
-    if (mid_tile_n() == 32) {
-        const int tn = Nout / MID_N32, g1 = (M / MID_T) * tn, tc = Nc / MID_T, tk = Kp / MID_N32, g2 = tc * tk * nsplit;
-        ProfScope ps(st, "da_dw_mid32_kernel<E%d,A%d> M=%d | dA N=%d K=%d grid=%d | dW N=%d K=%d split=%d grid=%d", E.mode, a2.mode, M, Nout,
-                     Kd, g1, Nc, Kp, nsplit, g2);
-#define PNPP_MIDP32(EMV, AX)                                                                                         \
-    {                                                                                                                \
-        mid_grant_lds32(da_dw_mid32_kernel<EMV, AX>);                                                                \
-        hipLaunchKernelGGL((da_dw_mid32_kernel<EMV, AX>), dim3(g1 + g2), dim3(256), MID_LDS32_BYTES, st, G, tn, g1, D, tc, tk); \
-    }
-        if (E.mode == E_STORE) {
-            if (a2.mode == A_BNRELU) PNPP_MIDP32(E_STORE, A_BNRELU) else PNPP_MIDP32(E_STORE, A_PLAIN)
-        } else {
-            if (a2.mode == A_BNRELU) PNPP_MIDP32(E_MASK_STATS, A_BNRELU) else PNPP_MIDP32(E_MASK_STATS, A_PLAIN)
-        }
-#undef PNPP_MIDP32
-        if (hipGetLastError() != hipSuccess) {
-            set_error("da_dw_mid32: launch failed");
-            *rc = PNPP_ERR_LAUNCH;
-        }
-        return true;
-    }
     const int tn = Nout / MID_T, g1 = (M / MID_T) * tn, tc = Nc / MID_T, tk = Kp / MID_T, g2 = tc * tk * nsplit;
     ProfScope ps(st, "da_dw_mid_kernel<E%d,A%d> M=%d | dA N=%d K=%d grid=%d | dW N=%d K=%d split=%d grid=%d", E.mode, a2.mode, M, Nout, Kd, g1,
                  Nc, Kp, nsplit, g2);

@@ -8,6 +8,7 @@
 // tables ATen's torch.special.i0/i1 evaluate, BSD-licensed Cephes Math Library constants);
 // log I0(k) = k + log(i0e(k)) never overflows, A(k) = I1/I0 = i1e/i0e, A'(k) = 1 - A^2 - A/k.
 #include "kernels.h"
+#include "sampler_device.h"
 
 namespace pnpp {
 
@@ -223,8 +224,18 @@ __global__ void __launch_bounds__(256) vm_head_kl_mean_kernel(const float *__res
 __global__ void __launch_bounds__(256)
 vm_fc_head_kl_step_kernel(const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ bias,
                           const float *__restrict__ mu_gt, const float *__restrict__ kappa_gt, int B, int K, int x_in_lds,
-                          float *__restrict__ loss_mean, float *__restrict__ dW, float *__restrict__ db, float *__restrict__ dx) {
+                          float *__restrict__ loss_mean, float *__restrict__ dW, float *__restrict__ db, float *__restrict__ dx,
+                          const SampleJob J) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // o[B][2] (then d_o in place), xs[B][K] when it fits
+    // The tail is ONE workgroup on a 256-CU chip.  The centre draw of the NEXT step (models/pointnet_pp_8dir.py:28 of sa1 and sa2)
+    // depends on nothing but its counter, so its 2 B workgroups ride in this launch (blocks 1 ..) instead of opening the next step
+    // with a launch of their own: same draws, same order, one launch and ~7 us fewer per step.
+    if (blockIdx.x > 0) {
+        __shared__ int nc_s;
+        sample_random_body(J.seed_lo, J.seed_hi, J.str_lo, J.str_hi, J.str_dev, J.N1, J.npoint1, J.out1, J.B, J.N2, J.npoint2, J.out2,
+                           (int)blockIdx.x - 1, (int)gridDim.x - 1, reinterpret_cast<unsigned long long *>(sm), nc_s);
+        return;
+    }
     __shared__ double red[256];
     float *o = sm;
     float *ws = sm + ((2 * B + 3) & ~3);         // W (2 x K) in LDS: with x, ONE round trip for everything the kernel reads
@@ -754,8 +765,37 @@ extern "C" int pnpp_vm_fc_head_kl_step(const float *x, const float *w, const flo
     PNPP_REQUIRE(lds <= 56 * 1024, PNPP_ERR_RANGE, "vm_fc_head_kl_step: 2*B + 2*K (+ B*K) floats = %zu bytes of LDS exceed 56 KB (B=%d, K=%d)",
                  lds, B, K);
     hipLaunchKernelGGL(vm_fc_head_kl_step_kernel, dim3(1), dim3(256), lds, as_stream(stream), x, w, b, mu_gt, kappa_gt, B, K, x_in_lds,
-                       loss_mean, dw, db, dx);
+                       loss_mean, dw, db, dx, SampleJob());
     PNPP_CHECK_LAUNCH("vm_fc_head_kl_step");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_vm_fc_head_kl_step_sample(const float *x, const float *w, const float *b, const float *mu_gt, const float *kappa_gt,
+                                              int B, int K, float *loss_mean, float *dw, float *db, float *dx, uint64_t seed,
+                                              uint64_t *stream_id_dev, uint64_t offset, int Bs, int N1, int npoint1, int32_t *out1, int N2,
+                                              int npoint2, int32_t *out2, void *stream) {
+    PNPP_REQUIRE(x && w && b && mu_gt && kappa_gt && loss_mean && dw && db, PNPP_ERR_ARG, "vm_fc_head_kl_step_sample: null pointer");
+    PNPP_REQUIRE(B > 0 && K > 0 && B <= 8192, PNPP_ERR_ARG, "vm_fc_head_kl_step_sample: B must be in 1..8192 and K positive");
+    PNPP_REQUIRE(stream_id_dev && out1 && out2, PNPP_ERR_ARG, "vm_fc_head_kl_step_sample: null sampler pointer");
+    PNPP_REQUIRE(Bs > 0 && N1 > 0 && npoint1 > 0 && N2 > 0 && npoint2 > 0, PNPP_ERR_ARG, "vm_fc_head_kl_step_sample: non-positive sampler size");
+    PNPP_REQUIRE(npoint1 <= N1 && npoint2 <= N2, PNPP_ERR_RANGE, "sample_random_dev2: npoint exceeds N");
+    const size_t o_floats = ((size_t)2 * B + 3) & ~(size_t)3;
+    const int x_in_lds = ((size_t)B * K <= 12288 && (((size_t)B * K) & 3) == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
+    const size_t w_floats = ((size_t)2 * K + 3) & ~(size_t)3;
+    size_t lds = (o_floats + w_floats + (x_in_lds ? (size_t)B * K : 0)) * sizeof(float);
+    const int Nmax = N1 > N2 ? N1 : N2;
+    const size_t lds_s = (size_t)(Nmax + 1) * sizeof(unsigned long long);   // the sampling workgroups' candidate table
+    if (lds_s > lds) lds = lds_s;
+    PNPP_REQUIRE(lds <= 56 * 1024, PNPP_ERR_RANGE, "vm_fc_head_kl_step_sample: %zu bytes of LDS exceed 56 KB (B=%d, K=%d, N=%d)", lds, B, K, Nmax);
+    SampleJob J;
+    J.seed_lo = (unsigned)seed, J.seed_hi = (unsigned)(seed >> 32), J.str_lo = (unsigned)offset, J.str_hi = (unsigned)(offset >> 32);
+    J.str_dev = reinterpret_cast<unsigned long long *>(stream_id_dev);
+    J.B = Bs, J.N1 = N1, J.npoint1 = npoint1, J.N2 = N2, J.npoint2 = npoint2, J.out1 = out1, J.out2 = out2;
+    ProfScope ps(as_stream(stream), "vm_fc_head_kl_step_kernel B=%d K=%d + sample_random B=%d N=%d npoint=%d + N=%d npoint=%d", B, K, Bs, N1,
+                 npoint1, N2, npoint2);
+    hipLaunchKernelGGL(vm_fc_head_kl_step_kernel, dim3(1 + 2 * Bs), dim3(256), lds, as_stream(stream), x, w, b, mu_gt, kappa_gt, B, K,
+                       x_in_lds, loss_mean, dw, db, dx, J);
+    PNPP_CHECK_LAUNCH("vm_fc_head_kl_step_sample");
     return PNPP_OK;
 }
 

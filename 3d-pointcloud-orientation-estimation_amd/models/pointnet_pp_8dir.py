@@ -138,9 +138,18 @@ class BackboneBNHead(nn.Module):
         self.bn2 = nn.BatchNorm1d(256)
         self.drop = nn.Dropout(0.5)
 
+    _presampled = None
+
+    def use_presampled(self, ring) -> None:
+        """ring: a pnpp_hip.sampling.CentreRing whose buffers hold the centres of the next forward pass (drawn one step ahead
+        by the previous step's tail launch); None switches back to drawing at the start of the step."""
+        self._presampled = ring
+
     def levels12(self, xyz, centres=None):
         """sa1 + sa2 -> (l2_xyz, l2_points); centres = (sa1 centre indices, sa2 centre indices) injects the draws."""
         B = xyz.size(0)
+        if centres is None and self._presampled is not None and self.training and self._presampled.B == B:
+            centres = self._presampled.centres
         c1, c2 = centres if centres is not None else (None, None)
         if (centres is None and self.sa1.sampler == "device" and self.sa2.sampler == "device" and not self.sa1.group_all
                 and not self.sa2.group_all):

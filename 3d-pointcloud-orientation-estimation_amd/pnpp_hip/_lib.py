@@ -87,6 +87,8 @@ SIGNATURES = {
     "pnpp_fc_backward": (_i, [C.POINTER(FcDesc), C.POINTER(FcBwdArgs), _fp]),
     "pnpp_vm_head_kl": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp]),
     "pnpp_vm_fc_head_kl_step": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _fp, _fp]),
+    "pnpp_vm_fc_head_kl_step_sample": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _fp, _u64, _fp, _u64, _i, _i, _i, _fp, _i, _i,
+                                            _fp, _fp]),
     "pnpp_vm_head_kl_mean": (_i, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp]),
     "pnpp_vm_head_bwd": (_i, [_fp, _fp, _fp, _i, _fp, _fp]),
     "pnpp_vm_kl_single": (_i, [_fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp]),

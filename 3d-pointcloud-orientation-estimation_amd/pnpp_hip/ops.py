@@ -642,7 +642,7 @@ def vm_head_kl_loss_backward(o, mu_gt, kappa_gt) -> torch.Tensor:
     return loss
 
 
-def vm_fc_head_kl_loss_backward(x, linear, mu_gt, kappa_gt) -> torch.Tensor:
+def vm_fc_head_kl_loss_backward(x, linear, mu_gt, kappa_gt, next_centres=None) -> torch.Tensor:
     """`o = linear(x)` (the model's fc3, two outputs), head, single-peak KL, `.mean()` and `loss.backward()` in ONE launch
     (pointnet_pp_vonMises.py:35-37 + train_single_peak_vonMises_KL.py:82-84): the gradients of `linear` land in its
     .grad (or the optimiser's flat buffer), the gradient of x seeds the rest of the backward pass.  Returns the
@@ -654,14 +654,25 @@ def vm_fc_head_kl_loss_backward(x, linear, mu_gt, kappa_gt) -> torch.Tensor:
         raise ValueError("vm_fc_head_kl_loss_backward: linear must map K -> 2 and the targets must be (B,)")
     if 4 * (2 * B + 2 * K + 8 + (B * K if B * K <= 12288 else 0)) > 56 * 1024:
         # the one-launch form stages fc3's weights and the outputs in LDS (56 KB); wider heads take the three launches it fuses
+        if next_centres is not None:
+            seed, counter, offset, Bs, N1, c1, N2, c2 = next_centres
+            L.check(L.lib().pnpp_sample_random_dev2(int(seed) & (2**64 - 1), counter.data_ptr(), int(offset), Bs, N1, c1.shape[1],
+                                                    c1.data_ptr(), N2, c2.shape[1], c2.data_ptr(), _stream()))
         return vm_head_kl_loss_backward(fc_block(x, linear, training=True), mu_gt, kappa_gt)
     loss = torch.empty((), device=x32.device, dtype=torch.float32)
     sinks = [grad_sink(p) for p in (linear.weight, linear.bias)]
     dw = sinks[0] if sinks[0] is not None else torch.empty_like(w)
     db = sinks[1] if sinks[1] is not None else torch.empty_like(b)
     dx = torch.empty_like(x32) if x.requires_grad else None
-    L.check(L.lib().pnpp_vm_fc_head_kl_step(x32.data_ptr(), w.data_ptr(), b.data_ptr(), mu_gt.data_ptr(), kappa_gt.data_ptr(), B, K,
-                                            loss.data_ptr(), dw.data_ptr(), db.data_ptr(), _p(dx), _stream()))
+    if next_centres is not None:   # sampling.CentreRing.job(): the next step's centre draw rides in this launch's idle CUs
+        seed, counter, offset, Bs, N1, c1, N2, c2 = next_centres
+        L.check(L.lib().pnpp_vm_fc_head_kl_step_sample(x32.data_ptr(), w.data_ptr(), b.data_ptr(), mu_gt.data_ptr(), kappa_gt.data_ptr(),
+                                                       B, K, loss.data_ptr(), dw.data_ptr(), db.data_ptr(), _p(dx), int(seed) & (2**64 - 1),
+                                                       counter.data_ptr(), int(offset), Bs, N1, c1.shape[1], c1.data_ptr(), N2, c2.shape[1],
+                                                       c2.data_ptr(), _stream()))
+    else:
+        L.check(L.lib().pnpp_vm_fc_head_kl_step(x32.data_ptr(), w.data_ptr(), b.data_ptr(), mu_gt.data_ptr(), kappa_gt.data_ptr(), B, K,
+                                                loss.data_ptr(), dw.data_ptr(), db.data_ptr(), _p(dx), _stream()))
     for p, g, sink in ((linear.weight, dw, sinks[0]), (linear.bias, db, sinks[1])):
         if sink is None and p.requires_grad:                     # plain autograd semantics: accumulate into .grad
             if p.grad is None:

@@ -69,11 +69,22 @@ def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=Tr
 
     fused_tail = os.environ.get("PNPP_FUSED_TAIL", "1") != "0"
 
+    # the centres of step t+1 are drawn by step t's tail launch, in the 255 CUs its single workgroup leaves idle (PNPP_TAIL_SAMPLER=0:
+    # every step opens with its own sampling launch); the draws and their order are the same either way
+    ring = None
+    if (fused_tail and os.environ.get("PNPP_TAIL_SAMPLER", "1") != "0" and model.sa1.sampler == "device" and model.sa2.sampler == "device"
+            and model._presampled is None):
+        from pnpp_hip import sampling as _sampling
+        ring = _sampling.CentreRing(xyz.size(0), xyz.size(1), model.sa1.npoint, model.sa2.npoint, xyz.device)
+        model.use_presampled(ring)
+    elif fused_tail and model._presampled is not None:
+        ring = model._presampled
+
     def tail(f, m, k):
         # fc3 + head + KL + .mean() + the seed of loss.backward() (train_single_peak_vonMises_KL.py:82-84) + fc3's backward in ONE
         # launch (12.5 us; as three launches -- fc3, head/KL, fc3 backward: 16.1 us, PNPP_FUSED_TAIL=0)
         if fused_tail:
-            return ops.vm_fc_head_kl_loss_backward(f, model.fc3, m, k)
+            return ops.vm_fc_head_kl_loss_backward(f, model.fc3, m, k, next_centres=ring.job() if ring is not None else None)
         return ops.vm_head_kl_loss_backward(ops.fc_block(f, model.fc3, training=model.training), m, k)
 
     def loss_fn(x, m, k):

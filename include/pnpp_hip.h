@@ -242,6 +242,14 @@ int pnpp_vm_head_kl(const float *o, const float *mu_gt, const float *kappa_gt, i
  * loss_mean[0], dw (2,K), db (2), dx (B,K; may be NULL).  Gradients are written, not accumulated. */
 int pnpp_vm_fc_head_kl_step(const float *x, const float *w, const float *b, const float *mu_gt, const float *kappa_gt, int B,
                             int K, float *loss_mean, float *dw, float *db, float *dx, void *stream);
+/* The same launch, carrying the NEXT step's centre draw in its idle CUs: workgroup 0 is pnpp_vm_fc_head_kl_step, workgroups 1 .. 2*Bs
+ * are pnpp_sample_random_dev2(seed, stream_id_dev, offset, Bs, N1, npoint1, out1, N2, npoint2, out2) -- the draws of
+ * models/pointnet_pp_8dir.py:28 for sa1 and sa2 depend on nothing but their counter, so a training loop that keeps (out1, out2)
+ * as the centres of its next forward pass draws exactly the sequence it would draw at the start of every step, one launch fewer. */
+int pnpp_vm_fc_head_kl_step_sample(const float *x, const float *w, const float *b, const float *mu_gt, const float *kappa_gt, int B,
+                                   int K, float *loss_mean, float *dw, float *db, float *dx, uint64_t seed, uint64_t *stream_id_dev,
+                                   uint64_t offset, int Bs, int N1, int npoint1, int32_t *out1, int N2, int npoint2, int32_t *out2,
+                                   void *stream);
 /* The same, followed by the batch mean of train_single_peak_vonMises_KL.py:83 (`loss = kl_von_mises(...).mean()`),
  * in one single-workgroup launch: loss_mean[0] = mean_b loss_vec[b] (fixed-order fp64 sum),
  * d_o_mean (B,2) = d loss_mean / d o.  mu, kappa and loss_vec may be NULL. */

@@ -429,3 +429,47 @@ def test_hipgraph_replays_are_bitwise_reproducible(oracle):
         loss = g(xyz, mu_gt, kappa_gt)
         assert float(loss) == ref_l, (it, float(loss), ref_l)
         assert torch.equal(o1.flat_g, ref_g), it
+
+
+def test_centres_drawn_one_step_ahead_by_the_tail_launch(oracle):
+    """sampling.CentreRing + pnpp_vm_fc_head_kl_step_sample (bench.py's default step): the draws of step t+1 ride in step t's
+    single-workgroup tail launch.  Same counter sequence, same kernels' arithmetic: every step's loss and the parameters after
+    three optimiser steps are bit for bit those of the loop that opens each step with its own sampling launch
+    (models/pointnet_pp_8dir.py:28 of sa1 and sa2, drawn per step)."""
+    import copy
+    from models.pointnet_pp_vonMises import PointNetPPVonMises
+    from pnpp_hip import ops, optim, sampling
+    torch.manual_seed(42)
+    m1 = PointNetPPVonMises(sampler="device").cuda().train()
+    m2 = copy.deepcopy(m1)
+    o1, o2 = optim.FlatAdam(m1.parameters()), optim.FlatAdam(m2.parameters())
+    xyz, mu_gt, kappa_gt, _ = oracle.synthetic_clouds(8, 1024, seed=3)
+    xyz, mu_gt, kappa_gt = xyz.cuda(), mu_gt.cuda(), kappa_gt.cuda()
+    m1.trunk(xyz)                                        # creates the device-side counters
+    snap = sampling.snapshot()
+    for p, q in zip(m1.buffers(), m2.buffers()):
+        p.copy_(q)
+
+    def run(model, opt, ring):
+        sampling.restore(snap)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            loss = ops.vm_fc_head_kl_loss_backward(model.trunk(xyz), model.fc3, mu_gt, kappa_gt,
+                                                   next_centres=ring.job() if ring is not None else None)
+            opt.step()
+            losses.append(float(loss))
+        return losses
+
+    la = run(m2, o2, None)                                # every step opens with its own centre draw
+    ring = sampling.CentreRing(8, 1024, m1.sa1.npoint, m1.sa2.npoint, xyz.device)
+    m1.use_presampled(ring)
+    lb = run(m1, o1, ring)                                # primed once, then refilled by each step's tail launch
+    assert la == lb, (la, lb)
+    assert torch.equal(o1.flat_p, o2.flat_p)
+    # after step 3 the ring already holds the centres step 4 would draw
+    sampling.restore(snap)
+    want = None
+    for _ in range(4):
+        want = sampling.device_random_centres_pair(8, 1024, m1.sa1.npoint, m1.sa1.npoint, m1.sa2.npoint, xyz.device)
+    assert torch.equal(ring.c1, want[0]) and torch.equal(ring.c2, want[1])
