@@ -229,6 +229,12 @@ def fit(model: torch.nn.Module, loss_fn: LossFn, loaders: Dict[str, Iterable], e
     "best" checkpoint is in fact the last one -- train_single_peak_vonMises_KL.py:90; the copy is deliberate).
     """
     world = pdist.world_size()
+    if world > 1 and os.environ.get("PNPP_SYNC_BN") == "1":
+        # SyncBN (off by default): BatchNorm statistics pooled over the ranks, so the global batch normalises like the reference's
+        # single process on the concatenated batch (22 small all-reduces per step; DDP-style per-rank statistics otherwise)
+        pdist.enable_sync_batchnorm()
+        if pdist.dist.get_backend() != "nccl" and use_graph is None:
+            use_graph = False                     # a host-staged exchange cannot be captured into a hipGraph
     if use_graph is None:
         use_graph = os.environ.get("PNPP_NO_GRAPH") != "1"
     if timing is None:
