@@ -2528,9 +2528,9 @@ bool try_launch_fc_dx_dw(const float *dz, const float *w, const float *x, int M,
 // dA (+ its epilogue) and dW of one small-M backward layer in one launch; returns false (nothing launched) when the
 // pair does not fit that form, and the caller launches the two separately.
 bool try_launch_da_dw(const AOperand &dz, const BOperand &Win, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,
-                      int Kp, float *slab, int *nsplit_io, int *kp_pad_io, hipStream_t st, int *rc) {
+                      int Kp, float *slab, int *nsplit_io, int *kp_pad_io, hipStream_t st, int *rc, float *dw_direct, int dw_ld) {
     *rc = PNPP_OK;
-    if (mid_tiles_on() && try_launch_mid_da_dw(dz, Win, M, Nout, Kd, E, nslab, a2, Kp, slab, nsplit_io, kp_pad_io, st, rc))
+    if (mid_tiles_on() && try_launch_mid_da_dw(dz, Win, M, Nout, Kd, E, nslab, a2, Kp, slab, nsplit_io, kp_pad_io, st, rc, dw_direct, dw_ld))
         return true;   // wide layers of a group_all level: 64 x 64 tiles over the whole reduction, no 64-row partials
     const int nsplit = *nsplit_io, kp_pad = *kp_pad_io;
     const int Nc = Kd;  // dZ is M x Nc; dA = dZ W contracts over Nc, dW is Nc x Kp
@@ -3027,7 +3027,9 @@ int launch_post_gemm(const double *slab, int nslab, int C, double count, int tra
     const DzJob J = make_dz_job(dz, M, C, dz_out);
     const int total = Nc * Kvalid, nfin = cdiv(C, FIN_COLS), ndz = dz_job_blocks(J, C), nf = nfin + ndz;
     ProfScope ps(st, "post_gemm_kernel C=%d%s | N=%d K=%d split=%d", C, ndz ? " +dZ" : "", Nc, Kvalid, nsplit);
-    if (slab_reduce_vec4(R)) {
+    if (nsplit == 0) {   // the weight gradient was written in place by its GEMM (one row range): nothing to reduce
+        hipLaunchKernelGGL(post_gemm_kernel<64>, dim3(nf), dim3(256), 0, st, F, nfin, R, ndz, J);
+    } else if (slab_reduce_vec4(R)) {
         const int groups = total / 4, epb = slab_reduce_epb4(nsplit);
         if (epb == 64) hipLaunchKernelGGL((post_gemm_kernel<64, true>), dim3(nf + cdiv(groups, 64)), dim3(256), 0, st, F, nfin, R, ndz, J);
         else if (epb == 16) hipLaunchKernelGGL((post_gemm_kernel<16, true>), dim3(nf + cdiv(groups, 16)), dim3(256), 0, st, F, nfin, R, ndz, J);
@@ -3047,7 +3049,8 @@ int launch_post_gemm(const double *slab, int nslab, int C, double count, int tra
 __global__ void __launch_bounds__(256) pool_fwd_kernel(const float *__restrict__ z, const float *__restrict__ scale,
                                                        const float *__restrict__ shift, int G, int K, int C,
                                                        float *__restrict__ out, int32_t *__restrict__ arg,
-                                                       float *__restrict__ origin_a, float *__restrict__ origin_b, int norigin) {
+                                                       float *__restrict__ origin_a, float *__restrict__ origin_b, int norigin,
+                                                       float *__restrict__ zsel) {
     if (blockIdx.x == 0)  // group_all levels: the centre of every cloud is the origin (pointnet_pp_8dir.py:24); no launch of its own
         for (int i = threadIdx.x; i < norigin; i += 256) {
             if (origin_a) origin_a[i] = 0.f;
@@ -3059,7 +3062,7 @@ __global__ void __launch_bounds__(256) pool_fwd_kernel(const float *__restrict__
         const int c = (int)(i - g * C);
         const float sc = scale[c], sh = shift[c];
         const float *p = z + g * K * C + c;
-        float best = -INFINITY;
+        float best = -INFINITY, zb = 0.f;
         int bi = 0;
         int k = 0;
         for (; k + 8 <= K; k += 8) {  // eight independent strided loads in flight per lane
@@ -3069,15 +3072,17 @@ __global__ void __launch_bounds__(256) pool_fwd_kernel(const float *__restrict__
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float v = fmaxf(fmaf(z[u], sc, sh), 0.f);
-                if (v > best) best = v, bi = k + u;
+                if (v > best) best = v, bi = k + u, zb = z[u];
             }
         }
         for (; k < K; ++k) {
-            const float v = fmaxf(fmaf(p[(size_t)k * C], sc, sh), 0.f);
-            if (v > best) best = v, bi = k;
+            const float zk = p[(size_t)k * C];
+            const float v = fmaxf(fmaf(zk, sc, sh), 0.f);
+            if (v > best) best = v, bi = k, zb = zk;
         }
         out[i] = best;
         arg[i] = bi;
+        if (zsel) zsel[i] = zb;   // the pre-BN value the maximum came from: backward reads it instead of gathering z
     }
 }
 
@@ -3164,7 +3169,7 @@ int pool_fwd_splits(int G, int K, int C) {
 }
 
 int launch_pool_fwd(const float *z, const float *scale, const float *shift, int G, int K, int C, float *out, int32_t *arg,
-                    hipStream_t st, float *origin_a, float *origin_b, int norigin, void *part) {
+                    hipStream_t st, float *origin_a, float *origin_b, int norigin, void *part, float *zsel) {
     const int nsplit = part ? pool_fwd_splits(G, K, C) : 1;
     if (nsplit > 1) {
         const int chunk = (cdiv(K, nsplit) + 3) & ~3;
@@ -3186,7 +3191,8 @@ int launch_pool_fwd(const float *z, const float *scale, const float *shift, int 
     const size_t total = (size_t)G * C;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     ProfScope ps(st, "pool_fwd_kernel G=%d K=%d C=%d", G, K, C);
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid), dim3(256), 0, st, z, scale, shift, G, K, C, out, arg, origin_a, origin_b, norigin);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid), dim3(256), 0, st, z, scale, shift, G, K, C, out, arg, origin_a, origin_b, norigin,
+                       zsel);
     PNPP_CHECK_LAUNCH("pool_fwd");
     return PNPP_OK;
 }
@@ -3197,7 +3203,8 @@ int launch_pool_fwd(const float *z, const float *scale, const float *shift, int 
 __global__ void __launch_bounds__(256)
 pool_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ arg, const float *__restrict__ z,
                 const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
-                const float *__restrict__ istd, int G, int K, int C, float *__restrict__ dm, double *__restrict__ slab) {
+                const float *__restrict__ istd, int G, int K, int C, float *__restrict__ dm, double *__restrict__ slab,
+                const float *__restrict__ zsel) {
     __shared__ double red[4][2][64];
     const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -3206,7 +3213,9 @@ pool_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ arg,
         const float mu = mean[c], is = istd[c], sc = scale[c], sh = shift[c];
         for (int g = blockIdx.y * 4 + gl; g < G; g += gridDim.y * 4) {
             const size_t gi = (size_t)g * C + c;
-            const float za = z[((size_t)g * K + arg[gi]) * C + c];
+            // the pre-BN value behind the pooled output: kept by the forward pass (zsel, a coalesced stream), or gathered --
+            // one 4-byte element per (group, channel) out of a row of Z, a 64-byte line each
+            const float za = zsel ? zsel[gi] : z[((size_t)g * K + arg[gi]) * C + c];
             const float d = fmaf(za, sc, sh) > 0.f ? dout[gi] : 0.f;  // ReLU'(pooled value), same expression as forward
             dm[gi] = d;
             s1 += (double)d;
@@ -3227,14 +3236,14 @@ pool_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ arg,
 
 int launch_pool_bwd(const float *dout, const int32_t *arg, const float *z, const float *scale, const float *shift,
                     const float *mean, const float *istd, int G, int K, int C, float *dm, double *slab, int *nslab,
-                    hipStream_t st) {
+                    hipStream_t st, const float *zsel) {
     int gy = cdiv(G, 16);  // four groups per lane-row and pass
     if (gy > kMaxStatBlocks) gy = kMaxStatBlocks;
     if (gy < 1) gy = 1;
     *nslab = gy;
     ProfScope ps(st, "pool_bwd_kernel G=%d K=%d C=%d", G, K, C);
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(cdiv(C, 64), gy), dim3(256), 0, st, dout, arg, z, scale, shift, mean, istd, G, K, C,
-                       dm, slab);
+                       dm, slab, zsel);
     PNPP_CHECK_LAUNCH("pool_bwd");
     return PNPP_OK;
 }

@@ -371,7 +371,7 @@ bool mid_da_dw_plan(int M, int Nout, int Nc, int Kp, int *nsplit) {
 }
 
 bool try_launch_mid_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,
-                          int Kp, float *slab, int *nsplit_out, int *kp_pad_out, hipStream_t st, int *rc) {
+                          int Kp, float *slab, int *nsplit_out, int *kp_pad_out, hipStream_t st, int *rc, float *dw_direct, int dw_ld) {
     *rc = PNPP_OK;
     const int Nc = Kd;
     int nsplit = 1;
@@ -383,8 +383,10 @@ bool try_launch_mid_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout
     if (M / MID_T > kMaxStatBlocks) return false;
     MidGemm G{dz.a, dz.lda, nullptr, nullptr, W.b, W.ldb, M, Nout, Kd, E};
     MidDw D{dz.a, dz.lda, a2.a, a2.lda, a2.scale, a2.shift, M, Nc, Kp, nsplit, M / nsplit, slab, Kp};
+    const bool in_place = nsplit == 1 && dw_direct && dw_ld == Kp;   // a single row range: no partial sums, no reduction launch
+    if (in_place) D.out = dw_direct, D.ldo = dw_ld;
     if (nslab) *nslab = M / MID_T;
-    *nsplit_out = nsplit, *kp_pad_out = Kp;
+    *nsplit_out = in_place ? 0 : nsplit, *kp_pad_out = Kp;
     const int tn = Nout / MID_T, g1 = (M / MID_T) * tn, tc = Nc / MID_T, tk = Kp / MID_T, g2 = tc * tk * nsplit;
     ProfScope ps(st, "da_dw_mid_kernel<E%d,A%d> M=%d | dA N=%d K=%d grid=%d | dW N=%d K=%d split=%d grid=%d", E.mode, a2.mode, M, Nout, Kd, g1,
                  Nc, Kp, nsplit, g2);

@@ -134,12 +134,13 @@ bool try_launch_fc_dx_dw(const float *dz, const float *w, const float *x, int M,
                          int *rc);
 // *nsplit / *kp_pad: in = what dw_plan chose (the slab is sized for it); out = the partial count and pitch actually written
 bool try_launch_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,
-                      int Kp, float *slab, int *nsplit, int *kp_pad, hipStream_t st, int *rc);
+                      int Kp, float *slab, int *nsplit, int *kp_pad, hipStream_t st, int *rc, float *dw_direct = nullptr, int dw_ld = 0);
 // gemm_mid_kernels.hip: 64 x 64 tiles over the whole reduction for the group_all level's wide layers
 bool try_launch_mid_gemm(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st,
                          int *rc);
 bool try_launch_mid_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,
-                          int Kp, float *slab, int *nsplit_out, int *kp_pad_out, hipStream_t st, int *rc);
+                          int Kp, float *slab, int *nsplit_out, int *kp_pad_out, hipStream_t st, int *rc, float *dw_direct = nullptr,
+                          int dw_ld = 0);   // dw_direct (Nc x dw_ld, dw_ld == Kp): written in place when one row range suffices; *nsplit_out = 0 then
 int launch_slab_reduce2(const float *slab1, int nsplit1, int Nc1, int kp_pad1, int Kvalid1, float *out1, int ldo1, const float *slab2,
                         int nsplit2, int Nc2, int kp_pad2, int Kvalid2, float *out2, int ldo2, hipStream_t st);
 int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kvalid, int perm_D, float *out, int ldo,
@@ -184,12 +185,13 @@ double *stats_buffer_local();
 // is split over K into partial maxima that a second launch merges (first maximum wins, as in the one-launch form)
 int pool_fwd_splits(int G, int K, int C);
 int launch_pool_fwd(const float *z, const float *scale, const float *shift, int G, int K, int C, float *out, int32_t *arg,
-                    hipStream_t st, float *origin_a = nullptr, float *origin_b = nullptr, int norigin = 0, void *part = nullptr);
+                    hipStream_t st, float *origin_a = nullptr, float *origin_b = nullptr, int norigin = 0, void *part = nullptr,
+                    float *zsel = nullptr);
 // backward of max + ReLU without materialising the dense gradient: writes the masked pooled gradient dm (G x C)
 // and collects the BatchNorm-backward column sums; consumers rebuild dy on the fly (A_DZ_POOL)
 int launch_pool_bwd(const float *dout, const int32_t *arg, const float *z, const float *scale, const float *shift,
                     const float *mean, const float *istd, int G, int K, int C, float *dm, double *slab, int *nslab,
-                    hipStream_t st);
+                    hipStream_t st, const float *zsel = nullptr);
 
 int launch_fill_zero(void *p, size_t bytes, hipStream_t st);
 

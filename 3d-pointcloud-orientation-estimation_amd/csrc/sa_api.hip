@@ -140,8 +140,12 @@ struct SaSaved {
     float *z[PNPP_MAX_LAYERS];
     float *mean[PNPP_MAX_LAYERS], *istd[PNPP_MAX_LAYERS], *scale[PNPP_MAX_LAYERS], *shift[PNPP_MAX_LAYERS];
     int32_t *arg;
+    float *zmax;   // (G, C_last): the pre-BN value each pooled output came from (the backward pass's ReLU gate and xhat need it)
     size_t bytes;
 };
+
+// whole-cloud pooling in K chunks (pool_fwd_split / merge) does not produce the selected pre-BN values; backward gathers them there
+static bool sa_keeps_zmax(const pnpp_sa_desc *d, const SaGeom &g) { return pool_fwd_splits(g.G, d->K, d->C[d->L - 1]) <= 1; }
 
 static SaSaved sa_saved_layout(const pnpp_sa_desc *d, const SaGeom &g, void *base) {
     Carver cv(base);
@@ -156,6 +160,7 @@ static SaSaved sa_saved_layout(const pnpp_sa_desc *d, const SaGeom &g, void *bas
         s.shift[l] = cv.take<float>(d->C[l]);
     }
     s.arg = cv.take<int32_t>((size_t)g.G * d->C[d->L - 1]);
+    s.zmax = cv.take<float>(sa_keeps_zmax(d, g) ? (size_t)g.G * d->C[d->L - 1] : 0);
     s.bytes = cv.bytes();
     return s;
 }
@@ -313,15 +318,15 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
             E.mode = E_STORE_STATS;
             E.slab = sc.slab;
             // last layer of a level with 32-row neighbourhoods: the max over the neighbourhood is taken from the GEMM's accumulators
-            // and finished by the statistics launch (sc.dm, idle in the forward pass, holds the extreme pre-BN values)
+            // and finished by the statistics launch (sv.zmax holds the extreme pre-BN values; the backward pass reads them too)
             const bool pool_here = l == d->L - 1 && !d->group_all && pool_fused_on() && gemm_pools_in_epilogue(A, g.M, d->C[l], g.Kd[l], d->K);
-            if (pool_here) E.pool_ext = sc.dm, E.pool_arg = sv.arg, E.pool_gamma = a->bn_w[l];
+            if (pool_here) E.pool_ext = sv.zmax, E.pool_arg = sv.arg, E.pool_gamma = a->bn_w[l];
             PNPP_TRY(launch_gemm(A, W, g.M, d->C[l], g.Kd[l], E, &nslab, st));
             StatsView V;
             PNPP_TRY(stats_exchange(sc.slab, nslab, d->C[l], (double)g.M, st, &V));
             PNPP_TRY(launch_bn_finalize_fwd(V.slab, V.nslab, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
                                             a->bn_rm[l], a->bn_rv[l], (long long *)a->bn_nbt[l], d->momentum, d->eps, 1, sv.mean[l], sv.istd[l],
-                                            sv.scale[l], sv.shift[l], st, V.count_dev, pool_here ? sc.dm : nullptr,
+                                            sv.scale[l], sv.shift[l], st, V.count_dev, pool_here ? sv.zmax : nullptr,
                                             pool_here ? a->out : nullptr, g.G, pool_here ? sv.arg : nullptr));
             pooled = pool_here;
         } else {
@@ -337,7 +342,8 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
     const int Lm = d->L - 1;
     if (!pooled) PNPP_TRY(launch_pool_fwd(sv.z[Lm], sv.scale[Lm], sv.shift[Lm], g.G, d->K, d->C[Lm], a->out, sv.arg, st,
                              d->group_all ? a->new_xyz : nullptr, d->group_all ? sv.new_xyz : nullptr, d->group_all ? g.G * 3 : 0,
-                             sc.dy[0]));  // dy[0] (M x C floats) is idle in the forward pass: >= the K/64 partials per (group, channel)
+                             sc.dy[0],   // dy[0] (M x C floats) is idle in the forward pass: >= the K/64 partials per (group, channel)
+                             sa_keeps_zmax(d, g) ? sv.zmax : nullptr));
     return PNPP_OK;
 }
 
@@ -356,7 +362,7 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
     const int Lm = d->L - 1;
     int cur = 0, nslab = 0, nslab_next = 0;
     PNPP_TRY(launch_pool_bwd(a->dout, sv.arg, sv.z[Lm], sv.scale[Lm], sv.shift[Lm], sv.mean[Lm], sv.istd[Lm], g.G, d->K,
-                             d->C[Lm], sc.dm, sc.slab, &nslab, st));
+                             d->C[Lm], sc.dm, sc.slab, &nslab, st, sa_keeps_zmax(d, g) ? sv.zmax : nullptr));
     // sc.cst holds the BatchNorm-backward constants of the layer being processed; layer l-1's are produced (together with
     // layer l's weight-gradient reduction) by the post-GEMM launch that ends iteration l
     // small-M levels materialise dZ once per layer; that pass rides in the launch that finalises the layer's BatchNorm sums
@@ -430,7 +436,8 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             W.ldb = d->C[l - 1];
             W.rows = C;
             int dw_slabs = 0, rc = PNPP_OK;
-            if (try_launch_da_dw(dz, W, g.M, d->C[l - 1], C, E, &nslab_next, a2, g.Cin[l], sc.dwslab, &nsplit, &kp_pad, st, &rc)) {
+            if (try_launch_da_dw(dz, W, g.M, d->C[l - 1], C, E, &nslab_next, a2, g.Cin[l], sc.dwslab, &nsplit, &kp_pad, st, &rc,
+                                 a->d_conv_w[l], g.Cin[l])) {
                 PNPP_TRY(rc);  // small-M level: dA and dW of this layer went out as one launch
                 pair_done = true;
             } else {
