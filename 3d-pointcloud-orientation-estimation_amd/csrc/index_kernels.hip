@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(64) scatter_rows_bwd_kernel(const float *__res
 __global__ void __launch_bounds__(256)
 subsample_points_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_lo, unsigned str_hi,
                         const float *__restrict__ bank, const int32_t *__restrict__ lengths,
-                        const int32_t *__restrict__ cloud_ids, int Lmax, int num, float *__restrict__ out) {
+                        const int32_t *__restrict__ cloud_ids, int Lmax, int num, float *__restrict__ out, int cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long cand[];
     // gridDim.y workgroups share one batch slot: each builds the slot's whole candidate list (cheap: one Philox call per
     // point) and ranks / gathers every gridDim.y-th candidate -- ranks do not depend on the order candidates were compacted in
@@ -525,29 +525,43 @@ subsample_points_kernel(unsigned seed_lo, unsigned seed_hi, unsigned str_lo, uns
     // Compaction without atomics: wave w scans the points [w L/4, (w+1) L/4) and appends its survivors to its own segment
     // of the list, so the list -- positions included -- is the same in every workgroup of the slot: position p of the
     // concatenated segments belongs to part p / 256 % nparts.  Segments are padded to an even length with a word above every key.
+    // The table holds `cap` words per segment whatever the cloud's length (clouds of millions of points draw through the same
+    // few thousand words): a cut that leaves fewer than num keys, or more than a segment holds, is bisected -- the result (the
+    // num smallest (key, index) words) never depends on where the cut ends up.
     __shared__ int cnt_s[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int seg = ((L + 3) / 4 + 3) & ~1;                 // capacity of one segment (even, >= its range + 2)
+    const int seg = cap;                                    // capacity of one segment (even)
     const int lo = wave * ((L + 3) / 4), hi = min(L, lo + (L + 3) / 4);
     unsigned long long *mycand = cand + (size_t)wave * seg;
-    for (;;) {
+    unsigned cut_lo = 0u, cut_hi = 0xffffffffu;             // keys <= cut_lo are too few, keys <= cut_hi may not fit
+    for (int round = 0;; ++round) {
         int cnt = 0;
         for (int n0 = lo; n0 < hi; n0 += 64) {
             const int n = n0 + lane;
             const unsigned k = n < hi ? philox_key((unsigned)n, (unsigned)b, str_lo, str_hi, seed_lo, seed_hi) : 0u;
             const bool keepit = n < hi && k <= cut;
             const unsigned long long vote = __ballot(keepit);
-            if (keepit) mycand[cnt + __popcll(vote & ((1ull << lane) - 1ull))] = ((unsigned long long)k << 32) | (unsigned)n;
+            const int pos = cnt + __popcll(vote & ((1ull << lane) - 1ull));
+            if (keepit && pos < seg - 1) mycand[pos] = ((unsigned long long)k << 32) | (unsigned)n;
             cnt += __popcll(vote);
         }
         if (lane == 0) {
-            if (cnt & 1) mycand[cnt] = ~0ull;
+            if ((cnt & 1) && cnt < seg) mycand[cnt] = ~0ull;
             cnt_s[wave] = cnt;
         }
         __syncthreads();
         const int total = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
-        if (total >= num || cut == 0xffffffffu) break;   // uniform
-        cut = 0xffffffffu;                                // a > 5 sigma event: redo without the cut
+        const bool fits = cnt_s[0] < seg && cnt_s[1] < seg && cnt_s[2] < seg && cnt_s[3] < seg;
+        if ((total >= num && fits) || round >= 40) break;   // uniform (round bound: never reached, 32 bisections settle any cut)
+        if (total < num) {                                  // too few keys under the cut (a > 5 sigma event): raise it
+            cut_lo = cut;
+            if (cut_hi != 0xffffffffu) cut = cut_lo + (cut_hi - cut_lo) / 2u;          // between a too-small and a too-large cut
+            else if (4 * (seg - 2) >= L + 8) cut = 0xffffffffu;                        // the whole cloud fits the table: take it
+            else cut = cut > 0x7fffffffu ? 0xffffffffu : 2u * cut + 1u;                // never overflowed yet: double
+        } else {                                            // a segment overflowed: lower it
+            cut_hi = cut;
+            cut = cut_lo + (cut_hi - cut_lo) / 2u;
+        }
         __syncthreads();
     }
     const int c0 = cnt_s[0], c1 = cnt_s[1], c2n = cnt_s[2], c3 = cnt_s[3], nc = c0 + c1 + c2n + c3;
@@ -733,8 +747,14 @@ extern "C" int pnpp_subsample_points(uint64_t seed, uint64_t stream_id, const fl
                                      const int32_t *cloud_ids, int B, int Lmax, int num, float *out, void *stream) {
     PNPP_REQUIRE(bank && lengths && out, PNPP_ERR_ARG, "subsample_points: null pointer");
     PNPP_REQUIRE(B > 0 && Lmax > 0 && num > 0, PNPP_ERR_ARG, "subsample_points: non-positive size");
-    PNPP_REQUIRE((size_t)(Lmax + 1) * 8 <= 128 * 1024, PNPP_ERR_ARG, "subsample_points: Lmax=%d too large (<= 16383)", Lmax);
-    const size_t lds = (size_t)(Lmax + 32) * sizeof(unsigned long long);   // four segments of (Lmax / 4 rounded up, + padding)
+    // four LDS segments of `cap` words: the whole cloud when it is short, else room for four times the keys the cut is expected
+    // to keep (num + 4 sqrt(num) + 16, spread over the segments) -- independent of the cloud's length
+    const long long want = 4ll * (long long)(num + 4.0 * sqrt((double)num) + 16.0) + 64;
+    long long per_seg = ((long long)Lmax + 3) / 4 + 4;
+    if (per_seg > want / 4 + 64) per_seg = want / 4 + 64;
+    const int cap = (int)((per_seg + 1) & ~1ll);
+    const size_t lds = (size_t)4 * cap * sizeof(unsigned long long);
+    PNPP_REQUIRE(lds <= 128 * 1024, PNPP_ERR_ARG, "subsample_points: num=%d needs %zu bytes of LDS (<= 128 KB)", num, lds);
     static size_t granted = 0;
     if (lds > 48 * 1024 && lds > granted) {
         (void)hipFuncSetAttribute((const void *)subsample_points_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -746,7 +766,7 @@ extern "C" int pnpp_subsample_points(uint64_t seed, uint64_t stream_id, const fl
     ProfScope ps(as_stream(stream), "subsample_points_kernel B=%d Lmax=%d num=%d parts=%d", B, Lmax, num, nparts);
     hipLaunchKernelGGL(subsample_points_kernel, dim3(B, nparts), dim3(256), lds, as_stream(stream), (unsigned)seed,
                        (unsigned)(seed >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32), bank, lengths, cloud_ids, Lmax,
-                       num, out);
+                       num, out, cap);
     PNPP_CHECK_LAUNCH("subsample_points");
     return PNPP_OK;
 }

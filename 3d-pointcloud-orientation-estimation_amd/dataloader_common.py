@@ -123,7 +123,7 @@ class DeviceCloudBank:
     a fresh (B, num_points, 3) float32 device tensor with the same distribution as sample_pts -- without replacement
     when the cloud has enough points, with replacement otherwise.  Draws are a pure function of (seed, draw counter).
     """
-    MAX_POINTS = 16383  # LDS-resident key table of the kernel
+    MAX_POINTS = 1 << 24  # the kernel's key table is sized by num_points, not by the cloud (any length the bank tensor can hold)
 
     def __init__(self, clouds, device, seed: int = 0):
         import torch

@@ -80,7 +80,7 @@ int pnpp_sample_random(uint64_t seed, uint64_t stream_id, int B, int N, int npoi
  * replace=len<num) rows of a cloud -- on the device, for a bank of full clouds resident in HBM: bank (n_clouds,Lmax,3),
  * lengths (n_clouds) valid rows per cloud, cloud_ids (B) bank row of every batch slot (NULL: slot b reads cloud b).
  * out (B,num,3): an ordered uniform subset without replacement where lengths >= num, uniform draws with replacement
- * where 0 < lengths < num, zeros for an empty cloud.  Pure function of (seed, stream_id, slot); Lmax <= 16383. */
+ * where 0 < lengths < num, zeros for an empty cloud.  Pure function of (seed, stream_id, slot); any Lmax (the LDS key table is sized by num, not by the cloud). */
 int pnpp_subsample_points(uint64_t seed, uint64_t stream_id, const float *bank, const int32_t *lengths,
                           const int32_t *cloud_ids, int B, int Lmax, int num, float *out, void *stream);
 /* Same, with the stream id read from DEVICE memory at kernel time: stream_id = stream_id_dev[0] + offset, and the

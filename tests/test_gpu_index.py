@@ -289,3 +289,13 @@ def test_device_samplers_bit_exact_vs_oracle(ops):
         idx = S.subsample_indices(77, 1, slot, lens[cid], num)
         want = clouds[cid][idx] if lens[cid] else np.zeros((num, 3), np.float32)
         assert np.array_equal(out[slot], want), (slot, cid)
+    # clouds far beyond what one workgroup's LDS could hold as a key table (the table is sized by num, not by the cloud), and
+    # draws whose first cut misses: num close to the cloud's length (the cut keeps everything), tiny num (wide relative spread)
+    lens2 = [60_000, 200_003, 1100, 17_000]
+    clouds2 = [rng.standard_normal((n, 3)).astype(np.float32) for n in lens2]
+    bank2 = dc.DeviceCloudBank(clouds2, "cuda", seed=78)
+    for draw, num2 in enumerate((1024, 1024, 8), start=1):
+        out2 = bank2.sample(torch.tensor([0, 1, 2, 3]), num2).cpu().numpy()
+        for slot in range(4):
+            idx = S.subsample_indices(78, draw, slot, lens2[slot], num2)
+            assert np.array_equal(out2[slot], clouds2[slot][idx]), (draw, slot)
