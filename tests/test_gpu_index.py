@@ -244,8 +244,10 @@ def test_subsample_points_on_device(ops):
         assert xyz.is_cuda and xyz.shape[1:] == (256, 3) and t.is_cuda
         seen += t.cpu().tolist()
     assert sorted(seen) == list(range(len(clouds)))
-    with pytest.raises(ValueError):
-        dc.DeviceCloudBank([np.zeros((20000, 3), np.float32)], "cuda")
+    # no length limit any more (the kernel's key table is sized by num, not by the cloud): a 20,000-point cloud draws distinct rows
+    far = dc.DeviceCloudBank([rng.standard_normal((20000, 3)).astype(np.float32)], "cuda", seed=5)
+    rows = far.sample(torch.zeros(1, dtype=torch.int64), 1024).cpu().numpy()[0]
+    assert len({r.tobytes() for r in rows}) == 1024
 
 
 def test_paired_device_draw_equals_two_draws():
