@@ -1829,8 +1829,10 @@ static int launch_gemm_cfg(const AOperand &A, const BOperand &B, int M, int Nout
 // Epilogue::pool_ext is honoured by the interior epilogue of the float32 weights-stationary kernel with one column tile per wave
 // (every dense launch of try_launch_ws); the caller asks before it relies on it
 bool gemm_pools_in_epilogue(const AOperand &A, int M, int Nout, int Kd, int nsample) {
+    if (nsample != 32) return false;
+    if (M < 8192) return mid_tiles_on() && mid_gemm_pools(A, M, Nout, Kd);   // group_all levels of 32-point clouds: the 64 x 64 kernel
     if (matmul_precision() != 0) return false;
-    if (nsample != 32 || M < 8192 || M % 64 != 0 || Nout % 64 != 0) return false;
+    if (M % 64 != 0 || Nout % 64 != 0) return false;
     if (!(A.mode == A_PLAIN || A.mode == A_BNRELU)) return false;
     if (A.lda % 4 != 0 || ((uintptr_t)A.a & 15) != 0) return false;
     return Kd == 64 || Kd == 128 || Kd == 256;
@@ -1847,6 +1849,7 @@ int launch_gemm(const AOperand &A, const BOperand &Bin, int M, int Nout, int Kd,
     {
         int rc = PNPP_OK;
         if (try_launch_ws_bf16(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;   // only in the opt-in bf16-operand mode
+        if (try_launch_wsf(A, B, M, Nout, Kd, E, nslab, st, &rc)) return rc;   // forward products: wave-private strips
         if (try_launch_ws(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;
         if (mid_tiles_on() && try_launch_mid_gemm(A, B, M, Nout, Kd, E, nslab, st, &rc)) return rc;
     }
@@ -2751,8 +2754,14 @@ bn_finalize_fwd_kernel(const double *__restrict__ slab, int nslab, int C, double
                        float *__restrict__ rv, long long *__restrict__ nbt, float momentum, float eps, int training,
                        float *__restrict__ mean, float *__restrict__ istd, float *__restrict__ scale,
                        float *__restrict__ shift, const double *__restrict__ count_dev, const float *__restrict__ pool_ext,
-                       float *__restrict__ pool_out, int G, int32_t *__restrict__ pool_arg) {
+                       float *__restrict__ pool_out, int G, int32_t *__restrict__ pool_arg, float *__restrict__ origin_a,
+                       float *__restrict__ origin_b, int norigin) {
     __shared__ double red[32][2][FIN_COLS];
+    if (blockIdx.x == 0 && blockIdx.y == 0)   // group_all levels: every cloud's centre is the origin (pointnet_pp_8dir.py:24)
+        for (int i = threadIdx.x; i < norigin; i += 256) {
+            if (origin_a) origin_a[i] = 0.f;
+            if (origin_b) origin_b[i] = 0.f;
+        }
     __shared__ float pool_cs[2][FIN_COLS];
     if (count_dev) count = *count_dev;   // SyncBN: the row count of ALL ranks, summed with the statistics
     // pooling in the producer's epilogue (Epilogue::pool_ext): gridDim.y row blocks each redo the slab reduction for their 8
@@ -2981,7 +2990,8 @@ int launch_slab_sum(const double *slab, int nslab, int C, double count, double *
 int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, const float *bias, const float *gamma,
                            const float *beta, float *rm, float *rv, long long *nbt, float momentum, float eps, int training,
                            float *mean, float *istd, float *scale, float *shift, hipStream_t st, const double *count_dev,
-                           const float *pool_ext, float *pool_out, int G, int32_t *pool_arg) {
+                           const float *pool_ext, float *pool_out, int G, int32_t *pool_arg, float *origin_a, float *origin_b,
+                           int norigin) {
     const bool pool = pool_ext && pool_out && G > 0 && training;
     int gy = 1;
     if (pool) {   // enough row blocks to fill the chip, at least 64 rows each
@@ -2992,7 +3002,8 @@ int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, c
     ProfScope ps(st, "bn_finalize_fwd_kernel C=%d%s", C, pool ? " +pool" : "");
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, FIN_COLS), gy), dim3(256), 0, st, slab, nslab, C, count, bias, gamma, beta,
                        rm, rv, nbt, momentum, eps, training, mean, istd, scale, shift, count_dev, pool ? pool_ext : nullptr,
-                       pool ? pool_out : nullptr, G, pool ? pool_arg : nullptr);
+                       pool ? pool_out : nullptr, G, pool ? pool_arg : nullptr, pool ? origin_a : nullptr, pool ? origin_b : nullptr,
+                       pool ? norigin : 0);
     PNPP_CHECK_LAUNCH("bn_finalize_fwd");
     return PNPP_OK;
 }

@@ -30,6 +30,8 @@
 
 namespace pnpp {
 
+static inline bool mid_ptr_ok_ext(const float *p, int ld) { return p && (ld & 3) == 0 && ((uintptr_t)p & 15) == 0; }
+
 constexpr int MID_T = 64;            // tile edge and chunk depth
 constexpr int MID_RP = 68;           // pitch of a row-operand image
 constexpr int MID_IMG = MID_T * MID_RP;          // floats per operand image (column operands use the first 64 * 64)
@@ -180,6 +182,24 @@ __device__ __forceinline__ void mid_gemm_tile(const MidGemm &G, const int tm, co
     }
 
     // epilogue: a lane holds 16 rows of one column; a half-wave store is 32 consecutive floats
+    if constexpr (EM == E_STORE_STATS) {
+        if (E.pool_ext) {   // (uniform) 32-row neighbourhoods: this wave's 32 x 32 tile is one of them -- its extreme row per column
+            const float sg = (E.pool_gamma ? E.pool_gamma[col] : 1.f) >= 0.f ? 1.f : -1.f;   // (see Epilogue::pool_ext, kernels.h)
+            float mx = sg * acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sg * acc[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            int a = 64;
+#pragma unroll
+            for (int r = 15; r >= 0; --r) a = (sg * acc[r] == mx) ? (r & 3) + 8 * (r >> 2) + 4 * lh : a;
+            a = min(a, __shfl_xor(a, 32, 64));
+            if (lh == 0) {
+                const size_t gi = (size_t)((m0 + wm * 32) >> 5) * E.ldc + col;
+                E.pool_ext[gi] = sg * mx;
+                E.pool_arg[gi] = a;
+            }
+        }
+    }
     float *tb = E.c + (size_t)(m0 + wm * 32 + 4 * lh) * E.ldc + col;
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -294,12 +314,27 @@ __device__ __forceinline__ void mid_dw_tile(const MidDw &D, const int tc, const 
     for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * D.ldo] = acc[r];
 }
 
+// XCD-aware tile map (speed only).  Workgroup b runs on XCD b % 8, each with its own L2: a column of tiles per XCD makes every XCD
+// fetch ALL rows of the row operand (4 MB of dZ eight times over).  Dealing the R x C tile grid out as 8 rectangles of (R/4) x (C/2)
+// tiles instead gives an XCD R/4 row blocks and C/2 column blocks of operands: the launch's L2 misses drop from ~8 x to ~3 x the
+// compulsory bytes.  b -> (row tile, column tile); falls back to row-major when the grid does not divide.
+__device__ __forceinline__ void mid_tile_map(int b, int R, int C, int &tr, int &tc) {
+    if ((R & 3) == 0 && (C & 1) == 0) {
+        const int xcd = b & 7, i = b >> 3, bw = C >> 1;   // rectangle (xcd / 2, xcd % 2), i-th tile inside it (R/4 x C/2, row-major)
+        tr = (xcd >> 1) * (R >> 2) + i / bw;
+        tc = (xcd & 1) * bw + i % bw;
+    } else {
+        tr = b / C, tc = b % C;
+    }
+}
+
 // ---- kernels ---------------------------------------------------------------------------------------------------------------
 template <int AX, bool BT, int EM>
 __global__ void __launch_bounds__(256) gemm_mid_kernel(const MidGemm G, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // XCD-aware order: the eight workgroups that share an XCD's L2 (b, b + 8, ...) take neighbouring column tiles of one row block
-    mid_gemm_tile<AX, BT, EM>(G, blockIdx.x / tiles_n, blockIdx.x % tiles_n, lds);
+    int tm, tn;
+    mid_tile_map(blockIdx.x, G.M / MID_T, tiles_n, tm, tn);
+    mid_gemm_tile<AX, BT, EM>(G, tm, tn, lds);
 }
 
 // dA (+ ReLU mask and BatchNorm-backward sums) and dW of one backward layer only share dZ: one launch, the first g1 workgroups
@@ -308,10 +343,15 @@ template <int EM, int A2X>
 __global__ void __launch_bounds__(256) da_dw_mid_kernel(const MidGemm G, int tiles_n, int g1, const MidDw D, int tiles_c, int tiles_k) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if ((int)blockIdx.x < g1) {
-        mid_gemm_tile<A_PLAIN, false, EM>(G, blockIdx.x / tiles_n, blockIdx.x % tiles_n, lds);
+        int tm, tn;
+        mid_tile_map(blockIdx.x, G.M / MID_T, tiles_n, tm, tn);
+        mid_gemm_tile<A_PLAIN, false, EM>(G, tm, tn, lds);
     } else {
         const int b = blockIdx.x - g1, per = tiles_c * tiles_k;
-        mid_dw_tile<A2X>(D, (b % per) / tiles_k, (b % per) % tiles_k, b / per, lds);
+        int tc, tk;
+        if ((g1 & 7) == 0 && (per & 7) == 0) mid_tile_map(b % per, tiles_c, tiles_k, tc, tk);   // (b % per) % 8 is still this block's XCD
+        else tc = (b % per) / tiles_k, tk = (b % per) % tiles_k;
+        mid_dw_tile<A2X>(D, tc, tk, b / per, lds);
     }
 }
 
@@ -326,16 +366,24 @@ static void mid_grant_lds(K kfn) {
     }
 }
 
+static bool mid_gemm_shape_ok(int M, int Nout, int Kd) {
+    if (M < 512 || M > 8192 || M % MID_T || Nout % MID_T || Kd % MID_T) return false;
+    if ((M / MID_T) * (Nout / MID_T) < 192) return false;   // fewer tiles than compute units: many small workgroups win (DESIGN.md 9)
+    return M / MID_T <= kMaxStatBlocks;
+}
+// true when try_launch_mid_gemm takes this forward product of a level's last layer (so its epilogue can take the max-pool)
+bool mid_gemm_pools(const AOperand &A, int M, int Nout, int Kd) {
+    return mid_gemm_shape_ok(M, Nout, Kd) && (A.mode == A_PLAIN || A.mode == A_BNRELU) && mid_ptr_ok_ext(A.a, A.lda);
+}
+
 // forward product of a group_all layer: Z = relu(bn(z_prev)) W^T (+ column statistics).  false: the shape stays on the 32 x 32 kernel.
 bool try_launch_mid_gemm(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st,
                          int *rc) {
     *rc = PNPP_OK;
-    if (M < 512 || M > 8192 || M % MID_T || Nout % MID_T || Kd % MID_T) return false;
-    if ((M / MID_T) * (Nout / MID_T) < 192) return false;   // fewer tiles than compute units: many small workgroups win (DESIGN.md 9)
+    if (!mid_gemm_shape_ok(M, Nout, Kd)) return false;
     if (!(A.mode == A_PLAIN || A.mode == A_BNRELU) || !B.trans || B.perm_D >= 0 || B.rows != Kd) return false;
     if (!(E.mode == E_STORE || E.mode == E_STORE_STATS)) return false;
     if (!mid_ptr_ok(A.a, A.lda) || !mid_ptr_ok(B.b, B.ldb) || !mid_ptr_ok(E.c, E.ldc)) return false;
-    if (M / MID_T > kMaxStatBlocks) return false;
     MidGemm G{A.a, A.lda, A.scale, A.shift, B.b, B.ldb, M, Nout, Kd, E};
     if (nslab) *nslab = M / MID_T;
     const int tn = Nout / MID_T, grid = (M / MID_T) * tn;

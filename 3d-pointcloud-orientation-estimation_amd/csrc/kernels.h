@@ -138,6 +138,9 @@ bool try_launch_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout, in
 // gemm_mid_kernels.hip: 64 x 64 tiles over the whole reduction for the group_all level's wide layers
 bool try_launch_mid_gemm(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st,
                          int *rc);
+bool mid_gemm_pools(const AOperand &A, int M, int Nout, int Kd);
+// gemm_wsf_kernels.hip: forward products of the grouped levels on wave-private row strips (no barrier in the tile loop)
+bool try_launch_wsf(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc);
 bool try_launch_mid_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,
                           int Kp, float *slab, int *nsplit_out, int *kp_pad_out, hipStream_t st, int *rc, float *dw_direct = nullptr,
                           int dw_ld = 0);   // dw_direct (Nc x dw_ld, dw_ld == Kp): written in place when one row range suffices; *nsplit_out = 0 then
@@ -149,7 +152,8 @@ int launch_slab_reduce(const float *slab, int nsplit, int Nc, int kp_pad, int Kv
 int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, const float *bias, const float *gamma,
                            const float *beta, float *rm, float *rv, long long *nbt, float momentum, float eps, int training,
                            float *mean, float *istd, float *scale, float *shift, hipStream_t st, const double *count_dev = nullptr,
-                           const float *pool_ext = nullptr, float *pool_out = nullptr, int G = 0, int32_t *pool_arg = nullptr);
+                           const float *pool_ext = nullptr, float *pool_out = nullptr, int G = 0, int32_t *pool_arg = nullptr,
+                           float *origin_a = nullptr, float *origin_b = nullptr, int norigin = 0);
 // true when launch_gemm will honour Epilogue::pool_ext for this shape (the weights-stationary kernel, 32-row neighbourhoods)
 bool gemm_pools_in_epilogue(const AOperand &A, int M, int Nout, int Kd, int nsample);
 int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, int training, const float *gamma,

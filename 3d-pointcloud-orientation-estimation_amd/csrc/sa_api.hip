@@ -319,7 +319,7 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
             E.slab = sc.slab;
             // last layer of a level with 32-row neighbourhoods: the max over the neighbourhood is taken from the GEMM's accumulators
             // and finished by the statistics launch (sv.zmax holds the extreme pre-BN values; the backward pass reads them too)
-            const bool pool_here = l == d->L - 1 && !d->group_all && pool_fused_on() && gemm_pools_in_epilogue(A, g.M, d->C[l], g.Kd[l], d->K);
+            const bool pool_here = l == d->L - 1 && l > 0 && pool_fused_on() && gemm_pools_in_epilogue(A, g.M, d->C[l], g.Kd[l], d->K);
             if (pool_here) E.pool_ext = sv.zmax, E.pool_arg = sv.arg, E.pool_gamma = a->bn_w[l];
             PNPP_TRY(launch_gemm(A, W, g.M, d->C[l], g.Kd[l], E, &nslab, st));
             StatsView V;
@@ -327,7 +327,9 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
             PNPP_TRY(launch_bn_finalize_fwd(V.slab, V.nslab, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
                                             a->bn_rm[l], a->bn_rv[l], (long long *)a->bn_nbt[l], d->momentum, d->eps, 1, sv.mean[l], sv.istd[l],
                                             sv.scale[l], sv.shift[l], st, V.count_dev, pool_here ? sv.zmax : nullptr,
-                                            pool_here ? a->out : nullptr, g.G, pool_here ? sv.arg : nullptr));
+                                            pool_here ? a->out : nullptr, g.G, pool_here ? sv.arg : nullptr,
+                                            d->group_all ? a->new_xyz : nullptr, d->group_all ? sv.new_xyz : nullptr,
+                                            d->group_all ? g.G * 3 : 0));
             pooled = pool_here;
         } else {
             E.mode = E_STORE;

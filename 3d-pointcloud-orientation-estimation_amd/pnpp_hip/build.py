@@ -28,6 +28,7 @@ SOURCES = {
     "gemm_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_bf16_kernels.hip": [],
     "gemm_mid_kernels.hip": [],
+    "gemm_wsf_kernels.hip": [],
     "loss_kernels.hip": [],
     "sa_api.hip": [],
     "fc_api.hip": [],
