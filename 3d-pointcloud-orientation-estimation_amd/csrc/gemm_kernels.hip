@@ -539,6 +539,9 @@ __device__ int g_stamp_kd;
 #endif
 // timing experiments only (results are WRONG with either on; never in a shipped build): what is left of a launch without its
 // matrix instructions, or without its output stores
+#ifndef PNPP_WS_TUNED128        // pooled K = 128 backward launch on the clamp-free staging pass + dW address table
+#define PNPP_WS_TUNED128 1
+#endif
 #ifndef PNPP_WS_DEFER_STORES     // forward kernels: a tile's stores are issued behind the NEXT tile's staging pass
 #define PNPP_WS_DEFER_STORES 1
 #endif
@@ -635,7 +638,7 @@ gemm_ws_kernel(const AOperand A, const BOperand B, int M, int Nout, int ncol, co
     // (round 3 A/B, two traces per variant on one box: for K <= 128 the clamp-free pass alone is +1.4 / +2.2 us on the pooled K = 128
     // and the K = 64 backward launch; together with the dW address table it is -2.4 us on the pooled K = 128 launch and 0 / +0.3
     // on the others -- so that one instantiation takes both)
-    constexpr bool TUNED_128 = KD == 128 && AMODE == A_DZ_POOL && FDW;
+    constexpr bool TUNED_128 = PNPP_WS_TUNED128 && KD == 128 && AMODE == A_DZ_POOL && FDW;
     constexpr bool DENSE_A = (AMODE == A_PLAIN || AMODE == A_BNRELU || AMODE == A_DZ || AMODE == A_DZ_POOL) &&
                              (KD >= PNPP_WS_DENSE_MINK || TUNED_128);
     const bool full_rows = DENSE_A && (M % BM) == 0 && (AMODE != A_DZ_POOL || A.K == 32);
