@@ -141,6 +141,9 @@ bool try_launch_mid_gemm(const AOperand &A, const BOperand &B, int M, int Nout, 
 bool mid_gemm_pools(const AOperand &A, int M, int Nout, int Kd);
 // gemm_wsf_kernels.hip: forward products of the grouped levels on wave-private row strips (no barrier in the tile loop)
 bool try_launch_wsf(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc);
+// gemm_wsp_kernels.hip: the fused backward product (dA + mask + sums + dW) of a grouped layer with a 64-channel input, wave-private strips
+bool try_launch_wsp(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc,
+                    int *dw_slabs);
 bool try_launch_mid_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,
                           int Kp, float *slab, int *nsplit_out, int *kp_pad_out, hipStream_t st, int *rc, float *dw_direct = nullptr,
                           int dw_ld = 0);   // dw_direct (Nc x dw_ld, dw_ld == Kp): written in place when one row range suffices; *nsplit_out = 0 then

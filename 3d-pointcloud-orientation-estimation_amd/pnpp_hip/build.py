@@ -29,6 +29,7 @@ SOURCES = {
     "gemm_bf16_kernels.hip": [],
     "gemm_mid_kernels.hip": [],
     "gemm_wsf_kernels.hip": [],
+    "gemm_wsp_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "loss_kernels.hip": [],
     "sa_api.hip": [],
     "fc_api.hip": [],

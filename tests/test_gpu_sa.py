@@ -188,6 +188,43 @@ def test_sa_config2_shapes(oracle):
     assert worst < 1e-1, worst                # per-tensor, relative to its max: small tensors carry the fp32 noise
 
 
+def test_sa1_shape_backward_in_eval_mode(oracle):
+    """Backward through the SA1 shape with BatchNorm in eval mode: the BatchNorm-backward transform degenerates to dZ = g dY (its
+    z-coefficient is exactly zero), which the fused backward kernel of the last layer cannot fold into its weight panel -- the
+    launch takes its other form (gemm_wsp_kernels.hip).  Against the float64 oracle with the kernels' max-pool routing."""
+    from models.pointnet_pp_8dir import PointNetSetAbstraction
+    torch.manual_seed(7)
+    sa = PointNetSetAbstraction(128, 32, 0, [64, 64, 128]).cuda()
+    with torch.no_grad():
+        for bn in sa.bns:
+            bn.running_mean.uniform_(-0.2, 0.2)
+            bn.running_var.uniform_(0.5, 1.5)
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.2, 0.2)
+    sa.eval()
+    xyz, _, _, _ = oracle.synthetic_clouds(4, 1024, seed=9)
+    torch.manual_seed(3)
+    c1, _ = oracle.replay_centres(4)
+    _, y = sa(xyz.cuda(), None, c1.cuda())
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(4))
+    y.backward(gy.cuda())
+    P = {}
+    for k, v in sa.state_dict().items():
+        if v.is_floating_point():
+            t = v.detach().cpu().double()
+            P[f"sa.{k}"] = t.requires_grad_(True) if "running" not in k else t
+    _, y_ref, _ = oracle.sa_forward(xyz, None, P, "sa", c1, 32, False, training=False)
+    (y_ref * gy.double()).sum().backward()
+    assert _rel(y.detach().cpu(), y_ref.detach()) < 3e-5
+    num = den = 0.0
+    for k, p in sa.named_parameters():
+        ref = P[f"sa.{k}"].grad.reshape(p.shape)
+        assert _rel(p.grad.cpu(), ref) < 2e-3, k     # (a max-pool tie routed the other way moves single entries)
+        num += float((p.grad.cpu().double() - ref).pow(2).sum())
+        den += float(ref.pow(2).sum())
+    assert np.sqrt(num / den) < 1e-3
+
+
 @pytest.mark.parametrize("c0,npoint,nsample,n", [(256, 96, 64, 256), (512, 40, 16, 128), (64, 160, 32, 512)])
 def test_sa_layer0_convolved_before_the_gather(oracle, c0, npoint, nsample, n):
     """Grouped levels with input features run layer 0 on the source points and gather afterwards (P[idx] + W_xyz (x - c),
