@@ -1,0 +1,599 @@
+// gemm_wsx_kernels.hip -- backward through layer 1 of a grouped level whose layer 0 convolves RELATIVE COORDINATES only (SA1 of every
+// reference model: in_channel = 3), with layer 0's whole backward folded in.  Wave-private row strips, as gemm_wsp_kernels.hip.
+//
+// Reference: the autograd backward of conv -> BatchNorm -> ReLU twice (models/pointnet_pp_8dir.py:32-41, layers 0 and 1 of sa1) on the
+// grouped relative coordinates `grouped_xyz - new_xyz` (pointnet_pp_8dir.py:31-32):
+//   dZ_1 = BatchNorm-backward(dY_1, Z_1)                                   (operand transform)
+//   dY_0 = (dZ_1 W_1) masked by ReLU'(layer 0)                             (first product + epilogue)
+//   dW_1 = dZ_1^T relu(bn(Z_0))                                            (second product)
+//   dZ_0 = BatchNorm-backward(dY_0, Z_0),  dW_0 = dZ_0^T rel,  dgamma_0, dbeta_0
+//
+// What is different from the generic path (gemm_ws_kernel<..., dW> + post_gemm + dw_xyz + slab_reduce): Z_0 = rel W_0^T is a function
+// of three numbers per row, so nothing of layer 0 has to travel through HBM in the backward pass.
+//   * Z_0's tile of a strip (32 rows x 64 channels) is two MFMA steps per column tile on the operand [x y z 1] x [s w_x, s w_y, s w_z, t]
+//     (s, t: layer 0's BatchNorm scale / shift), and it comes out in ACCUMULATOR layout -- exactly where the ReLU mask of dY_0 and the
+//     activation operand of dW_1 are needed.  Z_0 is never read.
+//   * dY_0 is never written: layer 0's backward only needs per-channel SUMS of it,
+//       c1[c] = sum v,   S[c][j] = sum v rel_j          (v = masked dY_0; three FMAs per element, rel from a wave-private LDS image)
+//     because Z_0 is linear in rel:  sum v Z_0 = W_0[c] . S[c],  sum xhat_0 rel_j = istd (W_0[c] . R2[:, j] - mu R1[j])  with the
+//     moments R1 = sum rel, R2 = sum rel rel^T of the relative coordinates (nine numbers, collected here too).  xyz0_post_kernel turns
+//     those sums into dW_0, dgamma_0, dbeta_0 in float64 and reduces dW_1's partials in the same launch.
+// Four launches (fused GEMM, post_gemm, dw_xyz, slab_reduce: 61 us at 131,072 rows) become two.
+#include <stdlib.h>
+
+#include "kernels.h"
+
+namespace pnpp {
+
+constexpr int kWsxSlab = 272;   // doubles per worker: c1[64], Sx[64], Sy[64], Sz[64], R1[3], R2[6] (xx xy xz yy yz zz), padding
+
+struct WsxArgs {
+    const float *dy, *z, *cst;   // dY_1, Z_1 (M x KD); [5][KD] = g, mu, istd, c1, c2 of layer 1
+    const float *W;              // W_1: KD x 64 row-major
+    int ldw, M;
+    const float *xyz, *centres;  // (B, N, 3), (G, 3)
+    const int32_t *idx;          // (M): neighbour of row r inside its cloud
+    int N, S;                    // points / centres per cloud (32 neighbours per centre: a strip is a neighbourhood)
+    const float *W0;             // W_0: 64 x 3, pitch ldw0
+    int ldw0;
+    const float *scale0, *shift0;
+    float *dwslab;               // [workers][KD][64]
+    double *xslab;               // [workers][kWsxSlab]
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wsx_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), (short)0, 0xfffffffe, 0x00020000);
+}
+__device__ __forceinline__ f32x4 wsx_load4(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned s_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)s_off, 0));
+}
+__device__ __forceinline__ float wsx_load1(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned s_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)s_off, 0));
+}
+
+#ifndef WSX_EXP   // timing experiments (wrong results): 2 no dW loop, 4 no dA loop, 8 no epilogue arithmetic
+#define WSX_EXP 0
+#endif
+
+// KD = C_1 (64); C_0 = 64.  One workgroup per CU or two (launch bounds 256 x WPC); a wave owns strips of 32 rows end to end.
+template <int KD, int WPC>
+__global__ void __launch_bounds__(256, WPC)
+gemm_wsx_kernel(const WsxArgs P) {
+    constexpr int BN = 64, NC = KD / 64, DP = KD + 4, CT = KD / 32;
+    constexpr int MAIN = BN * KD + 4 * 32 * DP, RED = CT * 2 * 4 * 4 * 64 * 4;
+    constexpr int TAB = MAIN > RED ? MAIN : RED;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Ws = lds;                                       // [BN][KD]: (diag(g) W_1)^T image, 16-byte groups swizzled by (n & 15)
+    float *Tsc = lds + TAB, *Tb = Tsc + KD, *Tbw = Tb + KD, *Tred = Tbw + BN;   // g[KD], b[KD], (b W)[64], scratch [4][64] floats / doubles
+    float *RlAll = Tred + 512;                             // [4 waves][32][4]: relative coordinates of the wave's strip
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *Dz = lds + BN * KD + wave * (32 * DP);          // this wave's dZ_1 strip image [32][DP]
+    float *Rl = RlAll + wave * 128;
+    const int l31 = lane & 31, lh = lane >> 5;
+    auto swz = [](int r) { return (r & 15) << 2; };
+    const int worker = blockIdx.x, nworkers = gridDim.x;
+
+    const int q4 = 4 * (lane & 15), rb = lane >> 4;        // staging map of a strip: column group lane % 16, rows lane / 16 + 4 i
+    const int nstrips = P.M / 32, stride = nworkers * 4;
+    int strip = worker * 4 + wave;
+    const __amdgpu_buffer_rsrc_t resZ = wsx_rsrc(P.z), resY = wsx_rsrc(P.dy), resI = wsx_rsrc(P.idx), resX = wsx_rsrc(P.xyz),
+                                 resC = wsx_rsrc(P.centres);
+    const __amdgpu_buffer_rsrc_t resNull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.z), (short)0, 0, 0x00020000);
+    unsigned oa[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) oa[i] = 4u * ((unsigned)(rb + 4 * i) * (unsigned)KD + (unsigned)q4);
+
+    // operand streams: registers, one strip ahead
+    f32x4 rz[NC][8], ry[NC][8];
+    auto fetch_z = [&](__amdgpu_buffer_rsrc_t rZ, __amdgpu_buffer_rsrc_t rY, int s, int c, int i) {
+        const unsigned so = (unsigned)s * (32u * KD * 4u);
+        rz[c][i] = wsx_load4(rZ, oa[i] + 256u * (unsigned)c, so);
+        ry[c][i] = wsx_load4(rY, oa[i] + 256u * (unsigned)c, so);
+    };
+    // geometry of a strip = one neighbourhood: row l31's neighbour index, then its coordinates and the centre's
+    int nidx;
+    float px, py, pz, cx, cy, cz;
+    auto fetch_idx = [&](__amdgpu_buffer_rsrc_t rI, int s) { nidx = __builtin_bit_cast(int, wsx_load1(rI, 4u * (unsigned)l31, (unsigned)s * 128u)); };
+    auto fetch_geo = [&](__amdgpu_buffer_rsrc_t rX, __amdgpu_buffer_rsrc_t rCn, int s) {
+        const unsigned cloud = (unsigned)(s / P.S) * (unsigned)P.N * 12u, po = 12u * (unsigned)nidx;
+        px = wsx_load1(rX, po, cloud), py = wsx_load1(rX, po + 4u, cloud), pz = wsx_load1(rX, po + 8u, cloud);
+        const unsigned co = (unsigned)s * 12u;
+        cx = wsx_load1(rCn, 0u, co), cy = wsx_load1(rCn, 4u, co), cz = wsx_load1(rCn, 8u, co);
+    };
+    // ---- everything the prologue reads is requested before its first wait: first strip, constants, weight panel ----
+    const bool have = strip < nstrips;
+    {
+        const __amdgpu_buffer_rsrc_t z0 = have ? resZ : resNull, y0 = have ? resY : resNull, i0 = have ? resI : resNull;
+        fetch_idx(i0, strip);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fetch_z(z0, y0, strip, c, i);
+    }
+    float ch_g = 0.f, ch_b = 0.f;
+    if (tid < KD) {
+        const float g = P.cst[tid], mu = P.cst[KD + tid], is = P.cst[2 * KD + tid], c1 = P.cst[3 * KD + tid], c2 = P.cst[4 * KD + tid];
+        const float k = -is * c2;
+        ch_g = g, ch_b = -g * c1 - g * k * mu;   // dZ = g (dY + k Z) + b
+    }
+    float4 kq[NC];   // staging multipliers k = -istd c2 of this lane's column group
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float *p = P.cst + 64 * c + q4;
+        const float4 is = *reinterpret_cast<const float4 *>(p + 2 * KD), c2 = *reinterpret_cast<const float4 *>(p + 4 * KD);
+        kq[c] = make_float4(-is.x * c2.x, -is.y * c2.y, -is.z * c2.z, -is.w * c2.w);
+    }
+    // layer 0 of this lane's two output columns: B operands of the Z_0 product, k = (x, y | z, 1) split over the lane halves
+    float zb0[2], zb1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = j * 32 + l31;
+        const float sc = P.scale0[col], sh = P.shift0[col];
+        const float wx = P.W0[col * P.ldw0], wy = P.W0[col * P.ldw0 + 1], wz = P.W0[col * P.ldw0 + 2];
+        zb0[j] = lh ? sc * wy : sc * wx;
+        zb1[j] = lh ? sh : sc * wz;
+    }
+    constexpr int NWF = (KD / 4) * BN / 256;
+    f32x4 tw[NWF];
+#pragma unroll
+    for (int j = 0; j < NWF; ++j) {
+        const int f = tid + 256 * j, nl = f % BN, k4 = 4 * (f / BN);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tw[j][e] = P.W[(size_t)(k4 + e) * P.ldw + nl];
+    }
+    if (tid < KD) Tsc[tid] = ch_g, Tb[tid] = ch_b;
+    __syncthreads();   // tables
+    {   // weight panel image [n][k ^ swz(n)] of diag(g) W (lane = column n), and this thread's share of b W
+        float bwp = 0.f;
+#pragma unroll
+        for (int j = 0; j < NWF; ++j) {
+            const int f = tid + 256 * j, nl = f % BN, k4 = 4 * (f / BN);
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(Tsc + k4), bb = *reinterpret_cast<const f32x4 *>(Tb + k4);
+            bwp = fmaf(bb[0], tw[j][0], fmaf(bb[1], tw[j][1], fmaf(bb[2], tw[j][2], fmaf(bb[3], tw[j][3], bwp))));
+            f32x4 t;
+            t[0] = sc[0] * tw[j][0], t[1] = sc[1] * tw[j][1], t[2] = sc[2] * tw[j][2], t[3] = sc[3] * tw[j][3];
+            *reinterpret_cast<f32x4 *>(Ws + nl * KD + (k4 ^ swz(nl))) = t;
+        }
+        Tred[wave * BN + lane] = bwp;   // nl == lane for every group of this thread
+    }
+    fetch_geo(have ? resX : resNull, have ? resC : resNull, have ? strip : 0);   // the first strip's indices have long arrived
+    __syncthreads();
+    if (tid < BN) Tbw[tid] = (Tred[tid] + Tred[BN + tid]) + (Tred[2 * BN + tid] + Tred[3 * BN + tid]);
+
+    f32x16 dw[CT][2];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dw[i][j][r] = 0.f;
+    double s1[2] = {0.0, 0.0}, sX[2] = {0.0, 0.0}, sY[2] = {0.0, 0.0}, sZ[2] = {0.0, 0.0}, sa[2] = {0.0, 0.0};
+    double mom[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    __syncthreads();   // the panel and (b W) are complete; from here on the waves run on their own
+    const float bw0 = Tbw[l31], bw1 = Tbw[32 + l31];
+
+    auto stage_z = [&](int c, int i) {   // one 16-byte group of the strip image: rows rb + 4 i of chunk c, dY + k Z
+        f32x4 v = rz[c][i];
+        const f32x4 dy = ry[c][i];
+        v[0] = fmaf(kq[c].x, v[0], dy[0]), v[1] = fmaf(kq[c].y, v[1], dy[1]);
+        v[2] = fmaf(kq[c].z, v[2], dy[2]), v[3] = fmaf(kq[c].w, v[3], dy[3]);
+        *reinterpret_cast<f32x4 *>(Dz + (rb + 4 * i) * DP + 64 * c + q4) = v;
+    };
+    const float *arow = Dz + l31 * DP + 4 * lh;
+    const float *brow[2];
+    int gb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = j * 32 + l31;
+        brow[j] = Ws + n * KD;
+        gb[j] = (4 * lh) ^ swz(n);
+    }
+    const float *dcol = Dz + 4 * lh * DP + l31;   // reduction rows of dW in accumulator order: row 4 lh + (s & 3) + 8 (s >> 2) at step s
+    const float *rrow = Rl + 16 * lh;             // the same rows of the coordinate image
+
+    for (; strip < nstrips; strip += stride) {
+        const bool more = strip + stride < nstrips;
+        const int snext = more ? strip + stride : 0;
+        const __amdgpu_buffer_rsrc_t nZ = more ? resZ : resNull, nY = more ? resY : resNull, nI = more ? resI : resNull,
+                                     nX = more ? resX : resNull, nC = more ? resC : resNull;
+        // ---- this strip's relative coordinates (the reference's float32 subtraction): LDS image, Z_0 operand, moments ----
+        const float rx = __fsub_rn(px, cx), ry_ = __fsub_rn(py, cy), rz_ = __fsub_rn(pz, cz);
+        {
+            f32x4 t;
+            t[0] = rx, t[1] = ry_, t[2] = rz_, t[3] = 0.f;
+            *reinterpret_cast<f32x4 *>(Rl + 4 * l31) = t;   // both lane halves hold row l31: the same bytes twice
+        }
+        const float za0 = lh ? ry_ : rx, za1 = lh ? 1.f : rz_;
+        mom[0] += (double)rx, mom[1] += (double)ry_, mom[2] += (double)rz_;
+        mom[3] += (double)(rx * rx), mom[4] += (double)(rx * ry_), mom[5] += (double)(rx * rz_);
+        mom[6] += (double)(ry_ * ry_), mom[7] += (double)(ry_ * rz_), mom[8] += (double)(rz_ * rz_);
+        fetch_idx(nI, snext);
+        // ---- the strip image (KD = 64: one chunk) ----
+#pragma unroll
+        for (int i = 0; i < 8; ++i) stage_z(0, i);
+        // ---- scale Z_0 + shift of the strip in accumulator layout: [x y | z 1] x [s w_x, s w_y | s w_z, t] ----
+        f32x16 zt[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zt[j][r] = 0.f;
+            zt[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(za0, zb0[j], zt[j], 0, 0, 0);
+            zt[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(za1, zb1[j], zt[j], 0, 0, 0);
+        }
+        // ---- dA = X W', two column tiles, k = 8 t + 4 lh + u; the accumulators start from b W ----
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = bw0, acc[1][r] = bw1;
+        if (!(WSX_EXP & 4)) {
+            float4 fa[2], fb[2][2];
+            auto ld = [&](int buf, int t) {
+                fa[buf] = *reinterpret_cast<const float4 *>(arow + 8 * t);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    fb[buf][j] = *reinterpret_cast<const float4 *>(brow[j] + ((8 * t) & ~63) + (((8 * t) & 63) ^ gb[j]));
+            };
+            auto mm = [&](int buf) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].x, fb[buf][j].x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].y, fb[buf][j].y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].z, fb[buf][j].z, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].w, fb[buf][j].w, acc[j], 0, 0, 0);
+                }
+            };
+            constexpr int NTT = KD / 8;
+            ld(0, 0);
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) {
+                if (NC == 2 && t < 4) stage_z(NC - 1, 2 * t), stage_z(NC - 1, 2 * t + 1);
+                // the dense streams of the next strip, one 16-byte group pair per step: its registers were staged above
+                if (NC == 2) {
+                    if (t < 8) fetch_z(nZ, nY, snext, 0, t);
+                    else fetch_z(nZ, nY, snext, 1, t - 8);
+                } else {
+                    fetch_z(nZ, nY, snext, 0, t);
+                }
+                if (t + 1 < NTT) ld((t + 1) & 1, t + 1);
+                mm(t & 1);
+            }
+        }
+        // the next strip's coordinates: its indices were requested a whole dA product ago
+        fetch_geo(nX, nC, snext);
+        // ---- dW_1 += X^T a_0 with the epilogue of the dA product: the activation of step s IS the value whose sign masks accumulator s.
+        // Mask; sums of v, v rel, a_0 ----
+        {
+            float t1[2] = {0.f, 0.f}, tx[2] = {0.f, 0.f}, ty[2] = {0.f, 0.f}, tz[2] = {0.f, 0.f}, ta[2] = {0.f, 0.f};
+            float fd[2][CT];
+            float4 rr[2];
+            auto ldw = [&](int buf, int s) {
+                const int ro = (s & 3) + 8 * (s >> 2);
+#pragma unroll
+                for (int i = 0; i < CT; ++i) fd[buf][i] = dcol[ro * DP + 32 * i];
+                rr[buf] = *reinterpret_cast<const float4 *>(rrow + 4 * ro);
+            };
+            ldw(0, 0);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                float bact[2];
+                const float4 q = rr[s & 1];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float a0 = zt[j][s];
+                    bact[j] = fmaxf(a0, 0.f);
+                    if (!(WSX_EXP & 8)) {
+                        const float v = a0 > 0.f ? acc[j][s] : 0.f;
+                        t1[j] += v;
+                        tx[j] = fmaf(v, q.x, tx[j]), ty[j] = fmaf(v, q.y, ty[j]), tz[j] = fmaf(v, q.z, tz[j]);
+                        ta[j] += bact[j];
+                    }
+                }
+                if (s + 1 < 16) ldw((s + 1) & 1, s + 1);
+                if (!(WSX_EXP & 2)) {
+#pragma unroll
+                    for (int i = 0; i < CT; ++i) {
+                        dw[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[s & 1][i], bact[0], dw[i][0], 0, 0, 0);
+                        dw[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[s & 1][i], bact[1], dw[i][1], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                s1[j] += (double)t1[j], sX[j] += (double)tx[j], sY[j] += (double)ty[j], sZ[j] += (double)tz[j];
+                sa[j] += (double)ta[j];
+            }
+        }
+    }
+
+    // ---- one dW_1 partial per workgroup: every wave parks its tiles of X^T A in LDS, one barrier, then wave w adds the four copies of
+    // tiles w, w + 4, ... in wave order, applies dW = g (X^T A) + b (1^T A) and stores them ----
+    __syncthreads();   // every wave is done with the panel and its strips
+    {
+        constexpr int NTILE = CT * 2;
+        f32x4 *red = reinterpret_cast<f32x4 *>(lds);   // [tile][wave][r4][lane]
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 v;
+                    v[0] = dw[i][j][4 * r4], v[1] = dw[i][j][4 * r4 + 1], v[2] = dw[i][j][4 * r4 + 2], v[3] = dw[i][j][4 * r4 + 3];
+                    red[(((i * 2 + j) * 4 + wave) * 4 + r4) * 64 + lane] = v;
+                }
+        double *ared = reinterpret_cast<double *>(Tred);   // [4 waves][64] doubles
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double a = sa[j] + shfl_xor_f64(sa[j], 32);
+            if (lh == 0) ared[wave * BN + j * 32 + l31] = a;
+        }
+        __syncthreads();
+        float asum[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = j * 32 + l31;
+            asum[j] = (float)((ared[k] + ared[BN + k]) + (ared[2 * BN + k] + ared[3 * BN + k]));
+        }
+        float *wb = P.dwslab + (size_t)worker * KD * 64;
+#pragma unroll
+        for (int tt = 0; tt < (NTILE + 3) / 4; ++tt) {
+            const int t = wave + 4 * tt, i = t >> 1, j = t & 1;
+            if (t < NTILE) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 a0 = red[((t * 4 + 0) * 4 + r4) * 64 + lane], a1 = red[((t * 4 + 1) * 4 + r4) * 64 + lane];
+                    const f32x4 a2 = red[((t * 4 + 2) * 4 + r4) * 64 + lane], a3 = red[((t * 4 + 3) * 4 + r4) * 64 + lane];
+                    const int c0 = i * 32 + 8 * r4 + 4 * lh;
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(Tsc + c0), bb = *reinterpret_cast<const f32x4 *>(Tb + c0);
+                    float *o = wb + (size_t)c0 * 64 + j * 32 + l31;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e * 64] = fmaf(sc[e], (a0[e] + a1[e]) + (a2[e] + a3[e]), bb[e] * (j == 0 ? asum[0] : asum[1]));
+                }
+            }
+        }
+    }
+    // ---- the worker's sums for layer 0: lane halves, then the four waves in wave order; the coordinate moments over the 32 row lanes ----
+    __syncthreads();
+    double *dred = reinterpret_cast<double *>(lds);   // [4 waves][4][64]
+    double *mred = dred + 4 * 4 * BN;                 // [4 waves][9]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double v0 = s1[j] + shfl_xor_f64(s1[j], 32), v1 = sX[j] + shfl_xor_f64(sX[j], 32);
+        const double v2 = sY[j] + shfl_xor_f64(sY[j], 32), v3 = sZ[j] + shfl_xor_f64(sZ[j], 32);
+        if (lh == 0) {
+            const int k = j * 32 + l31;
+            dred[(wave * 4 + 0) * BN + k] = v0, dred[(wave * 4 + 1) * BN + k] = v1;
+            dred[(wave * 4 + 2) * BN + k] = v2, dred[(wave * 4 + 3) * BN + k] = v3;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        double v = mom[i];
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) v += shfl_xor_f64(v, o);   // within a lane half: rows 0 .. 31 once
+        if (lane == 0) mred[wave * 9 + i] = v;
+    }
+    __syncthreads();
+    double *xs = P.xslab + (size_t)worker * kWsxSlab;
+    {
+        const int q = tid >> 6, cl = tid & 63;
+        xs[q * BN + cl] = (dred[(0 * 4 + q) * BN + cl] + dred[(1 * 4 + q) * BN + cl]) + (dred[(2 * 4 + q) * BN + cl] + dred[(3 * 4 + q) * BN + cl]);
+    }
+    if (tid < 9) xs[4 * BN + tid] = (mred[tid] + mred[9 + tid]) + (mred[18 + tid] + mred[27 + tid]);
+}
+
+// ---- the launch behind it: dW_1 = sum of the workers' partials; layer 0's parameter gradients from the workers' sums ----
+struct Xyz0PostArgs {
+    const float *dwslab;   // [nslab][KD][64]
+    int nslab, KD;
+    float *dw1;            // (KD x ld1)
+    int ld1;
+    const double *xslab;   // [nslab][kWsxSlab]
+    const float *W0;
+    int ldw0;
+    const float *gamma0, *mean0, *istd0;
+    double count;
+    int training;
+    float *dW0;
+    int ld0;
+    float *dgamma0, *dbeta0, *dbias0;
+};
+
+__global__ void __launch_bounds__(256) xyz0_post_kernel(const Xyz0PostArgs P, int nfin) {
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < nfin) {
+        // eight channels per block x 32 slab lanes; the nine moments on 16 slab lanes (lane = tid & 15, nine of sixteen used).  Sums go
+        // lanes -> wave (shuffles, fixed order) -> the four waves through LDS
+        __shared__ double red[4][4][8];
+        __shared__ double redm[4][16];
+        const int cl = tid & 7, g = tid >> 3, c = blockIdx.x * 8 + cl, wv = tid >> 6;
+        float w[3] = {0.f, 0.f, 0.f}, gam = 1.f, mu = 0.f, is = 0.f;
+        if (tid < 8) {   // parameters first, reduction second (bn_finalize_fwd_kernel)
+            w[0] = P.W0[c * P.ldw0], w[1] = P.W0[c * P.ldw0 + 1], w[2] = P.W0[c * P.ldw0 + 2];
+            if (P.gamma0) gam = P.gamma0[c];
+            mu = P.mean0[c], is = P.istd0[c];
+        }
+        // every load of a thread is in flight before its first use: a launch this short is the sum of its dependent round trips, and
+        // each slab line is a cold miss (written by a workgroup on another XCD)
+        double a[4] = {0.0, 0.0, 0.0, 0.0}, m = 0.0;
+        const int mq = tid & 15, ml = tid >> 4, mqc = mq < 9 ? mq : 8;
+        for (int base = 0; base < P.nslab; base += 256) {
+            double v[8][4], u[16];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int s = base + g + 32 * it;
+                const double *x = P.xslab + (size_t)(s < P.nslab ? s : 0) * kWsxSlab + c;
+                v[it][0] = x[0], v[it][1] = x[64], v[it][2] = x[128], v[it][3] = x[192];
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int s = base + ml + 16 * it;
+                u[it] = P.xslab[(size_t)(s < P.nslab ? s : 0) * kWsxSlab + 256 + mqc];
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const double ok = base + g + 32 * it < P.nslab ? 1.0 : 0.0;
+                a[0] += ok * v[it][0], a[1] += ok * v[it][1], a[2] += ok * v[it][2], a[3] += ok * v[it][3];
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) m += base + ml + 16 * it < P.nslab ? u[it] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // lanes cl + 8 j of a wave hold the same channel
+            double t = a[q];
+            t += shfl_xor_f64(t, 8), t += shfl_xor_f64(t, 16), t += shfl_xor_f64(t, 32);
+            if ((tid & 63) < 8) red[wv][q][cl] = t;
+        }
+        m += shfl_xor_f64(m, 16), m += shfl_xor_f64(m, 32);
+        if ((tid & 63) < 16) redm[wv][mq] = m;
+        __syncthreads();
+        if (tid >= 8) return;
+        double c1, S[3], R[9];
+        c1 = (red[0][0][cl] + red[1][0][cl]) + (red[2][0][cl] + red[3][0][cl]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) S[j] = (red[0][j + 1][cl] + red[1][j + 1][cl]) + (red[2][j + 1][cl] + red[3][j + 1][cl]);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) R[q] = (redm[0][q] + redm[1][q]) + (redm[2][q] + redm[3][q]);
+        const double wd[3] = {(double)w[0], (double)w[1], (double)w[2]}, mud = (double)mu, isd = (double)is, gd = (double)gam;
+        const double vz = wd[0] * S[0] + wd[1] * S[1] + wd[2] * S[2];   // sum v Z_0 (bias-free Z_0 = W_0 rel)
+        const double c2 = isd * (vz - mud * c1);                       // sum v xhat_0
+        if (P.dgamma0) P.dgamma0[c] = (float)c2;
+        if (P.dbeta0) P.dbeta0[c] = (float)c1;
+        // R2 as a symmetric matrix: xx xy xz yy yz zz
+        const double R2[3][3] = {{R[3], R[4], R[5]}, {R[4], R[6], R[7]}, {R[5], R[7], R[8]}};
+        const double gi = gd * isd, inv = 1.0 / P.count;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double v;
+            if (P.training) {   // dZ_0 = g istd (v - c1 / M - xhat c2 / M)
+                const double xr = isd * (wd[0] * R2[0][j] + wd[1] * R2[1][j] + wd[2] * R2[2][j] - mud * R[j]);   // sum xhat_0 rel_j
+                v = gi * (S[j] - (c1 * inv) * R[j] - (c2 * inv) * xr);
+            } else {
+                v = gi * S[j];
+            }
+            P.dW0[c * P.ld0 + j] = (float)v;
+        }
+        // a bias in front of a train-mode BatchNorm has exactly zero gradient; with running statistics d(bias) = g istd sum v
+        if (P.dbias0) P.dbias0[c] = P.training ? 0.f : (float)(gi * c1);
+        return;
+    }
+    // dW_1: 16 groups of four consecutive columns x 16 slab lanes per block
+    __shared__ float4 red4[16][16];
+    const int e = tid & 15, sl = tid >> 4;
+    const int grp = ((int)blockIdx.x - nfin) * 16 + e, ngrp = P.KD * 16;   // 64 columns = 16 groups per row
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int row = grp >> 4, k = 4 * (grp & 15);
+    if (grp < ngrp) {
+        const float *p = P.dwslab + (size_t)row * 64 + k;
+        const size_t st = (size_t)P.KD * 64;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        for (int base = 0; base < P.nslab; base += 256) {
+            float4 u[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int s = base + sl + 16 * it;
+                u[it] = *reinterpret_cast<const float4 *>(p + (size_t)(s < P.nslab ? s : 0) * st);
+            }
+#pragma unroll
+            for (int it = 0; it < 16; it += 2) {
+                const float k0 = base + sl + 16 * it < P.nslab ? 1.f : 0.f, k1 = base + sl + 16 * (it + 1) < P.nslab ? 1.f : 0.f;
+                a0.x = fmaf(k0, u[it].x, a0.x), a0.y = fmaf(k0, u[it].y, a0.y), a0.z = fmaf(k0, u[it].z, a0.z), a0.w = fmaf(k0, u[it].w, a0.w);
+                a1.x = fmaf(k1, u[it + 1].x, a1.x), a1.y = fmaf(k1, u[it + 1].y, a1.y), a1.z = fmaf(k1, u[it + 1].z, a1.z), a1.w = fmaf(k1, u[it + 1].w, a1.w);
+            }
+        }
+        acc = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+    }
+    red4[sl][e] = acc;
+    __syncthreads();
+    if (sl == 0 && grp < ngrp) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 u = red4[j][e];
+            t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
+        }
+        float *o = P.dw1 + (size_t)row * P.ld1 + k;
+        o[0] = t.x, o[1] = t.y, o[2] = t.z, o[3] = t.w;
+    }
+}
+
+// A/B switch: PNPP_NO_WSX=1 keeps the level on the generic path
+static bool wsx_on() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char *v = getenv("PNPP_NO_WSX");
+        cached = (v && atoi(v) != 0) ? 0 : 1;
+    }
+    return cached != 0;
+}
+
+size_t wsx_stat_doubles(int M) {   // what try_launch_wsx writes to its statistics workspace, at most
+    (void)M;
+    return (size_t)512 * kWsxSlab;
+}
+
+bool wsx_applies(const AOperand &dz, const BOperand &W, int M, int C1, int C0, const AOperand &geo) {
+    if (!wsx_on() || matmul_precision() != 0 || stats_sync_on()) return false;
+    if (M < 8192 || M % 32 != 0 || C1 != 64 || C0 != 64) return false;
+    if (dz.mode != A_DZ || dz.lda != C1 || dz.C != C1 || !dz.a || !dz.z || !dz.cst) return false;
+    if (geo.mode != A_GATHER || geo.D != 0 || geo.K != 32 || !geo.xyz || !geo.idx || !geo.new_xyz || geo.S <= 0 || geo.N <= 0) return false;
+    if (W.trans || W.perm_D >= 0 || (W.rows > 0 && W.rows != C1) || W.ldb < 64) return false;
+    if ((((uintptr_t)dz.a | (uintptr_t)dz.z | (uintptr_t)dz.cst) & 15) != 0) return false;
+    if ((unsigned long long)M * (unsigned)C1 * 4ull >= 0xfffffff0ull) return false;                                  // 32-bit buffer offsets
+    if ((unsigned long long)(M / 32 / geo.S) * (unsigned)geo.N * 12ull >= 0xfffffff0ull) return false;
+    return true;
+}
+
+template <int KD, int WPC>
+static void wsx_launch(const WsxArgs &P, int workers, hipStream_t st) {
+    constexpr size_t main_f = (size_t)64 * KD + 4 * 32 * (KD + 4), red_f = (size_t)(KD / 32) * 2 * 4 * 4 * 64 * 4;
+    constexpr size_t lds = ((main_f > red_f ? main_f : red_f) + 2 * KD + 64 + 512 + 512) * sizeof(float);
+    static_assert(lds * WPC <= 160 * 1024, "LDS budget");
+    auto kfn = gemm_wsx_kernel<KD, WPC>;
+    static bool granted = false;
+    if (lds > 48 * 1024 && !granted) {
+        (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        granted = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(workers), dim3(256), lds, st, P);
+}
+
+// dz: A_DZ operand of layer 1; W: W_1 (C_1 x C_0 as stored); geo: the level's grouping (A_GATHER operand of layer 0).
+// Writes dwslab[*workers][C1][64] and stat[*workers][kWsxSlab]; launch_xyz0_post consumes both.
+bool try_launch_wsx(const AOperand &dz, const BOperand &W, int M, int C1, int C0, const AOperand &geo, const float *W0, int ldw0,
+                    const float *scale0, const float *shift0, float *dwslab, double *stat, int *workers_out, hipStream_t st, int *rc) {
+    *rc = PNPP_OK;
+    if (!wsx_applies(dz, W, M, C1, C0, geo)) return false;
+    static const int wpc = (getenv("PNPP_WSX_WPC") && atoi(getenv("PNPP_WSX_WPC")) == 2) ? 2 : 1;
+    const int nstrips = M / 32;
+    int workers = 256 * wpc;
+    if (workers * 4 > nstrips) workers = (nstrips + 3) / 4;
+    *workers_out = workers;
+    WsxArgs P;
+    P.dy = dz.a, P.z = dz.z, P.cst = dz.cst, P.W = W.b, P.ldw = W.ldb, P.M = M;
+    P.xyz = geo.xyz, P.centres = geo.new_xyz, P.idx = geo.idx, P.N = geo.N, P.S = geo.S;
+    P.W0 = W0, P.ldw0 = ldw0, P.scale0 = scale0, P.shift0 = shift0, P.dwslab = dwslab, P.xslab = stat;
+    ProfScope ps(st, "gemm_wsx_kernel<%d,%d> M=%d N=%d K=%d grid=%dx1", C1, wpc, M, C0, C1, workers);
+    if (wpc == 2) wsx_launch<64, 2>(P, workers, st);
+    else wsx_launch<64, 1>(P, workers, st);
+    if (hipGetLastError() != hipSuccess) {
+        set_error("gemm_wsx: launch failed");
+        *rc = PNPP_ERR_LAUNCH;
+    }
+    return true;
+}
+
+int launch_xyz0_post(const float *dwslab, int workers, int C1, float *dw1, int ld1, const double *stat, const float *W0, int ldw0,
+                     const float *gamma0, const float *mean0, const float *istd0, double count, int training, float *dW0, int ld0,
+                     float *dgamma0, float *dbeta0, float *dbias0, hipStream_t st) {
+    Xyz0PostArgs P;
+    P.dwslab = dwslab, P.nslab = workers, P.KD = C1, P.dw1 = dw1, P.ld1 = ld1, P.xslab = stat, P.W0 = W0, P.ldw0 = ldw0;
+    P.gamma0 = gamma0, P.mean0 = mean0, P.istd0 = istd0, P.count = count, P.training = training;
+    P.dW0 = dW0, P.ld0 = ld0, P.dgamma0 = dgamma0, P.dbeta0 = dbeta0, P.dbias0 = dbias0;
+    const int nfin = 64 / 8, nred = cdiv(C1 * 16, 16);
+    ProfScope ps(st, "xyz0_post_kernel C=64 | N=%d K=64 split=%d", C1, workers);
+    hipLaunchKernelGGL(xyz0_post_kernel, dim3(nfin + nred), dim3(256), 0, st, P, nfin);
+    PNPP_CHECK_LAUNCH("xyz0_post");
+    return PNPP_OK;
+}
+
+}  // namespace pnpp

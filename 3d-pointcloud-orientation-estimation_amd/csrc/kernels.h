@@ -144,6 +144,15 @@ bool try_launch_wsf(const AOperand &A, const BOperand &B, int M, int Nout, int K
 // gemm_wsp_kernels.hip: the fused backward product (dA + mask + sums + dW) of a grouped layer with a 64-channel input, wave-private strips
 bool try_launch_wsp(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc,
                     int *dw_slabs);
+// gemm_wsx_kernels.hip: backward through layer 1 of a grouped level whose layer 0 convolves relative coordinates only (D == 0), with
+// layer 0's backward folded in: Z_0 is rebuilt from the coordinates, dY_0 is never written; launch_xyz0_post turns the workers' sums
+// into dW_1 and layer 0's parameter gradients
+bool try_launch_wsx(const AOperand &dz, const BOperand &W, int M, int C1, int C0, const AOperand &geo, const float *W0, int ldw0,
+                    const float *scale0, const float *shift0, float *dwslab, double *stat, int *workers_out, hipStream_t st, int *rc);
+size_t wsx_stat_doubles(int M);
+int launch_xyz0_post(const float *dwslab, int workers, int C1, float *dw1, int ld1, const double *stat, const float *W0, int ldw0,
+                     const float *gamma0, const float *mean0, const float *istd0, double count, int training, float *dW0, int ld0,
+                     float *dgamma0, float *dbeta0, float *dbias0, hipStream_t st);
 bool try_launch_mid_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,
                           int Kp, float *slab, int *nsplit_out, int *kp_pad_out, hipStream_t st, int *rc, float *dw_direct = nullptr,
                           int dw_ld = 0);   // dw_direct (Nc x dw_ld, dw_ld == Kp): written in place when one row range suffices; *nsplit_out = 0 then

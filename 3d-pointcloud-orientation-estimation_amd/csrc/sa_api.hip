@@ -197,7 +197,11 @@ static bool sa_delayed(const pnpp_sa_desc *d) {
 static SaScratch sa_scratch_layout(const pnpp_sa_desc *d, const SaGeom &g, void *base) {
     Carver cv(base);
     SaScratch s;
-    s.slab = cv.take<double>((size_t)kMaxStatBlocks * 2 * g.maxC);
+    {   // BatchNorm partial sums of one layer; a level on raw coordinates also parks layer 0's backward sums here (gemm_wsx_kernels.hip)
+        size_t nd = (size_t)kMaxStatBlocks * 2 * g.maxC;
+        if (!d->group_all && d->D == 0 && wsx_stat_doubles(g.M) > nd) nd = wsx_stat_doubles(g.M);
+        s.slab = cv.take<double>(nd);
+    }
     const int wide = g.maxC > d->D ? g.maxC : d->D;
     s.dy[0] = cv.take<float>((size_t)g.M * wide);
     s.dy[1] = cv.take<float>((size_t)g.M * wide);
@@ -404,6 +408,24 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             dz.lda = C;
         }
 
+        if (l == 1 && !small && !d->group_all && d->D == 0 && g.Cin[0] == 3) {
+            // layer 0 convolves relative coordinates only: layer 1's backward rebuilds Z_0 from them, keeps dY_0 on chip and hands
+            // layer 0's parameter gradients to the launch that reduces dW_1 (gemm_wsx_kernels.hip) -- two launches end the level
+            const AOperand geo = layer0_operand(d, a->xyz, a->points, sv);
+            BOperand W;
+            W.b = a->conv_w[1];
+            W.ldb = d->C[0];
+            W.rows = C;
+            int workers = 0, rc = PNPP_OK;
+            if (try_launch_wsx(dz, W, g.M, C, d->C[0], geo, a->conv_w[0], g.Cin[0], sv.scale[0], sv.shift[0], sc.dwslab, sc.slab, &workers, st,
+                               &rc)) {
+                PNPP_TRY(rc);
+                PNPP_TRY(launch_xyz0_post(sc.dwslab, workers, C, a->d_conv_w[1], g.Cin[1], sc.slab, a->conv_w[0], g.Cin[0], a->bn_w[0],
+                                          sv.mean[0], sv.istd[0], (double)g.M, d->training, a->d_conv_w[0], g.Cin[0], a->d_bn_w[0],
+                                          a->d_bn_b[0], a->d_conv_b[0], st));
+                break;
+            }
+        }
         AOperand a2;
         if (l == 0) {
             a2 = layer0_operand(d, a->xyz, a->points, sv);

@@ -30,6 +30,7 @@ SOURCES = {
     "gemm_mid_kernels.hip": [],
     "gemm_wsf_kernels.hip": [],
     "gemm_wsp_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
+    "gemm_wsx_kernels.hip": [],
     "loss_kernels.hip": [],
     "sa_api.hip": [],
     "fc_api.hip": [],

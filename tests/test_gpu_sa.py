@@ -225,6 +225,40 @@ def test_sa1_shape_backward_in_eval_mode(oracle):
     assert np.sqrt(num / den) < 1e-3
 
 
+@pytest.mark.parametrize("B,N", [(4, 1024), (9, 640)])
+def test_sa1_backward_of_layers_0_and_1_from_the_coordinates(oracle, B, N):
+    """Train-mode backward through the SA1 shape (D = 0, 32 neighbours, [64, 64, 128]) at 8192+ rows: layer 1's backward rebuilds
+    Z_0 from the relative coordinates, never writes dY_0, and layer 0's parameter gradients come from per-channel sums and the
+    coordinate moments (gemm_wsx_kernels.hip).  Every parameter gradient against the float64 oracle, tensor by tensor."""
+    from models.pointnet_pp_8dir import PointNetSetAbstraction
+    torch.manual_seed(11)
+    sa = PointNetSetAbstraction(128, 32, 0, [64, 64, 128]).cuda().train()
+    with torch.no_grad():
+        for bn in sa.bns:
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    xyz, _, _, _ = oracle.synthetic_clouds(B, N, seed=21)
+    g = torch.Generator().manual_seed(5)
+    c1 = torch.stack([torch.randperm(N, generator=g)[:128] for _ in range(B)])
+    _, y = sa(xyz.cuda(), None, c1.cuda())
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(6))
+    y.backward(gy.cuda())
+    P = {}
+    for k, v in sa.state_dict().items():
+        if v.is_floating_point():
+            t = v.detach().cpu().double()
+            P[f"sa.{k}"] = t.requires_grad_(True) if "running" not in k else t
+    _, y_ref, _ = oracle.sa_forward(xyz, None, P, "sa", c1, 32, False, training=True)
+    (y_ref * gy.double()).sum().backward()
+    assert _rel(y.detach().cpu(), y_ref.detach()) < 3e-5
+    for k, p in sa.named_parameters():
+        ref = P[f"sa.{k}"].grad.reshape(p.shape)
+        if k.startswith("convs") and k.endswith("bias"):
+            assert float(p.grad.abs().max()) == 0.0, k      # a bias in front of a train-mode BatchNorm
+            continue
+        assert _rel(p.grad.cpu(), ref) < 3e-3, (k, _rel(p.grad.cpu(), ref))   # (a max-pool tie routed the other way moves single entries)
+
+
 @pytest.mark.parametrize("c0,npoint,nsample,n", [(256, 96, 64, 256), (512, 40, 16, 128), (64, 160, 32, 512)])
 def test_sa_layer0_convolved_before_the_gather(oracle, c0, npoint, nsample, n):
     """Grouped levels with input features run layer 0 on the source points and gather afterwards (P[idx] + W_xyz (x - c),
