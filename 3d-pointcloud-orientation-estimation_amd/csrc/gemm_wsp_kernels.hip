@@ -149,6 +149,16 @@ gemm_wsp_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, c
         // dividing by k must stay finite for every pooled gradient: |k| >= 1e-30 (or the channel is dead: g == 0, dZ = 0)
         bad = (g != 0.f && !(fabsf(ch_k) >= 1e-30f)) || !(g == g);
     }
+    // the weight panel's loads go out here, in front of the first barrier (nothing they need is behind it): one round trip for constants,
+    // panel and first strip instead of two in a row
+    constexpr int NWF = (KD / 4) * BN / 256;
+    f32x4 tw[NWF];
+#pragma unroll
+    for (int j = 0; j < NWF; ++j) {
+        const int f = tid + 256 * j, nl = f % BN, k4 = 4 * (f / BN);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tw[j][e] = W[(size_t)(k4 + e) * ldw + nl];
+    }
     const bool fold = (AM == A_DZ_POOL) && !__syncthreads_or(bad);   // image = raw Z, panel = diag(a) W; else k-form, panel = diag(g) W
     if (tid < KD) Tsc[tid] = fold ? ch_a : ch_g, Tb[tid] = ch_b;
     // staging multipliers (k-form) / fix-up multipliers of this lane
@@ -179,14 +189,6 @@ gemm_wsp_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, c
     // weight panel: W is (KD x 64) row-major; image [n][k ^ swz(n)] of diag(scale) W (lane = column n: four dword loads of consecutive
     // rows, one conflict-free 16-byte LDS store per group); the same pass takes this thread's share of b W
     {
-        constexpr int NWF = (KD / 4) * BN / 256;
-        f32x4 tw[NWF];
-#pragma unroll
-        for (int j = 0; j < NWF; ++j) {
-            const int f = tid + 256 * j, nl = f % BN, k4 = 4 * (f / BN);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tw[j][e] = W[(size_t)(k4 + e) * ldw + nl];
-        }
         float bwp = 0.f;
 #pragma unroll
         for (int j = 0; j < NWF; ++j) {

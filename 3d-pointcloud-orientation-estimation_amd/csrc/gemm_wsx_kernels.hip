@@ -516,6 +516,285 @@ __global__ void __launch_bounds__(256) xyz0_post_kernel(const Xyz0PostArgs P, in
     }
 }
 
+// =====================================================================================================================
+// Forward: layer 0 never exists as a tensor either.
+//   rel_moments_kernel   R1 = sum rel, R2 = sum rel rel^T over the level's rows, one partial per workgroup (few: kMomSlabs at most)
+//   gemm_wsf0_kernel     layer 1's forward product on wave-private strips with its A operand relu(s Z_0 + t) built from the
+//                        coordinates (two MFMA steps per column tile, as in the backward kernel: the SAME instruction on the SAME
+//                        operands, so the ReLU mask the backward pass rebuilds is bit for bit the forward's).  Train mode: every
+//                        workgroup finishes layer 0's BatchNorm statistics itself in its prologue -- mean_c = W_0[c] . R1 / M,
+//                        E[z^2]_c = W_0[c]^T (R2 / M) W_0[c] in float64 from the few moment partials -- and workgroup 0 writes them
+//                        (and the running statistics) for the backward pass.  No layer-0 GEMM, no statistics launch, no Z_0.
+// Reference: models/pointnet_pp_8dir.py:31-41 (grouped_xyz - new_xyz, conv 3 -> 64, BatchNorm, ReLU, conv 64 -> 64).
+constexpr int kMomSlabs = 128, kMomPitch = 16;
+
+struct MomArgs {
+    const float *xyz, *centres;
+    const int32_t *idx;
+    int M, N, S, rows_per_block;
+    double *out;   // [gridDim.x][kMomPitch]
+};
+
+__global__ void __launch_bounds__(256) rel_moments_kernel(const MomArgs P) {
+    __shared__ double red[4][9];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r0 = blockIdx.x * P.rows_per_block, r1 = min(P.M, r0 + P.rows_per_block);
+    double m[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    constexpr int RP = 4;   // rows per thread and pass
+    for (int base = r0; base < r1; base += 256 * RP) {
+        int id[RP];
+        float p[RP][3], c[RP][3];
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {   // every index of the thread first, then every gather: two round trips per 1,024 rows
+            const int r = base + tid + 256 * i;
+            id[i] = P.idx[min(r, P.M - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            const int r = min(base + tid + 256 * i, P.M - 1), g = r >> 5;
+            const float *x = P.xyz + ((size_t)(g / P.S) * P.N + id[i]) * 3, *cc = P.centres + (size_t)g * 3;
+            p[i][0] = x[0], p[i][1] = x[1], p[i][2] = x[2], c[i][0] = cc[0], c[i][1] = cc[1], c[i][2] = cc[2];
+        }
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            const float ok = base + tid + 256 * i < r1 ? 1.f : 0.f;
+            const float x = __fsub_rn(p[i][0], c[i][0]) * ok, y = __fsub_rn(p[i][1], c[i][1]) * ok, z = __fsub_rn(p[i][2], c[i][2]) * ok;
+            m[0] += (double)x, m[1] += (double)y, m[2] += (double)z;
+            m[3] += (double)(x * x), m[4] += (double)(x * y), m[5] += (double)(x * z);
+            m[6] += (double)(y * y), m[7] += (double)(y * z), m[8] += (double)(z * z);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        double v = m[q];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += shfl_xor_f64(v, o);
+        if (lane == 0) red[wv][q] = v;
+    }
+    __syncthreads();
+    if (tid < 9) P.out[(size_t)blockIdx.x * kMomPitch + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+struct Wsf0Args {
+    const float *xyz, *centres;
+    const int32_t *idx;
+    int M, N, S;
+    const float *W0;   // 64 x 3, pitch ldw0
+    int ldw0;
+    // layer 0's BatchNorm: train mode finishes the statistics from the moment partials (mom, nmom); eval mode reads scale0 / shift0
+    const double *mom;
+    int nmom, training;
+    const float *bias0, *gamma0, *beta0;
+    float *rm0, *rv0;
+    long long *nbt0;
+    float momentum, eps;
+    float *mean0, *istd0, *scale0, *shift0;
+    const float *W1;   // C_1 x 64 as stored (row = output channel)
+    int ldw1;
+    float *z1;         // M x 64
+    double *slab;      // [workers][2][64] (EM == E_STORE_STATS)
+};
+
+template <int EM>
+__global__ void __launch_bounds__(256, 2)
+gemm_wsf0_kernel(const Wsf0Args P) {
+    constexpr int KD = 64, BN = 64, DP = KD + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Ws = lds;                          // [BN][KD] image of W_1, 16-byte groups swizzled by (n & 15)
+    float *AsAll = lds + BN * KD;             // [4 waves][32][DP]: relu(s Z_0 + t) of the wave's strip
+    float *Tc = AsAll + 4 * 32 * DP;          // [2][64]: s, t of layer 0
+    double *Rm = reinterpret_cast<double *>(Tc + 128);   // [4][9] + [9]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *As = AsAll + wave * (32 * DP);
+    const int l31 = lane & 31, lh = lane >> 5;
+    auto swz = [](int r) { return (r & 15) << 2; };
+    const int worker = blockIdx.x, nworkers = gridDim.x;
+    const int nstrips = P.M / 32, stride = nworkers * 4;
+    int strip = worker * 4 + wave;
+    const __amdgpu_buffer_rsrc_t resI = wsx_rsrc(P.idx), resX = wsx_rsrc(P.xyz), resC = wsx_rsrc(P.centres);
+    const __amdgpu_buffer_rsrc_t resNull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.xyz), (short)0, 0, 0x00020000);
+    int nidx;
+    float px, py, pz, cx, cy, cz;
+    auto fetch_idx = [&](__amdgpu_buffer_rsrc_t rI, int s) { nidx = __builtin_bit_cast(int, wsx_load1(rI, 4u * (unsigned)l31, (unsigned)s * 128u)); };
+    auto fetch_geo = [&](__amdgpu_buffer_rsrc_t rX, __amdgpu_buffer_rsrc_t rCn, int s) {
+        const unsigned cloud = (unsigned)(s / P.S) * (unsigned)P.N * 12u, po = 12u * (unsigned)nidx;
+        px = wsx_load1(rX, po, cloud), py = wsx_load1(rX, po + 4u, cloud), pz = wsx_load1(rX, po + 8u, cloud);
+        const unsigned co = (unsigned)s * 12u;
+        cx = wsx_load1(rCn, 0u, co), cy = wsx_load1(rCn, 4u, co), cz = wsx_load1(rCn, 8u, co);
+    };
+    // ---- everything the prologue reads is requested before its first wait ----
+    const bool have = strip < nstrips;
+    fetch_idx(have ? resI : resNull, have ? strip : 0);
+    double mpart = 0.0;
+    const int mq = tid & 15, mqc = mq < 9 ? mq : 8;
+    if (P.training) {   // moment partials: 16 slab lanes x (9 of 16) values
+#pragma unroll
+        for (int it = 0; it < kMomSlabs / 16; ++it) {
+            const int s = (tid >> 4) + 16 * it;
+            const double v = P.mom[(size_t)(s < P.nmom ? s : 0) * kMomPitch + mqc];
+            mpart += s < P.nmom ? v : 0.0;
+        }
+    }
+    float w0[3] = {0.f, 0.f, 0.f}, p_g = 1.f, p_b = 0.f, p_bias = 0.f, p_rm = 0.f, p_rv = 0.f;
+    if (tid < 64) {
+        w0[0] = P.W0[tid * P.ldw0], w0[1] = P.W0[tid * P.ldw0 + 1], w0[2] = P.W0[tid * P.ldw0 + 2];
+        if (P.training) {
+            if (P.gamma0) p_g = P.gamma0[tid];
+            if (P.beta0) p_b = P.beta0[tid];
+            if (worker == 0) {
+                if (P.bias0) p_bias = P.bias0[tid];
+                if (P.rm0) p_rm = P.rm0[tid], p_rv = P.rv0[tid];
+            }
+        } else {
+            p_g = P.scale0[tid], p_b = P.shift0[tid];
+        }
+    }
+    constexpr int NWF = (KD / 4) * BN / 256;   // weight panel W_1[n][0 .. KD): consecutive lanes take consecutive 16-byte groups of a row
+    f32x4 tw[NWF];
+#pragma unroll
+    for (int j = 0; j < NWF; ++j) {
+        const int f = tid + 256 * j, nl = f / (KD / 4), k4 = 4 * (f % (KD / 4));
+        tw[j] = *reinterpret_cast<const f32x4 *>(P.W1 + (size_t)nl * P.ldw1 + k4);
+    }
+    if (P.training) {   // lanes mq + 16 j of a wave hold the same moment
+        mpart += shfl_xor_f64(mpart, 16), mpart += shfl_xor_f64(mpart, 32);
+        if (lane < 16) Rm[wave * 16 + mq] = mpart;
+    }
+#pragma unroll
+    for (int j = 0; j < NWF; ++j) {
+        const int f = tid + 256 * j, nl = f / (KD / 4), k4 = 4 * (f % (KD / 4));
+        *reinterpret_cast<f32x4 *>(Ws + nl * KD + (k4 ^ swz(nl))) = tw[j];
+    }
+    fetch_geo(have ? resX : resNull, have ? resC : resNull, have ? strip : 0);
+    __syncthreads();
+    if (tid < 64) {
+        float sc = p_g, sh = p_b;
+        if (P.training) {
+            double R[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) R[q] = (Rm[q] + Rm[16 + q]) + (Rm[32 + q] + Rm[48 + q]);
+            const double inv = 1.0 / (double)P.M, wx = (double)w0[0], wy = (double)w0[1], wz = (double)w0[2];
+            const double mu = (wx * R[0] + wy * R[1] + wz * R[2]) * inv;
+            const double e2 = (wx * (wx * R[3] + wy * R[4] + wz * R[5]) + wy * (wx * R[4] + wy * R[6] + wz * R[7]) +
+                               wz * (wx * R[5] + wy * R[7] + wz * R[8])) * inv;
+            double var = e2 - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const double is = 1.0 / sqrt(var + (double)P.eps);
+            sc = (float)((double)p_g * is), sh = (float)((double)p_b - mu * (double)p_g * is);
+            if (worker == 0) {
+                P.mean0[tid] = (float)mu, P.istd0[tid] = (float)is, P.scale0[tid] = sc, P.shift0[tid] = sh;
+                if (P.rm0) {
+                    const double cnt = (double)P.M, unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+                    P.rm0[tid] = (float)((1.0 - (double)P.momentum) * (double)p_rm + (double)P.momentum * (mu + (double)p_bias));
+                    P.rv0[tid] = (float)((1.0 - (double)P.momentum) * (double)p_rv + (double)P.momentum * unbiased);
+                }
+                if (P.nbt0 && tid == 0) *P.nbt0 += 1;
+            }
+        }
+        Tc[tid] = sc, Tc[64 + tid] = sh;
+    }
+    __syncthreads();   // the panel and layer 0's constants are complete; from here on the waves run on their own
+    float zb0[2], zb1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = j * 32 + l31;
+        const float sc = Tc[col], sh = Tc[64 + col];
+        const float wx = P.W0[col * P.ldw0], wy = P.W0[col * P.ldw0 + 1], wz = P.W0[col * P.ldw0 + 2];
+        zb0[j] = lh ? sc * wy : sc * wx;
+        zb1[j] = lh ? sh : sc * wz;
+    }
+    double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
+    const float *arow = As + l31 * DP + 4 * lh;
+    float *wcol = As + 4 * lh * DP + l31;     // accumulator position (row 4 lh + ro, column 32 j + l31) of the strip image
+    const float *brow[2];
+    int gb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = j * 32 + l31;
+        brow[j] = Ws + n * KD;
+        gb[j] = (4 * lh) ^ swz(n);
+    }
+    for (; strip < nstrips; strip += stride) {
+        const bool more = strip + stride < nstrips;
+        const int snext = more ? strip + stride : 0;
+        const __amdgpu_buffer_rsrc_t nI = more ? resI : resNull, nX = more ? resX : resNull, nC = more ? resC : resNull;
+        const float rx = __fsub_rn(px, cx), ry_ = __fsub_rn(py, cy), rz_ = __fsub_rn(pz, cz);
+        const float za0 = lh ? ry_ : rx, za1 = lh ? 1.f : rz_;
+        fetch_idx(nI, snext);
+        // relu(s Z_0 + t) of the strip: [x y | z 1] x [s w_x, s w_y | s w_z, t], accumulator layout -> the strip image
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x16 zt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zt[r] = 0.f;
+            zt = __builtin_amdgcn_mfma_f32_32x32x2f32(za0, zb0[j], zt, 0, 0, 0);
+            zt = __builtin_amdgcn_mfma_f32_32x32x2f32(za1, zb1[j], zt, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wcol[((r & 3) + 8 * (r >> 2)) * DP + 32 * j] = fmaxf(zt[r], 0.f);
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        {
+            float4 fa[2], fb[2][2];
+            auto ld = [&](int buf, int t) {
+                fa[buf] = *reinterpret_cast<const float4 *>(arow + 8 * t);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[buf][j] = *reinterpret_cast<const float4 *>(brow[j] + ((8 * t) ^ gb[j]));
+            };
+            auto mm = [&](int buf) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].x, fb[buf][j].x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].y, fb[buf][j].y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].z, fb[buf][j].z, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].w, fb[buf][j].w, acc[j], 0, 0, 0);
+                }
+            };
+            ld(0, 0);
+#pragma unroll
+            for (int t = 0; t < 8; t += 2) {
+                ld(1, t + 1);
+                mm(0);
+                if (t + 2 < 8) ld(0, t + 2);
+                mm(1);
+            }
+        }
+        fetch_geo(nX, nC, snext);   // the next strip's coordinates: its indices were requested a whole product ago
+        float *tb = P.z1 + (size_t)(strip * 32 + 4 * lh) * 64 + l31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[j][r];
+                tb[(size_t)((r & 3) + 8 * (r >> 2)) * 64 + j * 32] = v;
+                t1 += v;
+                t2 = fmaf(v, v, t2);
+            }
+            if constexpr (EM == E_STORE_STATS) s1[j] += (double)t1, s2[j] += (double)t2;
+        }
+    }
+    if constexpr (EM == E_STORE_STATS) {
+        __syncthreads();   // every wave is done with the panel and its strip
+        double *red = reinterpret_cast<double *>(lds);   // [4 waves][2][64]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double a = s1[j] + shfl_xor_f64(s1[j], 32), b = s2[j] + shfl_xor_f64(s2[j], 32);
+            if (lh == 0) red[(wave * 2 + 0) * BN + j * 32 + l31] = a, red[(wave * 2 + 1) * BN + j * 32 + l31] = b;
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, cl = tid % BN;
+            const double t = (red[(0 * 2 + which) * BN + cl] + red[(1 * 2 + which) * BN + cl]) +
+                             (red[(2 * 2 + which) * BN + cl] + red[(3 * 2 + which) * BN + cl]);
+            P.slab[((size_t)worker * 2 + which) * 64 + cl] = t;
+        }
+    }
+}
+
 // A/B switch: PNPP_NO_WSX=1 keeps the level on the generic path
 static bool wsx_on() {
     static int cached = -1;
@@ -541,6 +820,60 @@ bool wsx_applies(const AOperand &dz, const BOperand &W, int M, int C1, int C0, c
     if ((unsigned long long)M * (unsigned)C1 * 4ull >= 0xfffffff0ull) return false;                                  // 32-bit buffer offsets
     if ((unsigned long long)(M / 32 / geo.S) * (unsigned)geo.N * 12ull >= 0xfffffff0ull) return false;
     return true;
+}
+
+// the whole shortcut: layer 0 on relative coordinates only (D == 0), 32 neighbours, 64 -> 64 channels in front of a third layer
+bool xyz0_applies(int M, int D, int K, int group_all, int L, const int *C) {
+    if (!wsx_on() || matmul_precision() != 0 || stats_sync_on()) return false;
+    if (group_all || D != 0 || K != 32 || L < 3 || C[0] != 64 || C[1] != 64) return false;
+    if (M < 8192 || M % 32 != 0 || (unsigned long long)M * 64ull * 4ull >= 0xfffffff0ull) return false;
+    return true;
+}
+size_t xyz0_moment_doubles() { return (size_t)kMomSlabs * kMomPitch; }
+
+int launch_rel_moments(const AOperand &geo, int M, double *mom, int *nmom, hipStream_t st) {
+    int nb = kMomSlabs;
+    int rows = cdiv(cdiv(M, nb), 256) * 256;   // whole passes of the workgroup
+    nb = cdiv(M, rows);
+    MomArgs P;
+    P.xyz = geo.xyz, P.centres = geo.new_xyz, P.idx = geo.idx, P.M = M, P.N = geo.N, P.S = geo.S, P.rows_per_block = rows, P.out = mom;
+    *nmom = nb;
+    ProfScope ps(st, "rel_moments_kernel M=%d grid=%dx1", M, nb);
+    hipLaunchKernelGGL(rel_moments_kernel, dim3(nb), dim3(256), 0, st, P);
+    PNPP_CHECK_LAUNCH("rel_moments");
+    return PNPP_OK;
+}
+
+// layer 1's forward product with layer 0 built from the coordinates.  training: mom / nmom from launch_rel_moments, the kernel writes
+// mean0 / istd0 / scale0 / shift0 (and updates rm0 / rv0 / nbt0); eval: scale0 / shift0 are read.  E: E_STORE or E_STORE_STATS.
+int launch_wsf0(const AOperand &geo, int M, const float *W0, int ldw0, const double *mom, int nmom, int training, const float *bias0,
+                const float *gamma0, const float *beta0, float *rm0, float *rv0, long long *nbt0, float momentum, float eps, float *mean0,
+                float *istd0, float *scale0, float *shift0, const float *W1, int ldw1, const Epilogue &E, int *nslab, hipStream_t st) {
+    PNPP_REQUIRE(E.ldc == 64 && !E.pool_ext && (E.mode == E_STORE || E.mode == E_STORE_STATS), PNPP_ERR_ARG, "wsf0: unsupported epilogue");
+    PNPP_REQUIRE((ldw1 & 3) == 0 && ((uintptr_t)W1 & 15) == 0, PNPP_ERR_ARG, "wsf0: weight alignment");
+    Wsf0Args P;
+    P.xyz = geo.xyz, P.centres = geo.new_xyz, P.idx = geo.idx, P.M = M, P.N = geo.N, P.S = geo.S, P.W0 = W0, P.ldw0 = ldw0;
+    P.mom = mom, P.nmom = nmom, P.training = training, P.bias0 = bias0, P.gamma0 = gamma0, P.beta0 = beta0, P.rm0 = rm0, P.rv0 = rv0;
+    P.nbt0 = nbt0, P.momentum = momentum, P.eps = eps, P.mean0 = mean0, P.istd0 = istd0, P.scale0 = scale0, P.shift0 = shift0;
+    P.W1 = W1, P.ldw1 = ldw1, P.z1 = E.c, P.slab = E.slab;
+    const int nstrips = M / 32;
+    int workers = 512;
+    if (workers * 4 > nstrips) workers = (nstrips + 3) / 4;
+    if (nslab) *nslab = workers;
+    constexpr size_t lds = ((size_t)64 * 64 + 4 * 32 * 68 + 128) * sizeof(float) + (64 + 16) * sizeof(double);
+    ProfScope ps(st, "gemm_wsf0_kernel<E%d> M=%d N=64 K=64 grid=%dx1", E.mode, M, workers);
+    static bool granted[2] = {false, false};
+    if (E.mode == E_STORE_STATS) {
+        auto kfn = gemm_wsf0_kernel<E_STORE_STATS>;
+        if (!granted[0]) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), granted[0] = true;
+        hipLaunchKernelGGL(kfn, dim3(workers), dim3(256), lds, st, P);
+    } else {
+        auto kfn = gemm_wsf0_kernel<E_STORE>;
+        if (!granted[1]) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), granted[1] = true;
+        hipLaunchKernelGGL(kfn, dim3(workers), dim3(256), lds, st, P);
+    }
+    PNPP_CHECK_LAUNCH("gemm_wsf0");
+    return PNPP_OK;
 }
 
 template <int KD, int WPC>

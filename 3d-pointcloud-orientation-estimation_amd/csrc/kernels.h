@@ -150,6 +150,14 @@ bool try_launch_wsp(const AOperand &A, const BOperand &B, int M, int Nout, int K
 bool try_launch_wsx(const AOperand &dz, const BOperand &W, int M, int C1, int C0, const AOperand &geo, const float *W0, int ldw0,
                     const float *scale0, const float *shift0, float *dwslab, double *stat, int *workers_out, hipStream_t st, int *rc);
 size_t wsx_stat_doubles(int M);
+// the forward half: layer 0's statistics from the moments of the relative coordinates, layer 1's product with its operand built from
+// the coordinates -- Z_0 is never stored.  xyz0_applies decides for BOTH directions of a level (forward keeps no Z_0 for a generic backward)
+bool xyz0_applies(int M, int D, int K, int group_all, int L, const int *C);
+size_t xyz0_moment_doubles();
+int launch_rel_moments(const AOperand &geo, int M, double *mom, int *nmom, hipStream_t st);
+int launch_wsf0(const AOperand &geo, int M, const float *W0, int ldw0, const double *mom, int nmom, int training, const float *bias0,
+                const float *gamma0, const float *beta0, float *rm0, float *rv0, long long *nbt0, float momentum, float eps, float *mean0,
+                float *istd0, float *scale0, float *shift0, const float *W1, int ldw1, const Epilogue &E, int *nslab, hipStream_t st);
 int launch_xyz0_post(const float *dwslab, int workers, int C1, float *dw1, int ld1, const double *stat, const float *W0, int ldw0,
                      const float *gamma0, const float *mean0, const float *istd0, double count, int training, float *dW0, int ld0,
                      float *dgamma0, float *dbeta0, float *dbias0, hipStream_t st);

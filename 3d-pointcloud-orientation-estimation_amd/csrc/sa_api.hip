@@ -186,6 +186,7 @@ struct SaScratch {
     float *dwslab;
     float *src;  // convolve-then-gather layer 0: one C_0-wide row per source point (P forward, G backward)
     float *xslab;  // ... and the [C_0][4] dW_xyz partials of its backward scatter
+    double *mom;   // a level on raw coordinates: moment partials of the relative coordinates (gemm_wsx_kernels.hip)
     size_t bytes;
 };
 
@@ -227,6 +228,7 @@ static SaScratch sa_scratch_layout(const pnpp_sa_desc *d, const SaGeom &g, void 
     s.dwslab = cv.take<float>(dwmax);
     s.src = cv.take<float>(sa_delayed(d) ? (size_t)d->B * d->N * d->C[0] : 0);
     s.xslab = cv.take<float>(sa_delayed(d) ? (size_t)scatter_dz_splits(d->B * d->N) * d->C[0] * 4 : 0);
+    s.mom = cv.take<double>((!d->group_all && d->D == 0) ? xyz0_moment_doubles() : 0);
     s.bytes = cv.bytes();
     return s;
 }
@@ -275,7 +277,30 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
 
     // 2. conv -> BN -> ReLU chain; BN apply + ReLU of layer l-1 happen inside layer l's operand loader
     bool pooled = false;
+    // a level on raw coordinates (SA1): layer 0 never exists as a tensor -- its statistics come from the moments of the relative
+    // coordinates, layer 1's product builds its operand from the coordinates (gemm_wsx_kernels.hip); the backward pass does the same
+    const bool xyz0 = xyz0_applies(g.M, d->D, d->K, d->group_all, d->L, d->C);
+    int nmom = 0;
     for (int l = 0; l < d->L; ++l) {
+        if (xyz0 && l == 0) {
+            if (d->training) {
+                PNPP_TRY(launch_rel_moments(layer0_operand(d, a->xyz, a->points, sv), g.M, sc.mom, &nmom, st));
+            } else {
+                PNPP_TRY(launch_bn_finalize_fwd(nullptr, 0, d->C[0], (double)g.M, a->conv_b[0], a->bn_w[0], a->bn_b[0], a->bn_rm[0],
+                                                a->bn_rv[0], nullptr, d->momentum, d->eps, 0, sv.mean[0], sv.istd[0], sv.scale[0],
+                                                sv.shift[0], st));
+            }
+            continue;
+        }
+        // layer 1 of such a level: the product that also finishes layer 0's BatchNorm
+        auto gemm_l = [&](const AOperand &Aop, const BOperand &Wop, const Epilogue &Eop, int *ns) -> int {
+            if (xyz0 && l == 1)
+                return launch_wsf0(layer0_operand(d, a->xyz, a->points, sv), g.M, a->conv_w[0], g.Cin[0], sc.mom, nmom, d->training ? 1 : 0,
+                                   a->conv_b[0], a->bn_w[0], a->bn_b[0], a->bn_rm[0], a->bn_rv[0],
+                                   d->training ? (long long *)a->bn_nbt[0] : nullptr, d->momentum, d->eps, sv.mean[0], sv.istd[0],
+                                   sv.scale[0], sv.shift[0], a->conv_w[1], g.Cin[1], Eop, ns, st);
+            return launch_gemm(Aop, Wop, g.M, d->C[l], g.Kd[l], Eop, ns, st);
+        };
         AOperand A;
         if (l == 0) {
             A = layer0_operand(d, a->xyz, a->points, sv);
@@ -325,7 +350,7 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
             // and finished by the statistics launch (sv.zmax holds the extreme pre-BN values; the backward pass reads them too)
             const bool pool_here = l == d->L - 1 && l > 0 && pool_fused_on() && gemm_pools_in_epilogue(A, g.M, d->C[l], g.Kd[l], d->K);
             if (pool_here) E.pool_ext = sv.zmax, E.pool_arg = sv.arg, E.pool_gamma = a->bn_w[l];
-            PNPP_TRY(launch_gemm(A, W, g.M, d->C[l], g.Kd[l], E, &nslab, st));
+            PNPP_TRY(gemm_l(A, W, E, &nslab));
             StatsView V;
             PNPP_TRY(stats_exchange(sc.slab, nslab, d->C[l], (double)g.M, st, &V));
             PNPP_TRY(launch_bn_finalize_fwd(V.slab, V.nslab, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
@@ -340,7 +365,7 @@ static int sa_forward_impl(const pnpp_sa_desc *d, const pnpp_sa_fwd_args *a, hip
             PNPP_TRY(launch_bn_finalize_fwd(nullptr, 0, d->C[l], (double)g.M, a->conv_b[l], a->bn_w[l], a->bn_b[l],
                                             a->bn_rm[l], a->bn_rv[l], nullptr, d->momentum, d->eps, 0, sv.mean[l], sv.istd[l],
                                             sv.scale[l], sv.shift[l], st));
-            PNPP_TRY(launch_gemm(A, W, g.M, d->C[l], g.Kd[l], E, nullptr, st));
+            PNPP_TRY(gemm_l(A, W, E, nullptr));
         }
     }
 
@@ -408,7 +433,7 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
             dz.lda = C;
         }
 
-        if (l == 1 && !small && !d->group_all && d->D == 0 && g.Cin[0] == 3) {
+        if (l == 1 && xyz0_applies(g.M, d->D, d->K, d->group_all, d->L, d->C)) {
             // layer 0 convolves relative coordinates only: layer 1's backward rebuilds Z_0 from them, keeps dY_0 on chip and hands
             // layer 0's parameter gradients to the launch that reduces dW_1 (gemm_wsx_kernels.hip) -- two launches end the level
             const AOperand geo = layer0_operand(d, a->xyz, a->points, sv);
@@ -425,6 +450,8 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
                                           a->d_bn_b[0], a->d_conv_b[0], st));
                 break;
             }
+            // the forward pass of this level kept no Z_0: there is no generic path to fall back to
+            PNPP_REQUIRE(false, PNPP_ERR_ARG, "sa_backward: the coordinate-level backward kernel does not take this call (alignment?)");
         }
         AOperand a2;
         if (l == 0) {

