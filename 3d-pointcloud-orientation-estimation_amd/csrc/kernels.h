@@ -144,6 +144,10 @@ bool try_launch_wsf(const AOperand &A, const BOperand &B, int M, int Nout, int K
 // gemm_wsp_kernels.hip: the fused backward product (dA + mask + sums + dW) of a grouped layer with a 64-channel input, wave-private strips
 bool try_launch_wsp(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc,
                     int *dw_slabs);
+// gemm_wsq_kernels.hip: the fused backward product of a level's last layer at 256 channels (K = 256, N = 128): 64-row tiles, the
+// BatchNorm-backward transform folded into the products, dW rows in accumulator order
+bool try_launch_wsq(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc,
+                    int *dw_slabs);
 // gemm_wsx_kernels.hip: backward through layer 1 of a grouped level whose layer 0 convolves relative coordinates only (D == 0), with
 // layer 0's backward folded in: Z_0 is rebuilt from the coordinates, dY_0 is never written; launch_xyz0_post turns the workers' sums
 // into dW_1 and layer 0's parameter gradients

@@ -31,6 +31,7 @@ SOURCES = {
     "gemm_wsf_kernels.hip": [],
     "gemm_wsp_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_wsx_kernels.hip": [],
+    "gemm_wsq_kernels.hip": [],
     "loss_kernels.hip": [],
     "sa_api.hip": [],
     "fc_api.hip": [],

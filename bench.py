@@ -172,7 +172,28 @@ def kernel_cost(tag: str):
         m = re.search(pattern, text)
         return tuple(int(x) for x in m.groups()) if m else None
 
-    if tag.startswith("da_dw_kernel"):
+    if tag.startswith(("gemm_wsp_kernel", "gemm_wsq_kernel")):
+        # the fused backward product of a level's last layer on gemm_wsp / gemm_wsq: dA (+ ReLU mask, sums) and dW in one launch;
+        # Z_l and z_{l-1} read once, dY_{l-1} written once, one K x 64 dW partial per workgroup
+        M, N, K = ints(r"M=(\d+) N=(\d+) K=(\d+)")
+        g, = ints(r"grid=(\d+)x")
+        return 4.0 * M * N * K, 4.0 * (M * K + 2.0 * M * N + K * N + K * 64.0 * g)
+    if tag.startswith("gemm_wsx_kernel"):
+        # layer 1's backward with layer 0 folded in: dY_1 and Z_1 read once, neighbour indices; Z_0 is rebuilt (two MFMA steps per
+        # tile), dY_0 is never written; one K x 64 dW partial + 272 doubles per workgroup
+        M, N, K = ints(r"M=(\d+) N=(\d+) K=(\d+)")
+        g, = ints(r"grid=(\d+)x")
+        return 4.0 * M * N * K + 8.0 * M * N, 4.0 * (2.0 * M * K + M + K * N + K * 64.0 * g) + 2176.0 * g
+    if tag.startswith("gemm_wsf0_kernel"):
+        M, N, K = ints(r"M=(\d+) N=(\d+) K=(\d+)")
+        return 2.0 * M * N * K + 8.0 * M * K, 4.0 * (M * N + M + K * N)   # z_1 written once, neighbour indices read; no operand stream
+    if tag.startswith("rel_moments_kernel"):
+        M, = ints(r"M=(\d+)")
+        return 18.0 * M, 4.0 * M                             # neighbour indices (the coordinates are L2-resident)
+    if tag.startswith("xyz0_post_kernel"):
+        n, s = ints(r"N=(\d+) K=64 split=(\d+)")
+        return 0.0, 4.0 * n * 64.0 * (s + 1) + 2176.0 * s
+    if tag.startswith("da_dw_kernel") or tag.startswith("da_dw_mid_kernel"):
         # one launch = the dA GEMM tiles and the dW blocks of a small-M backward layer (they only share dZ)
         M, = ints(r"M=(\d+)")
         n1, k1 = ints(r"dA N=(\d+) K=(\d+)")
@@ -211,7 +232,7 @@ def kernel_cost(tag: str):
         return None
     M, N, K = mnk
     flops = 2.0 * M * N * K
-    if tag.startswith(("gemm_kernel", "gemm_ws_kernel", "gemm_wsb_kernel", "gemm_smallm_kernel", "gemm_mid_kernel")):
+    if tag.startswith(("gemm_kernel", "gemm_ws_kernel", "gemm_wsb_kernel", "gemm_wsf_kernel", "gemm_smallm_kernel", "gemm_mid_kernel")):
         a, e = ints(r"A(\d),E(\d)")
         byts = 4.0 * (M * N + K * N)                      # write C, read weights
         byts += 4.0 * M * K * (2 if a == 4 else 1)        # read A (dy and z for the BatchNorm-backward operand; A5: z only,

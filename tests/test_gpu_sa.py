@@ -229,6 +229,51 @@ def test_sa1_shape_backward_in_eval_mode(oracle):
     assert np.sqrt(num / den) < 1e-3
 
 
+@pytest.mark.parametrize("training", [True, False])
+def test_sa2_shape_backward_of_the_256_channel_last_layer(oracle, training):
+    """The SA2 shape (128 features, 32 centres x 32 neighbours, [128, 128, 256]) at batch 32 = 32,768 rows: the last layer's fused backward
+    product runs on gemm_wsq_kernel (BatchNorm-backward folded into the weight panel; in eval mode its z-coefficient is exactly zero
+    and the launch takes the k-form).  Every parameter gradient and the feature gradient against the float64 oracle."""
+    from models.pointnet_pp_8dir import PointNetSetAbstraction
+    torch.manual_seed(13)
+    sa = PointNetSetAbstraction(32, 32, 128, [128, 128, 256]).cuda()
+    with torch.no_grad():
+        for bn in sa.bns:
+            bn.running_mean.uniform_(-0.2, 0.2)
+            bn.running_var.uniform_(0.5, 1.5)
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.2, 0.2)
+    sa.train(training)
+    B, N = 32, 128
+    g = torch.Generator().manual_seed(8)
+    xyz = torch.rand(B, N, 3, generator=g) * 2 - 1
+    feats = torch.randn(B, N, 128, generator=g)
+    c = torch.stack([torch.randperm(N, generator=g)[:32] for _ in range(B)])
+    f_hip = feats.cuda().requires_grad_(True)
+    _, y = sa(xyz.cuda(), f_hip, c.cuda())
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(9))
+    y.backward(gy.cuda())
+    P = {}
+    for k, v in sa.state_dict().items():
+        if v.is_floating_point():
+            t = v.detach().cpu().double()
+            P[f"sa.{k}"] = t.requires_grad_(True) if "running" not in k else t
+    f64 = feats.double().requires_grad_(True)
+    _, y_ref, _ = oracle.sa_forward(xyz, f64, P, "sa", c, 32, False, training=training)
+    (y_ref * gy.double()).sum().backward()
+    assert _rel(y.detach().cpu(), y_ref.detach()) < 3e-5
+    # relative L2 per tensor.  With 4 M activations per layer a float32 ReLU decision or max-pool tie falls the other way than float64's
+    # about once per layer and pass, each worth 5e-4 ... 3e-3 of a tensor's norm (measured on the generic kernels: 2.8e-3 train, 8.9e-4
+    # eval; the tensors no such decision reaches agree to 2e-7) -- the gate is for O(1) errors (a wrong operand map reads 1.2 here)
+    l2 = lambda a, b: float((a.double() - b).norm() / b.norm())
+    assert l2(f_hip.grad.cpu(), f64.grad) < 1e-2
+    for k, p in sa.named_parameters():
+        ref = P[f"sa.{k}"].grad.reshape(p.shape)
+        if training and k.startswith("convs") and k.endswith("bias"):
+            continue
+        assert l2(p.grad.cpu(), ref) < 1e-2, (k, l2(p.grad.cpu(), ref))
+
+
 @pytest.mark.parametrize("B,N", [(4, 1024), (9, 640)])
 def test_sa1_backward_of_layers_0_and_1_from_the_coordinates(oracle, B, N):
     """Train-mode backward through the SA1 shape (D = 0, 32 neighbours, [64, 64, 128]) at 8192+ rows: layer 1's backward rebuilds
