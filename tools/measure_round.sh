@@ -10,7 +10,9 @@ OUT=gpurun_out/$TAG
 P=$OUT/profiles
 mkdir -p $P
 export TMPDIR=/tmp
+PART=${PNPP_MEASURE_PART:-ABC}   # a gpurun call is limited to 20 minutes: A = counters + bench line + trace, B = index kernels + sweep + SQ counters, C = other configs and side tools
 BENCH="bench.py --steps 200 --warmup 20 --no-cpu-baseline"
+if [[ $PART == *A* ]]; then
 echo "[1/8] FETCH_SIZE of the step"; rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-graph --no-bf16-variant > $OUT/fetch.log 2>&1
 echo "[2/8] WRITE_SIZE of the step"; rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-graph --no-bf16-variant > $OUT/write.log 2>&1
 python3 tools/summarize_rocprof.py pmc $OUT/fetch $OUT/write $P/pmc_traffic.json $P/${TAG}_pmc_traffic.csv
@@ -21,6 +23,8 @@ PNPP_BENCH_DUMP=$P/${TAG}_kernel_table_events.txt python3 bench.py --steps 50 --
 PNPP_BENCH_DUMP=$P/${TAG}_kernel_table_events_bf16.txt python3 bench.py --precision bf16 --steps 50 --warmup 10 --no-cpu-baseline > $P/${TAG}_bench_bf16.json 2>> $OUT/bench.err
 echo "[4/8] kernel trace of the step"; rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $BENCH --no-roofline --no-bf16-variant > $OUT/trace.log 2>&1
 python3 tools/summarize_rocprof.py stats $OUT/trace $P/${TAG}_kernel_stats.csv
+fi
+if [[ $PART == *B* ]]; then
 echo "[5/8] index kernels: events, trace, counters"
 python3 tools/bench_index_kernels.py --json $P/${TAG}_index_kernels.json > $P/${TAG}_index_kernels.txt 2> $OUT/idx.err
 rocprofv3 --kernel-trace --stats -d $OUT/idx_trace -o idx --output-format csv -- python3 tools/bench_index_kernels.py --reps 5 > $OUT/idx_trace.log 2>&1
@@ -33,6 +37,8 @@ python3 tools/batch_sweep.py > $P/${TAG}_batch_sweep.json 2> $OUT/sweep.err
 echo "[7/8] SQ counters of every kernel (two --pmc passes, no trace domains)"
 PNPP_SQ_FILTER= bash tools/sq_counters.sh ${TAG}_sq > /dev/null 2>&1 || echo "sq counters failed"
 { echo "# SQ counters per kernel launch (rocprofv3 --pmc, two passes; tools/sq_counters.sh), kernel sources of $PNPP_GIT_REV"; cat gpurun_out/${TAG}_sq/sq_p1.txt; echo; cat gpurun_out/${TAG}_sq/sq_p2.txt; } > $P/${TAG}_sq_counters.txt
+fi
+if [[ $PART == *C* ]]; then
 echo "[8/8] the other BASELINE configs and the side tools"
 python3 tools/bench_config.py --config 2 > $P/${TAG}_bench_config2.json 2> $OUT/cfg2.err
 python3 tools/bench_config.py --config 3 > $P/${TAG}_bench_config3.json 2> $OUT/cfg3.err
@@ -40,6 +46,7 @@ python3 tools/bench_point_transformer.py > $P/${TAG}_point_transformer_step.json
 python3 tools/bench_simple_pointnet.py > $P/${TAG}_simple_pointnet_step.json 2> $OUT/simple.err || true
 python3 tools/script_throughput.py > $P/${TAG}_script_throughput.json 2> $OUT/script.err || true
 python3 tools/convergence.py > $P/${TAG}_convergence.json 2> $OUT/conv.err || true
+fi
 # raw directories can be large: keep only the summaries for the merge back
 rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/idx_trace $OUT/idx_fetch $OUT/idx_write
 ls -la $P
