@@ -1,0 +1,72 @@
+// Standalone A/B of the K = 256 fused backward product (gemm_wsq_kernel against gemm_ws_kernel<256,...,dW>) through launch_gemm:
+//   hipcc -O2 --offload-arch=gfx950 -std=c++17 -Iinclude tools/ab_wsq.hip -o ab/ab_wsq -L<pkg>/pnpp_hip -lpnpp_hip -ldl -Wl,-rpath,...
+//   PNPP_NO_WSQ=1 ab/ab_wsq ref.bin <mode> [keep];  PNPP_NO_WSQ=0 ab/ab_wsq new.bin <mode> [keep];  python tools/ab_wsq_cmp.py ref.bin new.bin
+// mode 0: train-mode constants, 1: eval-mode (k-form), 2: synthetic pattern (one-hot at row 5, all-ones weights) with `keep` selecting
+// which random parts survive (1 W, 2 z_{l-1} / scale / shift, 4 arg-max rows, 8 pooled gradient, 16 gamma) -- how the round-3 bug was
+// found: arg-max rows loaded through a FLOAT vector type were flushed as denormals (keep = 4 broke, everything else matched).
+// STAMPS=1 with a -DPNPP_STAMPS library prints the kernel's phase stamps.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <random>
+#include "../3d-pointcloud-orientation-estimation_amd/csrc/kernels.h"   // internal launcher interface (C++ symbols of libpnpp_hip.so)
+using namespace pnpp;
+#include <dlfcn.h>
+typedef int (*stamp_fn)(unsigned long long *, int);
+template <typename T> T *dev(const std::vector<T> &h) { T *d; hipMalloc(&d, h.size() * sizeof(T)); hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice); return d; }
+int main(int argc, char **argv) {
+    const int M = 32768, KD = 256, N = 128, G = M / 32, evalmode = argc > 2 ? atoi(argv[2]) : 0;
+    std::mt19937 rng(7); std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<float> z((size_t)M * KD), dm((size_t)G * KD), zp((size_t)M * N), W((size_t)KD * N), cst(5 * KD), sc(N), sh(N), mu(N), is(N);
+    std::vector<int> arg((size_t)G * KD);
+    for (auto &v : z) v = nd(rng); for (auto &v : dm) v = nd(rng) > 0.3f ? nd(rng) : 0.f; for (auto &v : zp) v = nd(rng); for (auto &v : W) v = 0.1f * nd(rng);
+    for (auto &v : arg) v = rng() % 32;
+    for (int c = 0; c < KD; ++c) { cst[c] = 0.5f + 0.01f * c; cst[KD + c] = 0.1f * nd(rng); cst[2 * KD + c] = 1.f + 0.1f * nd(rng); cst[3 * KD + c] = evalmode ? 0.f : 0.01f * nd(rng); cst[4 * KD + c] = evalmode ? 0.f : 0.01f * nd(rng); }
+    for (int c = 0; c < N; ++c) { sc[c] = 1.f + 0.1f * nd(rng); sh[c] = 0.1f * nd(rng); mu[c] = 0.1f * nd(rng); is[c] = 1.f + 0.1f * nd(rng); }
+    const int keep = argc > 3 ? atoi(argv[3]) : 0;   // which random parts survive the synthetic pattern: 1 W, 2 zp/sc/sh, 4 arg, 8 dm, 16 g
+    if (evalmode == 2) {   // synthetic pattern: dZ one-hot at row 5 of every neighbourhood, all-ones weights, mask all true
+        if (!(keep & 8)) for (auto &v : dm) v = 1.f;
+        if (!(keep & 4)) for (auto &v : arg) v = 5;
+        if (!(keep & 1)) for (auto &v : W) v = 1.f;
+        if (!(keep & 2)) for (auto &v : zp) v = 1.f;
+        for (int c = 0; c < KD; ++c) { if (!(keep & 16)) cst[c] = 1.f; cst[KD + c] = 0.f; cst[2 * KD + c] = 1.f; cst[3 * KD + c] = 0.f; cst[4 * KD + c] = 0.f; }
+        if (!(keep & 2)) for (int c = 0; c < N; ++c) { sc[c] = 1.f; sh[c] = 0.f; mu[c] = 0.f; is[c] = 1.f; }
+    }
+    float *dz = dev(z), *ddm = dev(dm), *dzp = dev(zp), *dW = dev(W), *dcst = dev(cst), *dsc = dev(sc), *dsh = dev(sh), *dmu = dev(mu), *dis = dev(is);
+    int *darg = dev(arg);
+    float *dC, *dws; double *dslab;
+    hipMalloc(&dC, (size_t)M * N * 4); hipMemset(dC, 0, (size_t)M * N * 4);
+    hipMalloc(&dws, (size_t)512 * KD * N * 4); hipMemset(dws, 0, (size_t)512 * KD * N * 4);
+    hipMalloc(&dslab, (size_t)512 * 2 * N * 8); hipMemset(dslab, 0, (size_t)512 * 2 * N * 8);
+    AOperand A; A.mode = A_DZ_POOL; A.a = ddm; A.arg = darg; A.K = 32; A.lda = KD; A.z = dz; A.cst = dcst; A.C = KD;
+    BOperand B; B.b = dW; B.ldb = N; B.rows = KD;
+    Epilogue E; E.mode = E_MASK_STATS; E.c = dC; E.ldc = N; E.slab = dslab; E.zp = dzp; E.scale = dsc; E.shift = dsh; E.mu = dmu; E.istd = dis; E.dwslab = dws; E.dw_ld = N;
+    int nslab = 0, dws_n = 0;
+    int rc = launch_gemm(A, B, M, N, KD, E, &nslab, 0, &dws_n);
+    hipDeviceSynchronize();
+    stamp_fn pnpp_debug_wsq_stamps = (stamp_fn)dlsym(RTLD_DEFAULT, "pnpp_debug_wsq_stamps");
+    if (pnpp_debug_wsq_stamps && getenv("STAMPS")) {
+        unsigned long long b[16];
+        pnpp_debug_wsq_stamps(b, 1);
+        for (int i = 0; i < 20; ++i) launch_gemm(A, B, M, N, KD, E, &nslab, 0, &dws_n);
+        pnpp_debug_wsq_stamps(b, 0);
+        const char *nm[10] = {"loop turn-around", "staging + fix-ups (+ wait for loads)", "barrier A", "dA product", "dW product + epilogue", "barrier B", "", "", "prologue", "tail"};
+        unsigned long long tot = 0; for (int i = 0; i < 10; ++i) tot += b[i];
+        for (int i = 0; i < 10; ++i) if (b[i]) printf("  %-40s %9.0f ticks/launch  %5.1f %%\n", nm[i], b[i] / 20.0, 100.0 * b[i] / tot);
+        printf("  total %.0f ticks per launch\n", tot / 20.0);
+    }
+    printf("rc %d nslab %d dw_slabs %d err %s\n", rc, nslab, dws_n, hipGetErrorString(hipGetLastError()));
+    std::vector<float> C((size_t)M * N), ws((size_t)dws_n * KD * N); std::vector<double> slab((size_t)nslab * 2 * N);
+    hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(ws.data(), dws, ws.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(slab.data(), dslab, slab.size() * 8, hipMemcpyDeviceToHost);
+    // reduce the partials so that the comparison does not depend on the worker layout
+    std::vector<double> dwsum((size_t)KD * N, 0.0), s((size_t)2 * N, 0.0);
+    for (int w = 0; w < dws_n; ++w) for (size_t i = 0; i < (size_t)KD * N; ++i) dwsum[i] += ws[(size_t)w * KD * N + i];
+    for (int w = 0; w < nslab; ++w) for (int i = 0; i < 2 * N; ++i) s[i] += slab[(size_t)w * 2 * N + i];
+    if (evalmode == 2 && keep == 0) {
+        for (int r = 0; r < 72; ++r) { printf("row %2d:", r); for (int c = 0; c < 132; c += 11) if (c < N) printf(" %6.1f", C[(size_t)r * N + c]); printf("\n"); }
+        printf("dW[0][0..3] %g %g %g %g  dW[100][70] %g\n", dwsum[0], dwsum[1], dwsum[2], dwsum[3], dwsum[100 * N + 70]);
+    }
+    FILE *f = fopen(argv[1], "wb"); fwrite(C.data(), 4, C.size(), f); fwrite(dwsum.data(), 8, dwsum.size(), f); fwrite(s.data(), 8, s.size(), f); fclose(f);
+    return 0;
+}

@@ -36,6 +36,23 @@ def tag_of(name, gx, gy, wg):
     if m:
         dw = ",dW" if m.group(6) == "true" else ""
         return f"gemm_ws_kernel<{m.group(1)},{m.group(2)},{m.group(3)},A{m.group(4)},E{m.group(5)}{dw}> {g}"
+    # the wave-private / folded kernels of round 3 (bench.py tags: gemm_wsp_kernel<K,A5>, gemm_wsq_kernel<K,A5>, gemm_wsx_kernel<K,wpc>,
+    # gemm_wsf_kernel<K,NT,Aa,Ee>, gemm_wsf0_kernel<Ee>)
+    m = re.search(r"gemm_wsp_kernel<(\d+), (\d+)>", name)
+    if m:
+        return f"gemm_wsp_kernel<{m.group(1)},A{m.group(2)}> {g}"
+    m = re.search(r"gemm_wsq_kernel<(\d+), \d+>", name)
+    if m:
+        return f"gemm_wsq_kernel<{m.group(1)},A5> {g}"
+    m = re.search(r"gemm_wsx_kernel<(\d+), (\d+)>", name)
+    if m:
+        return f"gemm_wsx_kernel<{m.group(1)},{m.group(2)}> {g}"
+    m = re.search(r"gemm_wsf_kernel<(\d+), (\d+), (\d+), (\d+)>", name)
+    if m:
+        return f"gemm_wsf_kernel<{m.group(1)},{m.group(2)},A{m.group(3)},E{m.group(4)}> {g}"
+    m = re.search(r"gemm_wsf0_kernel<(\d+)>", name)
+    if m:
+        return f"gemm_wsf0_kernel<E{m.group(1)}> {g}"
     m = re.search(r"gemm_smallm_kernel<(\d+), (\d+), (true|false)>", name)
     if m:
         return f"gemm_smallm_kernel<A{m.group(1)},E{m.group(2)},T{1 if m.group(3) == 'true' else 0}> {g}"
