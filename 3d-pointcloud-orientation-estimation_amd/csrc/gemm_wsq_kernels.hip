@@ -412,6 +412,323 @@ gemm_wsq_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, i
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Second form of the same launch: the weight panel in REGISTERS, two tile images, the images filled by LDS-DMA.
+// The stamps of gemm_wsq_kernel say where its time outside the matrix instructions goes: staging + fix-ups 8.5 % and the barriers
+// around them (a serial phase per tile in which no wave multiplies), a dA product at 82 % of the issue rate (two 16-byte LDS reads per
+// four MFMAs), prologue 9.6 %.
+//   * A lane's B operand of the dA product never changes -- column n0 + 32 wn + l31, reduction indices 8 t + 4 lh + {0..3}: 128 values --
+//     so it is loaded once into 128 registers (one wave per SIMD: 512 are there), scaled there; b W falls out of a lane-half exchange.
+//   * The 64 KB of LDS the panel occupied hold a SECOND tile image, and in the folded form the image is a COPY of Z: tile i + 1 goes
+//     global -> LDS directly (`buffer_load_dwordx4 ... lds`: a wave-instruction writes one 1-KiB row; no registers, no ds_write, no
+//     VALU), issued between the MFMAs of tile i's dA product; its fix-ups follow tile i's dW product; one barrier per tile.
+//     (A first version staged through registers: 128 + 64 operand registers pushed the panel into AGPRs, a v_accvgpr_read in front of
+//     every MFMA: 53.6 us against 49.5.)
+//   * The folded form is always valid here: a channel whose z-coefficient k = -istd c2 is (nearly) zero -- eval-mode statistics -- takes
+//     k' = 1e-18 instead: its one-hot term dm / k' times the panel's g k' is g dm to rounding, and the Z term it should not have is
+//     1e-18 g Z, far below the last bit of anything it is added to.
+template <int KD, int NOUT>
+__global__ void __launch_bounds__(256, 1)
+gemm_wsq2_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, int ncol, const Epilogue E) {
+    constexpr int Nout = NOUT;
+    constexpr int BM = 64, BN = 64, DP = KD + 4, CT = KD / 32, NT4 = KD / 8;
+    typedef __attribute__((address_space(3))) void lds_void;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Img0 = lds;                          // [2][BM][DP]: dZ images of two consecutive tiles
+    float *Tsc = lds + 2 * BM * DP, *Tb = Tsc + KD, *Tred = Tb + KD;   // scale[KD], b[KD], scratch [4][64] floats / doubles
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
+
+    const int nworkers = gridDim.x / ncol;
+    int col_blk = blockIdx.x % ncol, worker = blockIdx.x / ncol;
+    if ((nworkers & 7) == 0) {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        col_blk = i % ncol, worker = (i / ncol) * 8 + xcd;
+    }
+    const int n0 = col_blk * BN;
+    const int ntiles = M / BM;
+    int tile = worker;
+#ifdef PNPP_STAMPS
+    const bool st_on = blockIdx.x == 8 && wave == 0;
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
+
+    const int q4 = 4 * lane;
+    const __amdgpu_buffer_rsrc_t resZ = wsq_rsrc(A.z), resD = wsq_rsrc(A.a), resI = wsq_rsrc(A.arg), resP = wsq_rsrc(E.zp), resC = wsq_rsrc(E.c);
+    const __amdgpu_buffer_rsrc_t resNull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A.z), (short)0, 0, 0x00020000);
+    unsigned oq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) oq[g] = 4u * ((unsigned)(32 * wm + 4 * lh + 8 * g) * (unsigned)Nout + (unsigned)(n0 + 32 * wn + l31));
+    constexpr unsigned rowp = 4u * (unsigned)NOUT;
+
+    float zq[16], zn[16], vh[16];   // z_{l-1} of this / the next tile; this tile's outputs (stored during the next tile's dA product)
+    f32x4 gdm[2];                   // pooled gradient / arg-max rows of the tile whose image is being completed
+    i32x4q garg[2];
+    // row (wave + 4 i) of tile t -> its image: one wave-instruction, 64 lanes x 16 bytes = the row's 1 KiB
+    // Issued as an asm statement: through the builtin, hipcc orders every later ds_read behind the DMA with an `s_waitcnt vmcnt(0)` (it
+    // cannot see that the image being read and the image being filled are different halves of one LDS object) -- 170 cycles per row in
+    // the dA product.  An asm load is absent from hipcc's counter bookkeeping (its own waits can only become stricter: vmcnt counts in
+    // issue order); the kernel waits for its rows itself, once, behind the dW product.  M0 (the LDS destination) is written and
+    // restored inside the statement.  A descriptor with zero records (past the last tile) drops the load.
+    typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
+    auto dma_desc = [](const void *base, bool on) {
+        const unsigned long long a = (unsigned long long)base;
+        u32x4q d;
+        d[0] = (unsigned)a, d[1] = (unsigned)(a >> 32) & 0xffffu, d[2] = on ? 0xfffffffeu : 0u, d[3] = 0x00020000u;
+        return d;
+    };
+    const unsigned dma_voff = 16u * (unsigned)lane;
+    auto dma_row = [&](u32x4q dZ, float *img, int t, int i) {
+        const unsigned ldsa = (unsigned)(size_t)(lds_void *)(img + (wave + 4 * i) * DP);
+        const unsigned soff = (unsigned)t * (BM * KD * 4u) + (unsigned)(wave + 4 * i) * (KD * 4u);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(ldsa), "v"(dma_voff), "s"(dZ), "s"(soff)
+                     : "memory");
+    };
+    const u32x4q dmaZ = dma_desc(A.z, true), dmaNull = dma_desc(A.z, false);
+    auto fetch_p = [&](__amdgpu_buffer_rsrc_t rP, int t, int r) {
+        zn[r] = wsq_load1(rP, oq[r >> 2] + (unsigned)(r & 3) * rowp, (unsigned)t * (unsigned)BM * rowp);
+    };
+    auto fetch_g = [&](__amdgpu_buffer_rsrc_t rD, __amdgpu_buffer_rsrc_t rI, int t) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned so = (unsigned)(2 * t + h) * (KD * 4u);
+            gdm[h] = wsq_load4(rD, 4u * (unsigned)q4, so);
+            garg[h] = wsq_load4i(rI, 4u * (unsigned)q4, so);
+        }
+    };
+    // ---- everything the prologue reads is requested before its first wait ----
+    const bool have0 = tile < ntiles;
+    {
+        const __amdgpu_buffer_rsrc_t z0 = have0 ? resZ : resNull, d0 = have0 ? resD : resNull, i0 = have0 ? resI : resNull, p0 = have0 ? resP : resNull;
+        const int t0 = have0 ? tile : 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dma_row(have0 ? dmaZ : dmaNull, Img0, t0, i);
+        fetch_g(d0, i0, t0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fetch_p(p0, t0, r);
+    }
+    {   // per-channel tables: a' = g k', b (KD == 256 == blockDim: one channel per thread)
+        const float g = A.cst[tid], mu = A.cst[A.C + tid], is = A.cst[2 * A.C + tid], c1 = A.cst[3 * A.C + tid], c2 = A.cst[4 * A.C + tid];
+        float k = -is * c2;
+        k = fabsf(k) >= 1e-18f ? k : 1e-18f;
+        const float a = g * k;
+        Tsc[tid] = a, Tb[tid] = -g * c1 - a * mu;
+    }
+    f32x4 fxq;   // fix-up multipliers 1 / k' of this lane's column group
+    {
+        const float *p = A.cst + q4;
+        const float4 is = *reinterpret_cast<const float4 *>(p + 2 * A.C), c2 = *reinterpret_cast<const float4 *>(p + 4 * A.C);
+        const float k0 = -is.x * c2.x, k1 = -is.y * c2.y, k2 = -is.z * c2.z, k3 = -is.w * c2.w;
+        fxq[0] = 1.f / (fabsf(k0) >= 1e-18f ? k0 : 1e-18f), fxq[1] = 1.f / (fabsf(k1) >= 1e-18f ? k1 : 1e-18f);
+        fxq[2] = 1.f / (fabsf(k2) >= 1e-18f ? k2 : 1e-18f), fxq[3] = 1.f / (fabsf(k3) >= 1e-18f ? k3 : 1e-18f);
+    }
+    float e_sc, e_sh;
+    double e_mu, e_is;
+    {
+        const int col = n0 + 32 * wn + l31;
+        e_sc = E.scale[col], e_sh = E.shift[col], e_mu = (double)E.mu[col], e_is = (double)E.istd[col];
+    }
+    // this lane's B operand: W[8 t + 4 lh + u][n0 + 32 wn + l31] (coalesced over l31)
+    f32x4 pb[NT4];
+    {
+        const float *wc = W + (size_t)(4 * lh) * ldw + n0 + 32 * wn + l31;
+#pragma unroll
+        for (int t = 0; t < NT4; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pb[t][u] = wc[(size_t)(8 * t + u) * ldw];
+    }
+    // the fix-ups of a tile, by the wave whose rows they land on (that wave's DMA wrote them: its own counted wait orders them)
+    auto fixups = [&](float *img) {
+        float cur[2][4];
+        bool hit[2][4];
+        float *pp[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int a = garg[h][e];
+                hit[h][e] = (unsigned)a < 32u && (a & 3) == wave && gdm[h][e] != 0.f;
+                pp[h][e] = img + (32 * h + (hit[h][e] ? a : wave)) * DP + q4 + e;
+                cur[h][e] = *pp[h][e];
+            }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (hit[h][e]) *pp[h][e] = fmaf(fxq[e], gdm[h][e], cur[h][e]);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // image 0 has landed (and everything else of the prologue)
+    fixups(Img0);
+    {
+        const bool have1 = tile + nworkers < ntiles;
+        fetch_g(have1 ? resD : resNull, have1 ? resI : resNull, have1 ? tile + nworkers : 0);
+    }
+    __syncthreads();   // tables and image 0
+    // scale the panel in registers; b W of this lane's column from its half of the reduction + the other lane half's
+    float bw;
+    {
+        float bwp = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT4; ++t) {
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(Tsc + 8 * t + 4 * lh), bb = *reinterpret_cast<const f32x4 *>(Tb + 8 * t + 4 * lh);
+            bwp = fmaf(bb[0], pb[t][0], fmaf(bb[1], pb[t][1], fmaf(bb[2], pb[t][2], fmaf(bb[3], pb[t][3], bwp))));
+            pb[t][0] *= sc[0], pb[t][1] *= sc[1], pb[t][2] *= sc[2], pb[t][3] *= sc[3];
+        }
+        const float o = __shfl_xor(bwp, 32, 64);
+        bw = lh == 0 ? bwp + o : o + bwp;   // (lh = 0) + (lh = 1) in both halves
+    }
+
+    f32x16 dw[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw[i][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zq[r] = zn[r], vh[r] = 0.f;
+    double s1 = 0.0, s2 = 0.0, sa = 0.0;
+    __amdgpu_buffer_rsrc_t pC = resNull;   // the held outputs' destination (nothing is held before the first tile)
+    unsigned prev_off = 0;
+    int par = 0;
+    WSQ_STAMP(8)   // prologue
+    for (; tile < ntiles; tile += nworkers) {
+        WSQ_STAMP(0)
+        float *img = Img0 + par * (BM * DP), *imgn = Img0 + (par ^ 1) * (BM * DP);
+        const bool more1 = tile + nworkers < ntiles, more2 = tile + 2 * nworkers < ntiles;
+        const int t1 = more1 ? tile + nworkers : 0, t2 = more2 ? tile + 2 * nworkers : 0;
+        const __amdgpu_buffer_rsrc_t nZ = more1 ? resZ : resNull, nP = more1 ? resP : resNull, nD2 = more2 ? resD : resNull, nI2 = more2 ? resI : resNull;
+        const float *arow = img + (32 * wm + l31) * DP + 4 * lh;
+        const float *dcol = img + (32 * wm + 4 * lh) * DP + l31;
+        // ---- dA = X W': one 16-byte LDS read per four MFMAs, the B operand from registers.  Every memory operation of the tile is
+        // issued here: the previous tile's output stores, the next tile's z_{l-1}, the next tile's image rows (LDS-DMA) ----
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bw;
+        {
+            float4 fa[2];
+            fa[0] = *reinterpret_cast<const float4 *>(arow);
+#pragma unroll
+            for (int t = 0; t < NT4; ++t) {
+                if (!(WSQ_EXP & 128)) {
+                if (t < 16) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vh[t]), pC, (int)(oq[t >> 2] + (unsigned)(t & 3) * rowp), (int)prev_off, 0);
+                else fetch_p(nP, t1, t - 16);
+                }
+                if (!(WSQ_EXP & 64) && (t & 1) == 0) dma_row(more1 ? dmaZ : dmaNull, imgn, t1, t >> 1);
+                if (t + 1 < NT4) fa[(t + 1) & 1] = *reinterpret_cast<const float4 *>(arow + 8 * (t + 1));
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1].x, pb[t][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1].y, pb[t][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1].z, pb[t][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1].w, pb[t][3], acc, 0, 0, 0);
+            }
+        }
+        WSQ_STAMP(3)   // dA product
+        // ---- dW += X^T a with the epilogue (no memory operation in here) ----
+        {
+            float t1s = 0.f, t2s = 0.f, ta = 0.f;
+            float fd[2][CT];
+            auto ldw = [&](int buf, int s) {
+#pragma unroll
+                for (int i = 0; i < CT; ++i) fd[buf][i] = dcol[((s & 3) + 8 * (s >> 2)) * DP + 32 * i];
+            };
+            ldw(0, 0);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float z0 = zq[s];
+                const float a0 = fmaf(z0, e_sc, e_sh);
+                const float bact = fmaxf(a0, 0.f);
+                const float v = a0 > 0.f ? acc[s] : 0.f;
+                vh[s] = v;
+                t1s += v;
+                t2s = fmaf(v, z0, t2s);
+                ta += bact;
+                if (s + 1 < 16) ldw((s + 1) & 1, s + 1);
+#pragma unroll
+                for (int i = 0; i < CT; ++i) dw[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[s & 1][i], bact, dw[i], 0, 0, 0);
+            }
+            const double d1 = (double)t1s;
+            s1 += d1, s2 += e_is * ((double)t2s - e_mu * d1), sa += (double)ta;
+            pC = resC, prev_off = (unsigned)tile * (unsigned)BM * rowp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zq[r] = zn[r];
+        }
+        WSQ_STAMP(4)   // dW product + epilogue
+        // the next tile's rows were requested a whole dW product ago: this wait is for instructions long complete
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more1) {
+            fixups(imgn);
+            fetch_g(nD2, nI2, t2);
+        }
+        WSQ_STAMP(1)   // wait + fix-ups
+        __syncthreads();   // tile i's image is free, tile i + 1's is complete
+        WSQ_STAMP(5)   // barrier
+        par ^= 1;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)   // the last tile's outputs
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vh[r]), pC, (int)(oq[r >> 2] + (unsigned)(r & 3) * rowp), (int)prev_off, 0);
+
+    // ---- tail: as gemm_wsq_kernel (the images are free) ----
+    {
+        f32x4 *red = reinterpret_cast<f32x4 *>(Img0);   // [wn][dest wm][tile & 3][r4][lane]
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            if ((i >> 2) != wm) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 v;
+                    v[0] = dw[i][4 * r4], v[1] = dw[i][4 * r4 + 1], v[2] = dw[i][4 * r4 + 2], v[3] = dw[i][4 * r4 + 3];
+                    red[((((wn * 2 + (i >> 2)) * 4 + (i & 3)) * 4 + r4) * 64) + lane] = v;
+                }
+            }
+        }
+        double *ared = reinterpret_cast<double *>(Tred);   // [4 waves][32] doubles
+        {
+            const double a = sa + shfl_xor_f64(sa, 32);
+            if (lh == 0) ared[wave * 32 + l31] = a;
+        }
+        __syncthreads();
+        const float asum = (float)(ared[(0 * 2 + wn) * 32 + l31] + ared[(1 * 2 + wn) * 32 + l31]);
+        float *wb = E.dwslab + (size_t)worker * KD * E.dw_ld + n0 + 32 * wn + l31;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            if ((i >> 2) == wm) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 o = red[((((wn * 2 + wm) * 4 + (i & 3)) * 4 + r4) * 64) + lane];
+                    const int c0 = i * 32 + 8 * r4 + 4 * lh;
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(Tsc + c0), bb = *reinterpret_cast<const f32x4 *>(Tb + c0);
+                    float *op = wb + (size_t)c0 * E.dw_ld;
+                    op[0] = fmaf(sc[0], dw[i][4 * r4] + o[0], bb[0] * asum);
+                    op[(size_t)E.dw_ld] = fmaf(sc[1], dw[i][4 * r4 + 1] + o[1], bb[1] * asum);
+                    op[(size_t)2 * E.dw_ld] = fmaf(sc[2], dw[i][4 * r4 + 2] + o[2], bb[2] * asum);
+                    op[(size_t)3 * E.dw_ld] = fmaf(sc[3], dw[i][4 * r4 + 3] + o[3], bb[3] * asum);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double *dred = reinterpret_cast<double *>(Img0);   // [4 waves][2][32]
+    {
+        const double a = s1 + shfl_xor_f64(s1, 32), b = s2 + shfl_xor_f64(s2, 32);
+        if (lh == 0) dred[(wave * 2 + 0) * 32 + l31] = a, dred[(wave * 2 + 1) * 32 + l31] = b;
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+        const int which = tid / BN, cl = tid % BN, w2 = cl >> 5, c5 = cl & 31;
+        const double t = dred[((0 * 2 + w2) * 2 + which) * 32 + c5] + dred[((1 * 2 + w2) * 2 + which) * 32 + c5];
+        E.slab[((size_t)worker * 2 + which) * Nout + n0 + cl] = t;
+    }
+    WSQ_STAMP(9)   // tail
+#ifdef PNPP_STAMPS
+    if (st_on && lane == 0)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) g_wsq_stamps[i] += st_acc[i];
+#endif
+}
+
 // A/B switch: PNPP_NO_WSQ=1 keeps this launch on gemm_ws_kernel<256, ..., dW>
 static bool wsq_on() {
     static int cached = -1;
@@ -448,6 +765,21 @@ bool try_launch_wsq(const AOperand &A, const BOperand &B, int M, int Nout, int K
     constexpr size_t lds = ((size_t)64 * KD + 64 * (KD + 4) + 2 * KD + 64 + 2 * 4 * 64) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS budget");
     ProfScope ps(st, "gemm_wsq_kernel<%d,A%d> M=%d N=%d K=%d grid=%dx1", Kd, A.mode, M, Nout, Kd, workers * ncol);
+    // 1: weight panel in LDS, one image (default); 2: panel in registers, two images filled by LDS-DMA.  Form 2's wave timeline is 5 - 7 %
+    // shorter (stamps, alone and inside the step) and the launch takes the same time at every batch size (49.3 / 49.8 us at 32 clouds,
+    // 93.3 k / 93.4 k clouds/s at 512): DESIGN section 9
+    static const int form = getenv("PNPP_WSQ_FORM") ? atoi(getenv("PNPP_WSQ_FORM")) : 1;
+    if (form == 2) {
+        constexpr size_t lds2 = ((size_t)2 * 64 * (KD + 4) + 2 * KD + 2 * 4 * 64) * sizeof(float);
+        static_assert(lds2 <= 160 * 1024, "LDS budget");
+        auto kfn2 = gemm_wsq2_kernel<KD, 128>;
+        static bool granted2 = false;
+        if (!granted2) {
+            (void)hipFuncSetAttribute((const void *)kfn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            granted2 = true;
+        }
+        hipLaunchKernelGGL(kfn2, dim3(workers * ncol), dim3(256), lds2, st, A, B.b, B.ldb, M, ncol, E);
+    } else {
     auto kfn = gemm_wsq_kernel<KD, 128>;
     static bool granted = false;
     if (!granted) {
@@ -455,6 +787,7 @@ bool try_launch_wsq(const AOperand &A, const BOperand &B, int M, int Nout, int K
         granted = true;
     }
     hipLaunchKernelGGL(kfn, dim3(workers * ncol), dim3(256), lds, st, A, B.b, B.ldb, M, ncol, E);
+    }
     if (hipGetLastError() != hipSuccess) {
         set_error("gemm_wsq: launch failed");
         *rc = PNPP_ERR_LAUNCH;

@@ -649,6 +649,12 @@ gemm_wsf0_kernel(const Wsf0Args P) {
             p_g = P.scale0[tid], p_b = P.shift0[tid];
         }
     }
+    float wl[2][3];   // W_0 rows of this lane's two output columns (requested here: nothing they need is behind a barrier)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = j * 32 + l31;
+        wl[j][0] = P.W0[col * P.ldw0], wl[j][1] = P.W0[col * P.ldw0 + 1], wl[j][2] = P.W0[col * P.ldw0 + 2];
+    }
     constexpr int NWF = (KD / 4) * BN / 256;   // weight panel W_1[n][0 .. KD): consecutive lanes take consecutive 16-byte groups of a row
     f32x4 tw[NWF];
 #pragma unroll
@@ -699,9 +705,8 @@ gemm_wsf0_kernel(const Wsf0Args P) {
     for (int j = 0; j < 2; ++j) {
         const int col = j * 32 + l31;
         const float sc = Tc[col], sh = Tc[64 + col];
-        const float wx = P.W0[col * P.ldw0], wy = P.W0[col * P.ldw0 + 1], wz = P.W0[col * P.ldw0 + 2];
-        zb0[j] = lh ? sc * wy : sc * wx;
-        zb1[j] = lh ? sh : sc * wz;
+        zb0[j] = lh ? sc * wl[j][1] : sc * wl[j][0];
+        zb1[j] = lh ? sh : sc * wl[j][2];
     }
     double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
     const float *arow = As + l31 * DP + 4 * lh;
@@ -857,7 +862,8 @@ int launch_wsf0(const AOperand &geo, int M, const float *W0, int ldw0, const dou
     P.nbt0 = nbt0, P.momentum = momentum, P.eps = eps, P.mean0 = mean0, P.istd0 = istd0, P.scale0 = scale0, P.shift0 = shift0;
     P.W1 = W1, P.ldw1 = ldw1, P.z1 = E.c, P.slab = E.slab;
     const int nstrips = M / 32;
-    int workers = 512;
+    static const int wmax = getenv("PNPP_WSF0_WORKERS") ? atoi(getenv("PNPP_WSF0_WORKERS")) : 512;   // (256 measured: see DESIGN section 9)
+    int workers = wmax > 0 ? wmax : 512;
     if (workers * 4 > nstrips) workers = (nstrips + 3) / 4;
     if (nslab) *nslab = workers;
     constexpr size_t lds = ((size_t)64 * 64 + 4 * 32 * 68 + 128) * sizeof(float) + (64 + 16) * sizeof(double);

@@ -274,6 +274,16 @@ def test_sa2_shape_backward_of_the_256_channel_last_layer(oracle, training):
         assert l2(p.grad.cpu(), ref) < 1e-2, (k, l2(p.grad.cpu(), ref))
 
 
+def test_sa2_shape_second_form_of_the_kernel_in_a_child_process():
+    """gemm_wsq2_kernel (PNPP_WSQ_FORM=2: weight panel in registers, two tile images filled by LDS-DMA; measured equal, not the default)
+    stays under the same gate.  The switch is read once per process, so the test above runs again in a fresh child."""
+    import os, subprocess, sys
+    env = dict(os.environ, PNPP_WSQ_FORM="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-p", "no:cacheprovider", "-k",
+                        "test_sa2_shape_backward_of_the_256_channel_last_layer"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("B,N", [(4, 1024), (9, 640)])
 def test_sa1_backward_of_layers_0_and_1_from_the_coordinates(oracle, B, N):
     """Train-mode backward through the SA1 shape (D = 0, 32 neighbours, [64, 64, 128]) at 8192+ rows: layer 1's backward rebuilds

@@ -49,7 +49,11 @@ int main(int argc, char **argv) {
     if (pnpp_debug_wsq_stamps && getenv("STAMPS")) {
         unsigned long long b[16];
         pnpp_debug_wsq_stamps(b, 1);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, 0);
         for (int i = 0; i < 20; ++i) launch_gemm(A, B, M, N, KD, E, &nslab, 0, &dws_n);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1); printf("  20 launches back to back: %.2f us each\n", ms * 50.0);
         pnpp_debug_wsq_stamps(b, 0);
         const char *nm[10] = {"loop turn-around", "staging + fix-ups (+ wait for loads)", "barrier A", "dA product", "dW product + epilogue", "barrier B", "", "", "prologue", "tail"};
         unsigned long long tot = 0; for (int i = 0; i < 10; ++i) tot += b[i];
