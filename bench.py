@@ -211,6 +211,9 @@ def kernel_cost(tag: str):
     if tag.startswith("pool_bwd"):
         G, K, C = ints(r"G=(\d+) K=(\d+) C=(\d+)")
         return 0.0, 16.0 * G * C                           # dout, arg-max, the ONE z element it points at; write dm
+    if tag.startswith("knn_pair_kernel"):   # both grouped levels' searches in one launch; level 2 searches among level 1's S1 centres
+        B, S1, N1, k1, S2, N2, k2 = ints(r"B=(\d+) \| S=(\d+) N=(\d+) k=(\d+) \| S=(\d+) N=(\d+) k=(\d+)")
+        return 0.0, float(B) * (12.0 * N1 + 12.0 * S1 + 4.0 * S1 * k1 + 12.0 * N2 + 12.0 * S2 + 4.0 * S2 * k2)
     if tag.startswith("knn_kernel"):
         B, S, N, k = ints(r"B=(\d+) S=(\d+) N=(\d+) k=(\d+)")
         return 0.0, float(B) * (12.0 * N + 12.0 * S + 4.0 * S * k)

@@ -188,3 +188,30 @@ def _check_bench_line(d):
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - d["n_gpus"] * d["config"]["per_gpu_batch"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_every_launch_that_can_lead_the_step_has_a_cost_model():
+    """bench.py reports as dominant the largest launch it can price: every launch of the committed per-launch table above 10 us must
+    have a cost model (round 2's review: a kernel without one was skipped silently), and the models must be positive."""
+    import importlib.util, os, re, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_costs", os.path.join(root, "bench.py"))
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    seen = 0
+    for line in open(os.path.join(root, "profiles", "round3_kernel_table_events.txt")):
+        m = re.match(r"\s*([\d.]+) us/step\s+([\d.]+) x\s+([\d.]+) us\s+(.*)$", line)
+        if not m or float(m.group(3)) < 10.0:
+            continue
+        tag = m.group(4).strip()
+        if tag.startswith("vm_fc_head_kl_step_kernel"):   # one workgroup of float64 chains: latency, neither roof
+            continue
+        cost = bench.kernel_cost(tag)
+        assert cost is not None, tag
+        assert cost[0] >= 0.0 and cost[1] > 0.0, (tag, cost)
+        seen += 1
+    assert seen >= 15
