@@ -4,6 +4,8 @@
 // The matrix products run on the same fused MFMA GEMM / dW kernels as the set-abstraction layers;
 // the row/column normalisation passes here touch only M x N elements (M = batch), so they are plain
 // wave-per-row / lane-per-column kernels with float64 accumulation.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace pnpp {
@@ -153,6 +155,185 @@ fc_bwd_cols_kernel(const float *__restrict__ dy, const float *__restrict__ z, co
         } else if (db) {
             db[n] = (float)s1;
         }
+    }
+}
+
+// ---- backward of a head block with at most 32 rows, ONE launch (round 3) ------------------------------------------------------------
+// Linear -> BatchNorm1d (or none) -> ReLU -> Dropout, M <= 32 (models/pointnet_pp_vonMises.py:32-35 at batch 32): fc_bwd_cols_kernel
+// (dz and the normalisation's parameter gradients, 5 us) and fc_dx_dw_kernel (dx = dz W, dW = dz^T x, 6 - 7 us) only differ by WHO holds
+// dz -- and with 32 rows every workgroup that needs a column of dz can hold all of it: the column sums of BatchNorm-backward are sums
+// over the rows of ONE tile.  So dz is never written: the dW workgroups (32 columns n x 128 columns k) rebuild their 32 x 32 tile of it
+// from dy, z and the keep-mask, the dx workgroups (32 columns k, the reduction over n split over 16 waves) first rebuild ALL of dz --
+// 1024 / N threads per column, each with its share of the 32 rows in registers: three coalesced, L2-resident streams -- into an LDS image
+// that feeds their MFMA A operand.  (A first version formed the operand while loading it, lane = row: a 2 KB stride between the lanes of
+// every load, 26 - 30 us.)  The parameter gradients of the normalisation come from the dW workgroups of the first k block.
+// 5.0 + 5.6 and 5.7 + 7.5 us in four launches -> 9.5 and 11.1 us in two.
+#ifndef FCF_EXP   // timing experiments (wrong results): 1 no constants pass in the dx tiles, 2 no reduction loop there, 4 no column pass in the dW blocks
+#define FCF_EXP 0
+#endif
+struct FcFusedArgs {
+    const float *dy, *z;
+    const uint8_t *mask;
+    float drop_scale;
+    int relu, bn, training;
+    const float *scale, *shift, *mean, *istd, *bias;
+    const float *w, *x;
+    int M, N, K;
+    float *dx, *dw, *dnw, *dnb, *db;
+    int g1, gx2;
+};
+
+__device__ __forceinline__ float fc_masked_g(const FcFusedArgs &P, size_t i, float zz, float sc, float sh) {
+    float g = P.dy[i];
+    if (P.mask) g = P.mask[i] ? g * P.drop_scale : 0.f;
+    if (P.relu && !(fmaf(zz, sc, sh) > 0.f)) g = 0.f;
+    return g;
+}
+
+template <int TPC>   // threads per column of dz in the dx tiles' first pass (1024 / TPC columns at a time, 32 / TPC rows per thread)
+__global__ void __launch_bounds__(1024) fc_bwd_fused_kernel(const FcFusedArgs P) {
+    extern __shared__ __attribute__((aligned(16))) float fl[];
+    const int tid = threadIdx.x, M = P.M, N = P.N, K = P.K;
+    if ((int)blockIdx.x >= P.g1) {
+        // ---- dW block: columns n0 .. n0 + 32 of dz (all rows), columns k0 .. k0 + 128 of x ----
+        float (*dzs)[32] = reinterpret_cast<float (*)[32]>(fl);                    // [32][32]
+        float (*xs)[128] = reinterpret_cast<float (*)[128]>(fl + 32 * 32);         // [32][128]
+        float (*gs)[32] = reinterpret_cast<float (*)[32]>(fl + 32 * 32 + 32 * 128);   // masked upstream gradient
+        float (*zs)[32] = gs + 32;                                                  // xhat (bn) of the same elements
+        const int bx = ((int)blockIdx.x - P.g1) % P.gx2, by = ((int)blockIdx.x - P.g1) / P.gx2;
+        const int k0 = bx * 128, n0 = by * 32;
+        {
+            const int m = tid >> 5, n = tid & 31, nn = n0 + n;
+            float g = 0.f, xh = 0.f;
+            if (m < M && nn < N) {
+                const size_t i = (size_t)m * N + nn;
+                const float zz = P.z[i];
+                const float sc = P.bn ? P.scale[nn] : 1.f, sh = P.bn ? P.shift[nn] : P.bias[nn];
+                g = fc_masked_g(P, i, zz, sc, sh);
+                if (P.bn) xh = (zz - P.mean[nn]) * P.istd[nn];
+            }
+            gs[m][n] = g, zs[m][n] = xh;
+        }
+        for (int f = tid; f < 32 * 128; f += 1024) {
+            const int m = f >> 7, k = f & 127;
+            xs[m][k] = (m < M && k0 + k < K) ? P.x[(size_t)m * K + k0 + k] : 0.f;
+        }
+        __syncthreads();
+        if (tid < 32 && !(FCF_EXP & 4)) {   // one thread per column: the sums over the rows, in row order
+            const int nn = n0 + tid;
+            double s1 = 0.0, s2 = 0.0;
+            for (int m = 0; m < 32; ++m) s1 += (double)gs[m][tid], s2 += (double)gs[m][tid] * (double)zs[m][tid];
+            const float sc = (P.bn && nn < N) ? P.scale[nn] : 1.f;
+            const float c1 = (P.bn && P.training) ? (float)(s1 / (double)M) : 0.f, c2 = (P.bn && P.training) ? (float)(s2 / (double)M) : 0.f;
+            for (int m = 0; m < 32; ++m) dzs[m][tid] = (m < M && nn < N) ? (P.bn ? sc * (gs[m][tid] - c1 - zs[m][tid] * c2) : gs[m][tid]) : 0.f;
+            if (bx == 0 && nn < N) {
+                if (P.bn) {
+                    if (P.dnw) P.dnw[nn] = (float)s2;
+                    if (P.dnb) P.dnb[nn] = (float)s1;
+                    // a bias in front of a train-mode BatchNorm has exactly zero gradient; with running statistics d(bias) = scale sum g
+                    if (P.db) P.db[nn] = P.training ? 0.f : (float)((double)sc * s1);
+                } else if (P.db) {
+                    P.db[nn] = (float)s1;
+                }
+            }
+        }
+        __syncthreads();
+        const int kl = tid & 127, nh = tid >> 7;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int m = 0; m < 32; ++m) {
+            const float xv = xs[m][kl];
+            const float4 d = *reinterpret_cast<const float4 *>(&dzs[m][4 * nh]);
+            acc[0] = fmaf(d.x, xv, acc[0]), acc[1] = fmaf(d.y, xv, acc[1]);
+            acc[2] = fmaf(d.z, xv, acc[2]), acc[3] = fmaf(d.w, xv, acc[3]);
+        }
+        if (k0 + kl < K)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + 4 * nh + j;
+                if (n < N) P.dw[(size_t)n * K + k0 + kl] = acc[j];
+            }
+        return;
+    }
+    // ---- dx tile: columns k0 .. k0 + 32 of dx = dz W.  Pass 1: thread n holds column n of all 32 rows (three coalesced streams,
+    // eight rows in flight at a time), sums it, and writes its dz column to an LDS image [32][N + 1]; pass 2: wave w takes the
+    // reduction indices n = 2 w + 32 j (+ lane half) from that image, W from global memory (coalesced over the 32 output columns) ----
+    const int DP = N + 1;
+    float *dzs = fl;                                 // [32][N + 1]; afterwards [16 waves][16 registers][64 lanes] partial tiles
+    const int k0 = (int)blockIdx.x * 32;
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const bool colok = k0 + l31 < K;
+    const float *wcol = P.w + k0 + (colok ? l31 : 0);
+    constexpr int CPP = 1024 / TPC, R = 32 / TPC;    // columns per pass, rows per thread
+    double *ps = reinterpret_cast<double *>(fl + ((32 * DP + 1) & ~1));   // [TPC][2][CPP] partial sums of a pass
+    for (int c0 = 0; c0 < ((FCF_EXP & 1) ? 0 : N); c0 += CPP) {
+        const int cl = tid % CPP, rg = tid / CPP, n = c0 + cl, nc = min(n, N - 1);
+        const float sc = P.bn ? P.scale[nc] : 1.f, sh = P.bn ? P.shift[nc] : P.bias[nc];
+        const float mu = P.bn ? P.mean[nc] : 0.f, is = P.bn ? P.istd[nc] : 0.f;
+        float g[R], xh[R];
+#pragma unroll
+        for (int m0 = 0; m0 < R; m0 += 8) {
+            float zr[8], gr[8];
+            unsigned char kr[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned i = (unsigned)min(rg * R + m0 + j, M - 1) * (unsigned)N + (unsigned)nc;
+                zr[j] = P.z[i], gr[j] = P.dy[i], kr[j] = P.mask ? P.mask[i] : (unsigned char)1;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float gg = kr[j] ? gr[j] * (P.mask ? P.drop_scale : 1.f) : 0.f;
+                if (P.relu && !(fmaf(zr[j], sc, sh) > 0.f)) gg = 0.f;
+                if (rg * R + m0 + j >= M) gg = 0.f;
+                g[m0 + j] = gg, xh[m0 + j] = (zr[j] - mu) * is;
+            }
+        }
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int m = 0; m < R; ++m) s1 += (double)g[m], s2 += (double)g[m] * (double)xh[m];
+        if (TPC > 1) {   // the row groups of a column, in row order
+            ps[(rg * 2 + 0) * CPP + cl] = s1, ps[(rg * 2 + 1) * CPP + cl] = s2;
+            __syncthreads();
+            s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < TPC; ++q) s1 += ps[(q * 2 + 0) * CPP + cl], s2 += ps[(q * 2 + 1) * CPP + cl];
+            __syncthreads();
+        }
+        const float c1 = (P.bn && P.training) ? (float)(s1 / (double)M) : 0.f, c2 = (P.bn && P.training) ? (float)(s2 / (double)M) : 0.f;
+        if (n < N)
+#pragma unroll
+            for (int m = 0; m < R; ++m) dzs[(rg * R + m) * DP + n] = rg * R + m < M ? (P.bn ? sc * (g[m] - c1 - xh[m] * c2) : g[m]) : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float *arow = dzs + l31 * DP + lh;
+    // (all sixteen steps' weights requested at the top of the kernel, ahead of pass 1: 11.1 -> 15.0 us -- sixteen more live registers
+    // spill at the 128 a 1,024-thread workgroup leaves a lane)
+    for (int nb0 = 2 * wave; nb0 < ((FCF_EXP & 2) ? 0 : N); nb0 += 32 * 8) {   // eight steps' weights requested together
+        float wr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wr[j] = wcol[(size_t)min(nb0 + 32 * j + lh, N - 1) * K];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = nb0 + 32 * j + lh;
+            const float a = n < N ? arow[min(nb0 + 32 * j, N - 2)] : 0.f, b = (colok && n < N) ? wr[j] : 0.f;
+            if (nb0 + 32 * j < N) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);   // (uniform)
+        }
+    }
+    __syncthreads();   // every wave is done with the image: the partial tiles take its place
+    float *red = fl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    {   // one thread per output element: the sixteen partial tiles in wave order
+        const int r = tid >> 6, ln = tid & 63;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[(w * 16 + r) * 64 + ln];
+        const int row = (r & 3) + 4 * (ln >> 5) + 8 * (r >> 2), col = k0 + (ln & 31);
+        if (row < M && col < K) P.dx[(size_t)row * K + col] = t;
     }
 }
 
@@ -502,6 +683,38 @@ static int fc_backward_impl(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, hi
         PNPP_TRY(launch_slab_reduce(sc.gbuf, chunks, 1, d->N, d->N, -1, a->db, d->N, st));
     } else {
         const int bn = d->norm == PNPP_NORM_BATCH;
+        // head blocks of at most 32 rows with a gradient to pass on: dz is never written (fc_bwd_fused_kernel); PNPP_NO_FC_FUSED=1 keeps
+        // the two launches
+        static const bool fused_on = !(getenv("PNPP_NO_FC_FUSED") && atoi(getenv("PNPP_NO_FC_FUSED")) != 0);
+        if (fused_on && a->dx && d->M <= 32 && d->N >= 256 && d->N % 2 == 0 && !(bn && d->training && stats_sync_on())) {
+            FcFusedArgs P;
+            P.dy = a->dy, P.z = sv.z, P.mask = a->mask, P.drop_scale = d->drop_scale, P.relu = d->relu, P.bn = bn, P.training = d->training;
+            P.scale = sv.scale, P.shift = sv.shift, P.mean = sv.mean, P.istd = sv.istd, P.bias = a->b;
+            P.w = a->w, P.x = a->x, P.M = d->M, P.N = d->N, P.K = d->K;
+            P.dx = a->dx, P.dw = a->dw, P.dnw = a->dnw, P.dnb = a->dnb, P.db = a->db;
+            P.g1 = cdiv(d->K, 32), P.gx2 = cdiv(d->K, 128);
+            const int gy2 = cdiv(d->N, 32);
+            const int tpc = d->N <= 256 ? 4 : d->N <= 512 ? 2 : 1;
+            const size_t img = (size_t)32 * (d->N + 1) + 2 + (size_t)tpc * 2 * (1024 / tpc) * 2, part = (size_t)16 * 16 * 64;
+            const size_t lds_dx = (img > part ? img : part) * sizeof(float), lds_dw = (size_t)(32 * 32 + 32 * 128 + 2 * 32 * 32) * sizeof(float);
+            const size_t lds = lds_dx > lds_dw ? lds_dx : lds_dw;
+            if (lds <= 160 * 1024) {
+                static size_t granted[3] = {0, 0, 0};
+                auto go = [&](auto kfn, int slot) {
+                    if (lds > 48 * 1024 && lds > granted[slot]) {
+                        (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                        granted[slot] = lds;
+                    }
+                    hipLaunchKernelGGL(kfn, dim3(P.g1 + P.gx2 * gy2), dim3(1024), lds, st, P);
+                };
+                ProfScope ps(st, "fc_bwd_fused_kernel M=%d N=%d K=%d grid=%d+%d", d->M, d->N, d->K, P.g1, P.gx2 * gy2);
+                if (tpc == 4) go(fc_bwd_fused_kernel<4>, 0);
+                else if (tpc == 2) go(fc_bwd_fused_kernel<2>, 1);
+                else go(fc_bwd_fused_kernel<1>, 2);
+                PNPP_CHECK_LAUNCH("fc_backward(fused)");
+                return PNPP_OK;
+            }
+        }
         if (bn && d->training && stats_sync_on()) {   // SyncBN: sums -> exchange over the ranks -> apply
             hipLaunchKernelGGL(fc_bwd_cols_kernel, dim3(cdiv(d->N, 32)), dim3(256), 0, st, a->dy, sv.z, a->mask, d->drop_scale,
                                d->relu, bn, sv.scale, sv.shift, sv.mean, sv.istd, a->b, d->M, d->N, d->training, sc.dz, a->dnw,
