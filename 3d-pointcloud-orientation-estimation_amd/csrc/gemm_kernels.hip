@@ -2846,7 +2846,31 @@ struct BnFinalizeBwdArgs {
     // SyncBN: `slab` holds the sums over ALL ranks (one slab), *count_dev their row count; the parameter gradients stay this
     // rank's own sums (`local`: [2][C]) -- the gradient all-reduce adds the ranks up, as it does for every other parameter
     const double *count_dev = nullptr, *local = nullptr;
+    // Pooled source (levels with few groups: the group_all level has one per cloud): the column sums are taken straight from the pooled
+    // gradient -- sum over the G groups of d = ReLU'(scale zsel + shift) dout and of d xhat(zsel) -- instead of from slabs a pool_bwd
+    // launch would have written; the dZ job rebuilds d the same way.  No pool_bwd launch, no dm tensor.
+    const float *p_dout = nullptr, *p_zsel = nullptr, *p_scale = nullptr, *p_shift = nullptr;
+    int p_G = 0;
 };
+
+// column sums of one channel from the pooled source, groups in order
+__device__ __forceinline__ void pooled_column_sums(const BnFinalizeBwdArgs &F, int c, double &s1, double &s2) {
+    const float sc = F.p_scale[c], sh = F.p_shift[c], mu = F.mean[c], is = F.istd[c];
+    s1 = 0.0, s2 = 0.0;
+    for (int g0 = 0; g0 < F.p_G; g0 += 8) {   // eight groups' two streams in flight at a time (all 32 at once measured the same)
+        float za[8], dv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const size_t gi = (size_t)min(g0 + j, F.p_G - 1) * F.C + c;
+            za[j] = F.p_zsel[gi], dv[j] = F.p_dout[gi];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = (g0 + j < F.p_G && fmaf(za[j], sc, sh) > 0.f) ? dv[j] : 0.f;
+            s1 += (double)d, s2 += (double)d * (double)((za[j] - mu) * is);
+        }
+    }
+}
 
 __device__ __forceinline__ void bn_finalize_bwd_block(const BnFinalizeBwdArgs &F, int bid) {
     __shared__ double red[32][2][FIN_COLS];
@@ -2860,8 +2884,13 @@ __device__ __forceinline__ void bn_finalize_bwd_block(const BnFinalizeBwdArgs &F
         p_is = F.istd[c], p_mu = F.mean[c];
     }
     double s1, s2;
-    slab_column_sums(F.slab, F.nslab, C, c, s1, s2, red);
-    if (!owner) return;
+    if (F.p_dout) {
+        if (!owner) return;
+        pooled_column_sums(F, c, s1, s2);
+    } else {
+        slab_column_sums(F.slab, F.nslab, C, c, s1, s2, red);
+        if (!owner) return;
+    }
     const double count = F.count_dev ? *F.count_dev : F.count;
     float *cst = F.cst;
     cst[c] = g * p_is;
@@ -2898,7 +2927,10 @@ __device__ __forceinline__ void dz_fused_block(const BnFinalizeBwdArgs &F, const
     {   // column sums of the slabs: 64 columns x 4 slab lanes, every load of a lane in flight at once, lanes combined in order
         const int cl = threadIdx.x & 63, q = threadIdx.x >> 6, c = min(c0 + cl, C - 1);
         double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
-        int sidx = q;
+        if (F.p_dout) {   // pooled source: lane 0 of the four takes the whole column (a few dozen groups)
+            if (q == 0) pooled_column_sums(F, c, a1, a2);
+        }
+        int sidx = F.p_dout ? F.nslab : q;
 #pragma unroll 4
         for (; sidx + 4 < F.nslab; sidx += 8) {
             a1 += F.slab[((size_t)sidx * 2 + 0) * C + c];
@@ -2939,7 +2971,13 @@ __device__ __forceinline__ void dz_fused_block(const BnFinalizeBwdArgs &F, const
         float4 dy;
         if (J.arg) {
             const int grp = row / J.K, kk = row - grp * J.K;
-            const float4 dm = *reinterpret_cast<const float4 *>(J.dy + (size_t)grp * C + c);
+            float4 dm = *reinterpret_cast<const float4 *>(J.dy + (size_t)grp * C + c);
+            if (F.p_dout) {   // J.dy is dout itself: d = ReLU'(scale zsel + shift) dout, as pool_bwd_kernel writes it
+                const float4 zs = *reinterpret_cast<const float4 *>(F.p_zsel + (size_t)grp * C + c);
+                const float4 ps = *reinterpret_cast<const float4 *>(F.p_scale + c), ph = *reinterpret_cast<const float4 *>(F.p_shift + c);
+                dm.x = fmaf(zs.x, ps.x, ph.x) > 0.f ? dm.x : 0.f, dm.y = fmaf(zs.y, ps.y, ph.y) > 0.f ? dm.y : 0.f;
+                dm.z = fmaf(zs.z, ps.z, ph.z) > 0.f ? dm.z : 0.f, dm.w = fmaf(zs.w, ps.w, ph.w) > 0.f ? dm.w : 0.f;
+            }
             const int4 ia = *reinterpret_cast<const int4 *>(J.arg + (size_t)grp * C + c);
             dy = make_float4(kk == ia.x ? dm.x : 0.f, kk == ia.y ? dm.y : 0.f, kk == ia.z ? dm.z : 0.f, kk == ia.w ? dm.w : 0.f);
         } else {
@@ -3024,11 +3062,13 @@ static DzJob make_dz_job(const AOperand *dz, int M, int C, float *out) {
 
 int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, int training, const float *gamma,
                            const float *mean, const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias,
-                           hipStream_t st, const AOperand *dz, int M, float *dz_out, const double *count_dev, const double *local) {
-    const BnFinalizeBwdArgs F{slab, nslab, C, count, training, gamma, mean, istd, cst, dgamma, dbeta, dbias, count_dev, local};
+                           hipStream_t st, const AOperand *dz, int M, float *dz_out, const double *count_dev, const double *local,
+                           const PooledSource *pooled) {
+    BnFinalizeBwdArgs F{slab, nslab, C, count, training, gamma, mean, istd, cst, dgamma, dbeta, dbias, count_dev, local};
+    if (pooled) F.p_dout = pooled->dout, F.p_zsel = pooled->zsel, F.p_scale = pooled->scale, F.p_shift = pooled->shift, F.p_G = pooled->G;
     const DzJob J = make_dz_job(dz, M, C, dz_out);
     const int nfin = cdiv(C, FIN_COLS), ndz = dz_job_blocks(J, C);
-    ProfScope ps(st, "bn_finalize_bwd_kernel C=%d%s", C, ndz ? " +dZ" : "");
+    ProfScope ps(st, "bn_finalize_bwd_kernel C=%d%s%s", C, ndz ? " +dZ" : "", pooled ? " +pool" : "");
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(nfin + ndz), dim3(256), 0, st, F, nfin, J);
     PNPP_CHECK_LAUNCH("bn_finalize_bwd");
     return PNPP_OK;

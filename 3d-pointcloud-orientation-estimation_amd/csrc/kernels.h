@@ -180,10 +180,16 @@ int launch_bn_finalize_fwd(const double *slab, int nslab, int C, double count, c
                            float *origin_a = nullptr, float *origin_b = nullptr, int norigin = 0);
 // true when launch_gemm will honour Epilogue::pool_ext for this shape (the weights-stationary kernel, 32-row neighbourhoods)
 bool gemm_pools_in_epilogue(const AOperand &A, int M, int Nout, int Kd, int nsample);
+// pooled (optional): levels with few groups take the column sums (and, in the dZ job, the masked pooled gradient) straight from
+// dout / zsel -- the pool_bwd launch and its dm tensor are not needed then (dz->a must be dout)
+struct PooledSource {
+    const float *dout = nullptr, *zsel = nullptr, *scale = nullptr, *shift = nullptr;
+    int G = 0;
+};
 int launch_bn_finalize_bwd(const double *slab, int nslab, int C, double count, int training, const float *gamma,
                            const float *mean, const float *istd, float *cst, float *dgamma, float *dbeta, float *dbias,
                            hipStream_t st, const AOperand *dz = nullptr, int M = 0, float *dz_out = nullptr,
-                           const double *count_dev = nullptr, const double *local = nullptr);
+                           const double *count_dev = nullptr, const double *local = nullptr, const PooledSource *pooled = nullptr);
 
 // bn_finalize_bwd of one layer and the weight-gradient slab reduction of the layer above it, in one launch
 // dz / M / dz_out (optional): also materialise dZ = BN-backward(dz operand) of the layer being finalised (small-M levels)

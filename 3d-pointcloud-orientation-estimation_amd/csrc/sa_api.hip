@@ -392,8 +392,14 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
 
     const int Lm = d->L - 1;
     int cur = 0, nslab = 0, nslab_next = 0;
-    PNPP_TRY(launch_pool_bwd(a->dout, sv.arg, sv.z[Lm], sv.scale[Lm], sv.shift[Lm], sv.mean[Lm], sv.istd[Lm], g.G, d->K,
-                             d->C[Lm], sc.dm, sc.slab, &nslab, st, sa_keeps_zmax(d, g) ? sv.zmax : nullptr));
+    // a level with few groups (group_all: one per cloud) whose dZ is materialised anyway: the finalisation launch takes the pooled
+    // gradient as it is -- no pool_bwd launch, no dm tensor (PNPP_NO_POOL_BWD_FUSION=1 keeps the launch)
+    static const bool pool_bwd_fused = !(getenv("PNPP_NO_POOL_BWD_FUSION") && atoi(getenv("PNPP_NO_POOL_BWD_FUSION")) != 0);
+    const bool pooled_src = pool_bwd_fused && g.M <= kSmallM && g.G <= 64 && sa_keeps_zmax(d, g) && (d->C[Lm] & 3) == 0 &&
+                            !(d->training && stats_sync_on());
+    if (!pooled_src)
+        PNPP_TRY(launch_pool_bwd(a->dout, sv.arg, sv.z[Lm], sv.scale[Lm], sv.shift[Lm], sv.mean[Lm], sv.istd[Lm], g.G, d->K,
+                                 d->C[Lm], sc.dm, sc.slab, &nslab, st, sa_keeps_zmax(d, g) ? sv.zmax : nullptr));
     // sc.cst holds the BatchNorm-backward constants of the layer being processed; layer l-1's are produced (together with
     // layer l's weight-gradient reduction) by the post-GEMM launch that ends iteration l
     // small-M levels materialise dZ once per layer; that pass rides in the launch that finalises the layer's BatchNorm sums
@@ -410,8 +416,14 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
         dz.C = d->C[l];
         return dz;
     };
-    const AOperand dz_top = dz_operand(Lm, 0);
-    {
+    AOperand dz_top = dz_operand(Lm, 0);
+    if (pooled_src) {
+        dz_top.a = a->dout;   // the dZ job masks it itself
+        PooledSource ps;
+        ps.dout = a->dout, ps.zsel = sv.zmax, ps.scale = sv.scale[Lm], ps.shift = sv.shift[Lm], ps.G = g.G;
+        PNPP_TRY(launch_bn_finalize_bwd(nullptr, 0, d->C[Lm], (double)g.M, d->training, a->bn_w[Lm], sv.mean[Lm], sv.istd[Lm], sc.cst,
+                                        a->d_bn_w[Lm], a->d_bn_b[Lm], a->d_conv_b[Lm], st, &dz_top, g.M, sc.dzbuf, nullptr, nullptr, &ps));
+    } else {
         StatsView V;
         V.slab = sc.slab, V.nslab = nslab;
         if (d->training) PNPP_TRY(stats_exchange(sc.slab, nslab, d->C[Lm], (double)g.M, st, &V));
