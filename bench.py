@@ -202,6 +202,9 @@ def kernel_cost(tag: str):
         flops = 2.0 * M * (n1 * k1 + n2 * k2)
         byts = 4.0 * (M * k1 + k1 * n1 + M * n1 * (2 if e == 2 else 1) + M * k2 + n2 * k2)   # dZ, W, dA (+ its ReLU-mask operand), a2, dW once
         return flops, byts
+    if tag.startswith("fc_bwd_fused_kernel"):   # dz rebuilt from dy, z and the keep-mask; dx = dz W and dW = dz^T x
+        M, N, K = ints(r"M=(\d+) N=(\d+) K=(\d+)")
+        return 4.0 * M * N * K, 9.0 * M * N + 4.0 * (2.0 * N * K + 2.0 * M * K)
     if tag.startswith("fc_dx_dw_kernel"):
         M, N, K = ints(r"M=(\d+) N=(\d+) K=(\d+)")
         return 4.0 * M * N * K, 4.0 * (M * N + 2.0 * N * K + 2.0 * M * K)
