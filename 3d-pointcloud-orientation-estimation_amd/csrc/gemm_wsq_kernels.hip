@@ -89,6 +89,7 @@ gemm_wsq_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, i
     const bool st_on = blockIdx.x == 8 && wave == 0;
     unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_real0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: shader cycles / real time = the clock held
 #endif
 
     // staging map of a tile: column group lane (16 bytes), rows wave + 4 i -- a row's stager is the wave (row mod 4)
@@ -406,6 +407,7 @@ gemm_wsq_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, i
     }
     WSQ_STAMP(9)   // tail
 #ifdef PNPP_STAMPS
+    st_acc[6] = __builtin_amdgcn_s_memrealtime() - st_real0;
     if (st_on && lane == 0)
 #pragma unroll
         for (int i = 0; i < 10; ++i) g_wsq_stamps[i] += st_acc[i];
@@ -452,6 +454,7 @@ gemm_wsq2_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
     const bool st_on = blockIdx.x == 8 && wave == 0;
     unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_real0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: shader cycles / real time = the clock held
 #endif
 
     const int q4 = 4 * lane;
@@ -723,6 +726,7 @@ gemm_wsq2_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
     }
     WSQ_STAMP(9)   // tail
 #ifdef PNPP_STAMPS
+    st_acc[6] = __builtin_amdgcn_s_memrealtime() - st_real0;
     if (st_on && lane == 0)
 #pragma unroll
         for (int i = 0; i < 10; ++i) g_wsq_stamps[i] += st_acc[i];
@@ -765,9 +769,9 @@ bool try_launch_wsq(const AOperand &A, const BOperand &B, int M, int Nout, int K
     constexpr size_t lds = ((size_t)64 * KD + 64 * (KD + 4) + 2 * KD + 64 + 2 * 4 * 64) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS budget");
     ProfScope ps(st, "gemm_wsq_kernel<%d,A%d> M=%d N=%d K=%d grid=%dx1", Kd, A.mode, M, Nout, Kd, workers * ncol);
-    // 1: weight panel in LDS, one image (default); 2: panel in registers, two images filled by LDS-DMA.  Form 2's wave timeline is 5 - 7 %
-    // shorter (stamps, alone and inside the step) and the launch takes the same time at every batch size (49.3 / 49.8 us at 32 clouds,
-    // 93.3 k / 93.4 k clouds/s at 512): DESIGN section 9
+    // 1: weight panel in LDS, one image (default); 2: panel in registers, two images filled by LDS-DMA.  Form 2's stamped wave ends
+    // 1.6 us earlier inside the step (5 - 7 % fewer shader cycles at a 1 - 2 % lower clock) and the launch takes the same time at every
+    // batch size (49.3 / 49.8 us at 32 clouds, 93.3 k / 93.4 k clouds/s at 512): DESIGN section 9
     static const int form = getenv("PNPP_WSQ_FORM") ? atoi(getenv("PNPP_WSQ_FORM")) : 1;
     if (form == 2) {
         constexpr size_t lds2 = ((size_t)2 * 64 * (KD + 4) + 2 * KD + 2 * 4 * 64) * sizeof(float);

@@ -56,8 +56,9 @@ int main(int argc, char **argv) {
         float ms = 0; hipEventElapsedTime(&ms, e0, e1); printf("  20 launches back to back: %.2f us each\n", ms * 50.0);
         pnpp_debug_wsq_stamps(b, 0);
         const char *nm[10] = {"loop turn-around", "staging + fix-ups (+ wait for loads)", "barrier A", "dA product", "dW product + epilogue", "barrier B", "", "", "prologue", "tail"};
-        unsigned long long tot = 0; for (int i = 0; i < 10; ++i) tot += b[i];
-        for (int i = 0; i < 10; ++i) if (b[i]) printf("  %-40s %9.0f ticks/launch  %5.1f %%\n", nm[i], b[i] / 20.0, 100.0 * b[i] / tot);
+        unsigned long long tot = 0; for (int i = 0; i < 10; ++i) if (i != 6) tot += b[i];
+        if (b[6]) printf("  shader cycles %.0f in %.2f us of real time per launch: %.3f GHz\n", tot / 20.0, b[6] / 20.0 / 100.0, (double)tot / (b[6] * 10.0));
+        for (int i = 0; i < 10; ++i) if (b[i] && i != 6) printf("  %-40s %9.0f ticks/launch  %5.1f %%\n", nm[i], b[i] / 20.0, 100.0 * b[i] / tot);
         printf("  total %.0f ticks per launch\n", tot / 20.0);
     }
     printf("rc %d nslab %d dw_slabs %d err %s\n", rc, nslab, dws_n, hipGetErrorString(hipGetLastError()));

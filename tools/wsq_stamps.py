@@ -23,8 +23,9 @@ N = 20
 for _ in range(N): step()
 buf = (ctypes.c_ulonglong * 16)()
 lib.pnpp_debug_wsq_stamps(buf, 0)
-tot = sum(buf[i] for i in range(10))
+tot = sum(buf[i] for i in range(10) if i != 6)
 print("form", os.environ.get("PNPP_WSQ_FORM", "default"))
 for i, n in enumerate(names):
-    if buf[i]: print(f"  {n:40s} {buf[i]/N:9.0f} ticks/launch  {100*buf[i]/max(tot,1):5.1f} %")
+    if buf[i] and i != 6: print(f"  {n:40s} {buf[i]/N:9.0f} ticks/launch  {100*buf[i]/max(tot,1):5.1f} %")
 print(f"  total {tot/N:.0f} ticks per launch")
+if buf[6]: print(f"  {tot/N:.0f} shader cycles in {buf[6]/N/100:.2f} us of real time (s_memrealtime, 100 MHz): {tot/(buf[6]*10):.3f} GHz")
