@@ -43,15 +43,149 @@ BYTES_PER_CLOUD = 34.6e6       # 5 E + 3 G float32 words + xyz / indi
 
 
 def is_capture_error(e: BaseException) -> bool:
-    """True for what a failed stream capture raises (torch surfaces HIP's capture status codes as RuntimeError /
-    AcceleratorError texts); anything else -- TypeError, ValueError, a PNPP status -- is a bug and propagates."""
+    """True for what a failed stream capture raises: HIP's capture status codes (hipErrorStreamCaptureUnsupported /
+    ...Invalidated / ...Merge / ...Unmatched / ...Unjoined / ...Isolation / ...Implicit / ...WrongThread, hipErrorCapturedEvent --
+    "operation not permitted when stream is capturing", "operation failed due to a previous error during capture", ...) and
+    torch's own capture checks ("... must be captured on a non-default stream"), all of which say capture / capturing / captured.
+    Anything else -- TypeError, ValueError, a PNPP status, a HIP fault, an NCCL error, autograd's "backward through the graph a
+    second time" -- is a bug or a fault and propagates."""
     if not isinstance(e, RuntimeError) or isinstance(e, NotImplementedError):
         return False
-    msg = str(e).lower()
-    return any(w in msg for w in ("captur", "hipgraph", "cudagraph", "cuda graph", "hip graph", "streamcapture", "graph"))
+    return "captur" in str(e).lower()
 
 
-DP_SCHEDULES = ("captured_overlap", "captured_single", "overlap", "single")
+# Data-parallel schedules.  The host-issued ones run on any backend and are rehearsed on two ranks by tests/: they are built, timed
+# and MEASURED first.  The captured ones (RCCL's launches as nodes of the step's hipGraph) have only ever executed with a one-rank
+# communicator (the builder's box has one GPU), so they are opt-in (PNPP_DP_CAPTURED=1) and, when opted in, tried only AFTER the
+# measurement of the best host-issued schedule is in hand, each under a bounded wait (ScheduleTrial).
+SAFE_SCHEDULES = ("single", "overlap")
+CAPTURED_SCHEDULES = ("captured_single", "captured_overlap")
+DP_SCHEDULES = CAPTURED_SCHEDULES + SAFE_SCHEDULES
+SCHEDULE_MODE_PREFIX = {"captured_overlap": "ONE hipGraph (fwd + bwd, the two", "captured_single": "ONE hipGraph (fwd + bwd + the captured",
+                        "overlap": "two hipGraphs", "single": "hipGraph(fwd+loss+bwd) + eager"}
+
+
+def run_bounded(fn, limit_s, thread_setup=None):
+    """Runs fn() on a helper thread and waits at most limit_s for it: ("ok", value) | ("error", exception) | ("timeout", None).
+    A timed-out helper is abandoned (daemon thread): whatever it waits for -- a device that no longer answers, a collective whose
+    peers never arrive -- must not be touched again by the caller."""
+    import threading
+    box = {}
+
+    def target():
+        try:
+            if thread_setup is not None:
+                thread_setup()
+            box["value"] = fn()
+        except BaseException as e:   # noqa: BLE001 -- handed to the caller, which decides
+            box["error"] = e
+
+    th = threading.Thread(target=target, daemon=True)
+    th.start()
+    th.join(limit_s)
+    if th.is_alive():
+        return "timeout", None
+    if "error" in box:
+        return "error", box["error"]
+    return "ok", box.get("value")
+
+
+class Ctrl:
+    """Control plane between the ranks: agreement on small CPU values over gloo, independent of the GPU streams and of the RCCL
+    communicator -- a rank whose device hangs can still tell the others, and nobody waits on the communicator that hung."""
+
+    def __init__(self, world):
+        self.world, self.group = world, None
+        if world > 1:
+            import datetime
+            import torch.distributed as tdist
+            # always a group of its own (also when the data plane is gloo): a helper thread may be stuck inside a data-plane collective
+            self.group = tdist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+
+    def _reduce(self, x, op):
+        if self.world == 1:
+            return float(x)
+        import torch.distributed as tdist
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        tdist.all_reduce(t, op=getattr(tdist.ReduceOp, op), group=self.group)
+        return float(t)
+
+    def all_ok(self, flag) -> bool:
+        return self._reduce(1.0 if flag else 0.0, "MIN") >= 1.0
+
+    def max(self, x) -> float:
+        return self._reduce(x, "MAX")
+
+
+class ScheduleTrial:
+    """Builds and times data-parallel schedules so that the run cannot lose its measurement.
+
+    build(name) -> (step, mode, local)   may raise; time_steps(step, n) -> seconds on this rank for n steps (fenced).
+    safe(names):     built and timed in the open.  An exception propagates (a bug or a fault in the step must exit non-zero with its
+                     message, never hide behind a slower schedule); a schedule whose capture fell back to another form is recorded.
+    optional(names): each build and each timing under run_bounded.  Any failure on any rank (error, timeout, wrong form) is agreed
+                     over the control plane and the schedule is abandoned by every rank; after a TIMEOUT -- or an error that is not a
+                     capture error -- the device or the communicator may be unusable: `poisoned` is set, nothing further is tried,
+                     and the caller must finish on what it has already measured without touching the GPU again."""
+
+    def __init__(self, build, time_steps, ctrl, bounded_s=60.0, thread_setup=None, log=None):
+        self.build, self.time_steps, self.ctrl, self.bounded_s, self.thread_setup = build, time_steps, ctrl, bounded_s, thread_setup
+        self.log = log or (lambda msg: print(f"[bench] {msg}", file=sys.stderr))
+        self.built, self.trial_ms, self.failed, self.poisoned = {}, {}, {}, False
+
+    def _form_ok(self, name, mode):
+        return mode.startswith(SCHEDULE_MODE_PREFIX.get(name, ""))
+
+    def safe(self, names, n_warm=5, n=30):
+        for name in names:
+            cand = self.build(name)
+            if not self.ctrl.all_ok(self._form_ok(name, cand[1])):
+                self.failed[name] = "capture fell back: " + cand[1][:60]
+                continue
+            for _ in range(n_warm):
+                cand[0]()
+            self.built[name] = cand
+            self.trial_ms[name] = self.ctrl.max(self.time_steps(cand[0], n)) / n * 1e3
+        return self
+
+    def optional(self, names, n_warm=5, n=30):
+        for name in names:
+            if self.poisoned:
+                self.failed.setdefault(name, "not tried: an earlier optional schedule left the device or the communicator unusable")
+                continue
+            status, val = run_bounded(lambda: self.build(name), self.bounded_s, self.thread_setup)
+            mine = status == "ok" and self._form_ok(name, val[1])
+            hard = status == "timeout" or (status == "error" and not is_capture_error(val))
+            why = (f"timed out after {self.bounded_s:.0f} s while building" if status == "timeout"
+                   else f"{type(val).__name__}: {str(val)[:160]}" if status == "error"
+                   else None if mine else "capture fell back: " + val[1][:60])
+            if self.ctrl.all_ok(mine):
+                def warm_and_time(step=val[0]):
+                    for _ in range(n_warm):
+                        step()
+                    return self.time_steps(step, n)
+                status, t = run_bounded(warm_and_time, self.bounded_s, self.thread_setup)
+                mine = status == "ok"
+                hard = hard or not mine
+                why = (f"timed out after {self.bounded_s:.0f} s in its first replays" if status == "timeout"
+                       else f"{type(t).__name__}: {str(t)[:160]}" if status == "error" else None)
+                if self.ctrl.all_ok(mine):
+                    self.built[name] = val
+                    self.trial_ms[name] = self.ctrl.max(t) / n * 1e3
+                    continue
+            self.failed[name] = why or "another rank could not build or run it"
+            self.log(f"{name}: abandoned by every rank ({self.failed[name]})")
+            # a failure on ANOTHER rank leaves this rank's helper waiting for peers that will not come: that is a hang too
+            if not self.ctrl.all_ok(not hard):
+                self.poisoned = True
+        return self
+
+    def best(self, among=None):
+        pool = {k: v for k, v in self.trial_ms.items() if among is None or k in among}
+        return min(pool, key=pool.get) if pool else None
+
+    def report(self, chosen):
+        return {"candidates_ms": dict(self.trial_ms), "chosen": chosen, **({"not_built": dict(self.failed)} if self.failed else {})}
 
 
 def build_step(model, opt, xyz, mu_gt, kappa_gt, world, use_graph, collective=True, schedule=None):
@@ -174,16 +308,16 @@ def kernel_cost(tag: str):
 
     if tag.startswith(("gemm_wsp_kernel", "gemm_wsq_kernel")):
         # the fused backward product of a level's last layer on gemm_wsp / gemm_wsq: dA (+ ReLU mask, sums) and dW in one launch;
-        # Z_l and z_{l-1} read once, dY_{l-1} written once, one K x 64 dW partial per workgroup
+        # Z_l and z_{l-1} read once, dY_{l-1} written once, the weights read and dW written once.  The kernel's own dW partial
+        # slabs (one per workgroup) are NOT algorithmic bytes: they show up in `traffic` (round 3 counted them here and read 1.035 x;
+        # operands-once / results-once it was 1.10 x for gemm_wsp and 1.31 x for gemm_wsq)
         M, N, K = ints(r"M=(\d+) N=(\d+) K=(\d+)")
-        g, = ints(r"grid=(\d+)x")
-        return 4.0 * M * N * K, 4.0 * (M * K + 2.0 * M * N + K * N + K * 64.0 * g)
+        return 4.0 * M * N * K, 4.0 * (M * K + 2.0 * M * N + 2.0 * K * N)
     if tag.startswith("gemm_wsx_kernel"):
         # layer 1's backward with layer 0 folded in: dY_1 and Z_1 read once, neighbour indices; Z_0 is rebuilt (two MFMA steps per
-        # tile), dY_0 is never written; one K x 64 dW partial + 272 doubles per workgroup
+        # tile), dY_0 is never written; weights read, dW written once (partial slabs are traffic, not algorithmic bytes)
         M, N, K = ints(r"M=(\d+) N=(\d+) K=(\d+)")
-        g, = ints(r"grid=(\d+)x")
-        return 4.0 * M * N * K + 8.0 * M * N, 4.0 * (2.0 * M * K + M + K * N + K * 64.0 * g) + 2176.0 * g
+        return 4.0 * M * N * K + 8.0 * M * N, 4.0 * (2.0 * M * K + M + 2.0 * K * N)
     if tag.startswith("gemm_wsf0_kernel"):
         M, N, K = ints(r"M=(\d+) N=(\d+) K=(\d+)")
         return 2.0 * M * N * K + 8.0 * M * K, 4.0 * (M * N + M + K * N)   # z_1 written once, neighbour indices read; no operand stream
@@ -247,10 +381,9 @@ def kernel_cost(tag: str):
             byts = 4.0 * (M * N + K * N) + 4.0 * M
         if e == 2:
             byts += 4.0 * M * N                            # read the previous layer's z for the ReLU mask
-        if ",dW>" in tag:                                  # fused weight gradient: second GEMM on the tiles already in LDS,
-            flops *= 2.0                                   # one K x N partial per persistent worker
-            g = re.search(r"grid=(\d+)x(\d+)", tag)
-            byts += 4.0 * K * N * int(g.group(1)) * int(g.group(2)) / max(1, N // 64)
+        if ",dW>" in tag:                                  # fused weight gradient: second GEMM on the tiles already in LDS;
+            flops *= 2.0                                   # dW written once (the per-worker partials are traffic, not algorithmic)
+            byts += 4.0 * K * N
         return flops, byts
     if tag.startswith("dw_kernel") or tag.startswith("dw_lds_kernel"):
         a2 = ints(r",A(\d)>")
@@ -408,8 +541,10 @@ def cpu_baseline(B, budget_s=16.0):
 
 def rccl_tuning_log_setup():
     """Ask RCCL to write which algorithm / protocol it picks for each message size to a per-process FILE (never stdout: the
-    one JSON line lives there).  Must run before the communicator is created.  PNPP_RCCL_TUNING_LOG=0 turns it off."""
-    if os.environ.get("PNPP_RCCL_TUNING_LOG", "1") == "0" or "NCCL_DEBUG" in os.environ:
+    one JSON line lives there).  Must run before the communicator is created.  OFF by default (PNPP_RCCL_TUNING_LOG=1 turns it on):
+    the TUNING subsystem logs a line on the host for every eagerly enqueued collective -- inside the timed loop of the host-issued
+    schedules -- so a run that carries it is a diagnostic run, and its line says so (`rccl.logging_perturbs_timing`)."""
+    if os.environ.get("PNPP_RCCL_TUNING_LOG", "0") != "1" or "NCCL_DEBUG" in os.environ:
         return None
     import tempfile
     path = os.path.join(tempfile.gettempdir(), f"pnpp_rccl_{os.getpid()}.log")
@@ -419,7 +554,9 @@ def rccl_tuning_log_setup():
 
 def rccl_choice(path):
     """Algorithm / protocol RCCL chose for the gradient messages, from its own tuning log (None under gloo)."""
-    if not path or not os.path.exists(path):
+    if not path:
+        return None
+    if not os.path.exists(path):
         return None
     algos = {0: "tree", 1: "ring", 2: "collnet_direct", 3: "collnet_chain", 4: "nvls", 5: "nvls_tree", 6: "pat"}
     protos = {0: "LL", 1: "LL128", 2: "simple"}
@@ -437,7 +574,7 @@ def rccl_choice(path):
     except OSError:
         return None
     big = sorted(seen_.values(), key=lambda d: -d["bytes"])[:3]
-    return {"allreduce": big, "coll_channels": chans} if big else None
+    return {"allreduce": big, "coll_channels": chans, "logging_perturbs_timing": True} if big else None
 
 
 def self_launch(args) -> int:
@@ -457,37 +594,6 @@ def self_launch(args) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-def rehearse(args):
-    """Launcher / rendezvous / collective plumbing WITHOUT kernels (`--rehearse`, CPU + gloo): what tests/ can run in a
-    container that has no GPU.  The line it prints is marked as a rehearsal and carries no throughput."""
-    import torch.distributed as tdist
-    from pnpp_hip import dist as pdist
-    rank, _, world = pdist.init_from_env(backend="gloo")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    flat_g = torch.ones(1_465_922)                          # the flat gradient of PointNetPPVonMises
-    seen = torch.ones(1)
-    if world > 1:
-        tdist.all_reduce(seen)
-        tdist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pdist.all_reduce_flat_grad(flat_g)
-        flat_g.mul_(1.0 / world)
-    if world > 1:
-        tdist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    if world > 1:
-        tdist.all_reduce(el, op=tdist.ReduceOp.MAX)
-    if rank == 0:
-        print(json.dumps({"metric": "REHEARSAL of the launcher and the flat-gradient all-reduce (gloo, no kernels, not a measurement)",
-                          "value": None, "unit": "clouds/s", "n_gpus": world, "n_ranks_seen": int(seen.item()),
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(el) / max(args.steps, 1),
-                          "rehearsal": True, "allreduce_ok": bool(torch.all(flat_g == 1.0))}))
-    if world > 1:
-        tdist.barrier()
-        tdist.destroy_process_group()
-
-
 def timed(step, n, fence):
     fence()
     t0 = time.perf_counter()
@@ -496,6 +602,125 @@ def timed(step, n, fence):
         loss = step()
     fence()
     return time.perf_counter() - t0, loss
+
+
+def measure_schedules(args, world, ctrl, trial, fence, want_captured):
+    """The order that cannot lose the measurement (world > 1, no schedule pinned):
+      1. the host-issued schedules are built and timed; the fastest is warmed up and TIMED for exactly --steps steps: that number
+         is in hand before anything untested runs;
+      2. only then, and only when asked for (PNPP_DP_CAPTURED=1 on a capturable backend), the captured schedules are tried, each
+         under a bounded wait; one that beats the best host-issued trial is warmed up and timed the same way (bounded as well) and
+         replaces the result;
+      3. if a captured schedule left the device or the communicator unusable (`trial.poisoned`), the caller prints the line of
+         step 1 and leaves without touching the GPU again.
+    Returns {"name", "elapsed" (max over ranks, s), "loss", "cand"}."""
+    trial.safe(SAFE_SCHEDULES)
+    assert trial.trial_ms, f"no data-parallel schedule could be built: {trial.failed}"
+
+    def run(name, bounded):
+        cand = trial.built[name]
+
+        def body():
+            for _ in range(args.warmup):
+                cand[0]()
+            return timed(cand[0], args.steps, fence)
+        if not bounded:
+            el, loss = body()
+        else:
+            status, val = run_bounded(body, trial.bounded_s + 0.01 * (args.steps + args.warmup), trial.thread_setup)
+            if not ctrl.all_ok(status == "ok"):
+                trial.failed[name] = "its timed run " + ("timed out" if status == "timeout" else f"failed: {val}"[:160])
+                trial.trial_ms.pop(name, None)
+                trial.poisoned = True
+                return None
+            el, loss = val
+        return {"name": name, "elapsed": ctrl.max(el), "loss": loss, "cand": cand}
+
+    result = run(trial.best(SAFE_SCHEDULES), bounded=False)
+    if want_captured:
+        trial.optional(CAPTURED_SCHEDULES)
+        best = trial.best()
+        if not trial.poisoned and best in CAPTURED_SCHEDULES:
+            better = run(best, bounded=True)
+            if better is not None and better["elapsed"] < result["elapsed"]:
+                result = better
+    return result
+
+
+def pdist_rank():
+    import torch.distributed as tdist
+    return tdist.get_rank() if tdist.is_initialized() else 0
+
+
+class _RehearsalStep:
+    """Stand-in for a captured step in --rehearse: the flat all-reduce over gloo, in the schedule's shape, or an injected failure."""
+
+    def __init__(self, name, flat_g, inject):
+        import torch.distributed as tdist
+        if inject and "@" in inject:                        # "hang@1": on rank 1 only (its peers then wait for it in the collective)
+            inject, only = inject.split("@")
+            inject = inject if int(only) == pdist_rank() else None
+        self.name, self.g, self.inject, self.tdist = name, flat_g, inject, tdist
+        if inject == "raise_build":
+            raise RuntimeError("HIP error: an illegal memory access was encountered (injected by --rehearse-inject)")
+        if inject == "capture_error":
+            raise RuntimeError("operation not permitted when stream is capturing (injected by --rehearse-inject)")
+
+    def __call__(self):
+        if self.inject == "hang":
+            time.sleep(3600)
+        if self.inject == "raise":
+            raise RuntimeError("NCCL error: unhandled system error (injected by --rehearse-inject)")
+        from pnpp_hip import dist as pdist
+        if "overlap" in self.name:
+            cut = self.g.numel() // 16
+            pdist.all_reduce_flat_grad(self.g[cut:])
+            pdist.all_reduce_flat_grad(self.g[:cut])
+        else:
+            pdist.all_reduce_flat_grad(self.g)
+        self.g.fill_(1.0)
+        return torch.zeros(())
+
+
+def rehearse(args):
+    """Launcher / rendezvous / collective plumbing and the WHOLE schedule-selection flow WITHOUT kernels (`--rehearse`, CPU + gloo):
+    what tests/ can run in a container that has no GPU.  The line it prints is marked as a rehearsal and carries no throughput.
+    --rehearse-inject captured_single=raise,captured_overlap=hang (raise | raise_build | capture_error | hang) makes a captured
+    schedule fail the way a real one could; the line must still come out, with the host-issued candidates' times."""
+    import torch.distributed as tdist
+    from pnpp_hip import dist as pdist
+    rank, _, world = pdist.init_from_env(backend="gloo")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    flat_g = torch.ones(1_465_922)                          # the flat gradient of PointNetPPVonMises
+    seen = torch.ones(1)
+    if world > 1:
+        tdist.all_reduce(seen)
+    pdist.all_reduce_flat_grad(flat_g)
+    allreduce_ok = bool(torch.all(flat_g == float(world)))
+    inject = dict(kv.split("=") for kv in args.rehearse_inject.split(",") if kv)
+    ctrl = Ctrl(world)
+
+    def fence():
+        if world > 1:
+            tdist.barrier()
+
+    def build(name):
+        return _RehearsalStep(name, flat_g, inject.get(name)), SCHEDULE_MODE_PREFIX[name], None
+
+    trial = ScheduleTrial(build, lambda step, n: timed(step, n, fence)[0], ctrl, bounded_s=float(os.environ.get("PNPP_DP_BOUNDED_S", "60")))
+    res = measure_schedules(args, world, ctrl, trial, fence, want_captured=bool(inject) or os.environ.get("PNPP_DP_CAPTURED") == "1")
+    if rank == 0:
+        print(json.dumps({"metric": "REHEARSAL of the launcher, the schedule selection and the flat-gradient all-reduce (gloo, no kernels, not a measurement)",
+                          "value": None, "unit": "clouds/s", "n_gpus": world, "n_ranks_seen": int(seen.item()),
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * res["elapsed"] / max(args.steps, 1),
+                          "rehearsal": True, "allreduce_ok": allreduce_ok, "config": {"dp_schedule": trial.report(res["name"])},
+                          "poisoned": trial.poisoned}), flush=True)
+    if trial.poisoned:                                      # a helper thread still hangs: leave without waiting for anything
+        sys.stderr.flush()
+        os._exit(0)
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
 
 
 def main():
@@ -510,9 +735,12 @@ def main():
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
                     help="f32 (default, the reference's arithmetic: the headline) or bf16 (opt-in throughput mode: bf16 MFMA operands, "
                          "f32 accumulate, reported under its own metric key)")
-    ap.add_argument("--no-bf16-variant", action="store_true", help="skip the secondary bf16-operand measurement of the default run")
+    ap.add_argument("--bf16-variant", action="store_true",
+                    help="also measure the secondary bf16-operand line (never the headline; off by default since round 4)")
+    ap.add_argument("--no-bf16-variant", action="store_true", help="accepted for older command lines: the variant is off by default")
     ap.add_argument("--rehearse", action="store_true",
-                    help="CPU/gloo rehearsal of the launcher and the collective plumbing only (no kernels, no throughput)")
+                    help="CPU/gloo rehearsal of the launcher, the schedule selection and the collective plumbing only (no kernels)")
+    ap.add_argument("--rehearse-inject", default="", help="--rehearse only: name=raise|raise_build|capture_error|hang[@rank][,name=...]")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # no launcher around us: become one (no GPU call made so far)
@@ -543,6 +771,7 @@ def main():
     seen = torch.ones(1, device=dev)
     if world > 1:
         tdist.all_reduce(seen)                             # every rank really is in the job (and the communicator exists)
+    ctrl = Ctrl(world)
 
     def fence():
         torch.cuda.synchronize()
@@ -550,81 +779,93 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize()
 
-    # Data-parallel schedule, chosen by measurement before the warm-up (never inside the timed region).  Overlap is not free on
-    # this chip: the collective's workgroups need CUs that the persistent GEMM kernels of the backward pass (one or two
-    # workgroups per CU, nearly all of the LDS and registers) assume to own, and a fork / join pair inside a replayed graph has
-    # its own price -- so every rank builds every schedule its backend can run, times it (MAX over ranks) and all take the
-    # fastest.  PNPP_DP_SCHEDULE (or PNPP_NO_OVERLAP=0/1) pins one.
-    dp_schedule = None
+    def emit(elapsed, final_loss, launch_mode, dp_schedule, exposed_us=None, replicas=None, bf16=None, roof=None, table=(), kernel_ms=None,
+             cpu=None, note=None):
+        ms = 1e3 * elapsed / args.steps
+        per_gpu = B * args.steps / elapsed
+        out = {
+            "metric": "clouds/sec fwd+bwd, pointnet_pp_vonMises N=1024" + (
+                "" if args.precision == "f32" else ", bf16-operand MFMA variant (f32 accumulate)"), "value": world * per_gpu,
+            "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "configs[1]: models/pointnet_pp_vonMises.py single-peak KL, N=1024, batch=32 per GPU, "
+                                   "fwd+loss+bwd+allreduce+Adam, random-init weights (seed 42), device-side centre sampling",
+                       "per_gpu_batch": B, "global_batch": B * world, "points": N_POINTS,
+                       "parallelism": f"dp{world}" if world > 1 else "single", "launch": launch_mode,
+                       **({"dp_schedule": dp_schedule} if dp_schedule else {})},
+            "final_loss": final_loss, "n_ranks_seen": int(seen_host), "allreduce_exposed_us": exposed_us,
+            **({"replicas_rel_spread": replicas} if world > 1 else {}),
+            **({"rccl": rccl_choice(rccl_log)} if world > 1 and rccl_log else {}),
+            # whole step against both roofs (SURVEY 8d): algorithmic FLOPs / bytes per cloud x clouds/s per GPU
+            "mfma_fraction": per_gpu * FLOPS_PER_CLOUD / (MFMA_F32_PEAK_TFLOPS * 1e12),
+            "hbm_fraction": per_gpu * BYTES_PER_CLOUD / (HBM_PEAK_GBS * 1e9),
+            "kernel_ms_per_step": kernel_ms, **({"bf16_variant": bf16} if bf16 else {}), **({"note": note} if note else {}),
+            "roofline": roof, "cpu_baseline": cpu, "top_kernels": list(table),
+        }
+        print(json.dumps(out), flush=True)
+
+    seen_host = float(seen.item())
     forced = os.environ.get("PNPP_DP_SCHEDULE") or {"0": "overlap", "1": "single"}.get(os.environ.get("PNPP_NO_OVERLAP", ""))
+    dp_schedule = None
     if world > 1 and not args.no_graph and forced is None:
-        capturable = tdist.get_backend() == "nccl"        # RCCL launches are stream work; gloo goes through the host
-        built, trial, failed = {}, {}, {}
-        for name in DP_SCHEDULES:
-            if name.startswith("captured") and not capturable:
-                failed[name] = f"backend {tdist.get_backend()} cannot be captured"
-                continue
-            ok = torch.ones(1, device=dev)
-            try:
-                cand = build_step(model, opt, xyz, mu_gt, kappa_gt, world, True, schedule=name)
-            except RuntimeError as e:                      # build_step has already re-raised what is not a capture error
-                cand, ok = None, torch.zeros(1, device=dev)
-                failed[name] = f"{type(e).__name__}: {str(e)[:120]}"
-            tdist.all_reduce(ok, op=tdist.ReduceOp.MIN)    # a schedule is a candidate only if EVERY rank could build it
-            if float(ok) < 1.0 or cand is None:
-                failed.setdefault(name, "another rank could not build it")
-                continue
-            want = {"captured_overlap": "ONE hipGraph (fwd + bwd, the two", "captured_single": "ONE hipGraph (fwd + bwd + the captured",
-                    "overlap": "two hipGraphs", "single": "hipGraph(fwd+loss+bwd) + eager"}[name]
-            got = torch.tensor([1.0 if cand[1].startswith(want) else 0.0], device=dev)
-            tdist.all_reduce(got, op=tdist.ReduceOp.MIN)
-            if float(got) < 1.0:                           # fell back to another form inside build_step: not this schedule
-                failed[name] = "capture fell back: " + cand[1][:60]
-                continue
-            built[name] = cand
-        for name, cand in built.items():
-            for _ in range(5):
-                cand[0]()
-            t_el, _ = timed(cand[0], 30, fence)
-            t = torch.tensor([t_el], device=dev, dtype=torch.float64)
-            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-            trial[name] = float(t) / 30 * 1e3
-        assert trial, f"no data-parallel schedule could be built: {failed}"
-        chosen = min(trial, key=trial.get)
-        dp_schedule = {"candidates_ms": trial, "chosen": chosen, **({"not_built": failed} if failed else {})}
-        step, launch_mode, step_local = built[chosen]
+        # Data-parallel schedule, chosen by measurement (never inside the timed region).  Overlap is not free on this chip: the
+        # collective's workgroups need CUs that the persistent GEMM kernels of the backward pass assume to own -- so every rank builds
+        # the host-issued schedules, times them (MAX over ranks) and all take the fastest; PNPP_DP_SCHEDULE (or PNPP_NO_OVERLAP=0/1)
+        # pins one, PNPP_DP_CAPTURED=1 adds the captured ones behind the secured measurement (measure_schedules).
+        capturable = tdist.get_backend() == "nccl"         # RCCL launches are stream work; gloo goes through the host
+        want_captured = os.environ.get("PNPP_DP_CAPTURED") == "1"
+        trial = ScheduleTrial(lambda name: build_step(model, opt, xyz, mu_gt, kappa_gt, world, True, schedule=name),
+                              lambda step, n: timed(step, n, fence)[0], ctrl,
+                              bounded_s=float(os.environ.get("PNPP_DP_BOUNDED_S", "60")),
+                              thread_setup=lambda: torch.cuda.set_device(dev))
+        if not want_captured:
+            trial.failed.update({n: "opt-in (PNPP_DP_CAPTURED=1): never run with more than one RCCL rank" for n in CAPTURED_SCHEDULES})
+        elif not capturable:
+            trial.failed.update({n: f"backend {tdist.get_backend()} cannot be captured" for n in CAPTURED_SCHEDULES})
+        res = measure_schedules(args, world, ctrl, trial, fence, want_captured and capturable)
+        dp_schedule = trial.report(res["name"])
+        elapsed, loss = res["elapsed"], res["loss"]
+        step, launch_mode, step_local = res["cand"]
+        if trial.poisoned:
+            # a captured schedule hung or faulted AFTER the host-issued measurement was taken: print that measurement and leave.  No
+            # further GPU call, no collective on the communicator that hung, no wait for the helper thread; a rank never re-execs.
+            if rank == 0:
+                emit(elapsed, None, launch_mode, dp_schedule,
+                     note="a captured schedule left the device or the communicator unusable; this is the host-issued measurement taken before it")
+            sys.stderr.flush()
+            os._exit(0)
         if step_local is None:                             # captured collective: its collective-free twin is the plain graph
             step_local = build_step(model, opt, xyz, mu_gt, kappa_gt, world, True, collective=False)[0]
-        del built
     else:
         step, launch_mode, step_local = build_step(model, opt, xyz, mu_gt, kappa_gt, world, not args.no_graph, schedule=forced)
         if step_local is None:
             step_local = build_step(model, opt, xyz, mu_gt, kappa_gt, world, not args.no_graph, collective=False)[0]
+        for _ in range(args.warmup):
+            step()
+        el, loss = timed(step, args.steps, fence)
+        elapsed = ctrl.max(el)
+    final_loss = float(loss.detach())
     eager_step, _, _ = build_step(model, opt, xyz, mu_gt, kappa_gt, world, False, collective=False)   # rank-local, for the roofline pass
 
-    for _ in range(args.warmup):
-        step()
-
-    el, loss = timed(step, args.steps, fence)
-    elapsed = torch.tensor([el], device=dev, dtype=torch.float64)
+    exposed_us, replicas = None, None
     if world > 1:
-        tdist.all_reduce(elapsed, op=tdist.ReduceOp.MAX)
-    elapsed = float(elapsed)
-    final_loss = float(loss.detach())
-
-    exposed_us = None
-    if world > 1:   # the same captured step without the collective: what the all-reduce costs beyond what backward hides
+        # every replica took the same reduced gradients: their parameters must still be the same numbers (a collective that ran in
+        # the wrong place of a schedule shows up here, not in the timing)
+        chk = opt.flat_p.double().abs().sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        tdist.all_reduce(lo, op=tdist.ReduceOp.MIN)
+        tdist.all_reduce(hi, op=tdist.ReduceOp.MAX)
+        replicas = float((hi - lo) / hi.clamp_min(1e-30))
+        # the same captured step without the collective: what the all-reduce costs beyond what backward hides
         for _ in range(min(args.warmup, 5)):
             step_local()
         el2, _ = timed(step_local, args.steps, fence)
-        e2 = torch.tensor([el2], device=dev, dtype=torch.float64)
-        tdist.all_reduce(e2, op=tdist.ReduceOp.MAX)
-        exposed_us = 1e6 * (elapsed - float(e2)) / args.steps
+        exposed_us = 1e6 * (elapsed - ctrl.max(el2)) / args.steps
         pdist.broadcast_flat(opt.flat_p)                   # replicas drifted apart in the local-only steps: not used after this
 
-    # secondary line (never the headline): the same step with bf16 MFMA operands in the grouped layers' large GEMMs
+    # secondary line (never the headline, opt-in): the same step with bf16 MFMA operands in the grouped layers' large GEMMs
     bf16 = None
-    if args.precision == "f32" and world == 1 and not args.no_bf16_variant:
+    if args.precision == "f32" and world == 1 and args.bf16_variant and not args.no_bf16_variant:
         ops.set_matmul_precision("bf16")
         torch.manual_seed(42)
         m16 = PointNetPPVonMises(sampler="device").to(dev).train()
@@ -650,27 +891,9 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(B)
-        ms = 1e3 * elapsed / args.steps
-        per_gpu = B * args.steps / elapsed
-        out = {
-            "metric": "clouds/sec fwd+bwd, pointnet_pp_vonMises N=1024" + (
-                "" if args.precision == "f32" else ", bf16-operand MFMA variant (f32 accumulate)"), "value": world * per_gpu,
-            "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "configs[1]: models/pointnet_pp_vonMises.py single-peak KL, N=1024, batch=32 per GPU, "
-                                   "fwd+loss+bwd+allreduce+Adam, random-init weights (seed 42), device-side centre sampling",
-                       "per_gpu_batch": B, "global_batch": B * world, "points": N_POINTS,
-                       "parallelism": f"dp{world}" if world > 1 else "single", "launch": launch_mode,
-                       **({"dp_schedule": dp_schedule} if dp_schedule else {})},
-            "final_loss": final_loss, "n_ranks_seen": int(seen.item()), "allreduce_exposed_us": exposed_us,
-            **({"rccl": rccl_choice(rccl_log)} if world > 1 else {}),
-            # whole step against both roofs (SURVEY 8d): algorithmic FLOPs / bytes per cloud x clouds/s per GPU
-            "mfma_fraction": per_gpu * FLOPS_PER_CLOUD / (MFMA_F32_PEAK_TFLOPS * 1e12),
-            "hbm_fraction": per_gpu * BYTES_PER_CLOUD / (HBM_PEAK_GBS * 1e9),
-            "kernel_ms_per_step": kernel_ms, "bf16_variant": bf16,
-            "roofline": roof, "cpu_baseline": cpu, "top_kernels": table,
-        }
-        print(json.dumps(out))
+        emit(elapsed, final_loss, launch_mode, dp_schedule, exposed_us, replicas, bf16, roof, table, kernel_ms, cpu)
+    elif rccl_log and os.path.exists(rccl_log):
+        os.remove(rccl_log)
     if world > 1:
         tdist.barrier()
         tdist.destroy_process_group()
