@@ -775,6 +775,8 @@ static int fc_backward_impl(const pnpp_fc_desc *d, const pnpp_fc_bwd_args *a, hi
     return PNPP_OK;
 }
 
+unsigned fc_build_flags() { return (FCF_EXP != 0) ? 32u : 0u; }
+
 }  // namespace pnpp
 
 using namespace pnpp;

@@ -3334,4 +3334,11 @@ int launch_fill_zero(void *p, size_t bytes, hipStream_t st) {
     return PNPP_OK;
 }
 
+#ifdef PNPP_STAMPS
+#define PNPP_STAMPS_BIT 64u
+#else
+#define PNPP_STAMPS_BIT 0u
+#endif
+unsigned gemm_build_flags() { return ((PNPP_WS_EXP_NO_MFMA != 0) ? 1u : 0u) | PNPP_STAMPS_BIT; }
+
 }  // namespace pnpp

@@ -481,6 +481,13 @@ bool try_launch_wsp(const AOperand &A, const BOperand &B, int M, int Nout, int K
     return true;
 }
 
+#ifdef PNPP_STAMPS
+#define PNPP_STAMPS_BIT 64u
+#else
+#define PNPP_STAMPS_BIT 0u
+#endif
+unsigned wsp_build_flags() { return ((WSP_EXP != 0) ? 2u : 0u) | PNPP_STAMPS_BIT; }
+
 }  // namespace pnpp
 
 #ifdef PNPP_STAMPS

@@ -799,6 +799,13 @@ bool try_launch_wsq(const AOperand &A, const BOperand &B, int M, int Nout, int K
     return true;
 }
 
+#ifdef PNPP_STAMPS
+#define PNPP_STAMPS_BIT 64u
+#else
+#define PNPP_STAMPS_BIT 0u
+#endif
+unsigned wsq_build_flags() { return ((WSQ_EXP != 0) ? 8u : 0u) | ((WSQ_PLAIN != 0) ? 16u : 0u) | PNPP_STAMPS_BIT; }
+
 }  // namespace pnpp
 
 #ifdef PNPP_STAMPS

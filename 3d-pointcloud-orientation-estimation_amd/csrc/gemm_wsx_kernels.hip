@@ -935,4 +935,66 @@ int launch_xyz0_post(const float *dwslab, int workers, int C1, float *dw1, int l
     return PNPP_OK;
 }
 
+// ---- diagnostics for the parity tests: the ReLU decisions of a layer exactly as the backward pass takes them ----
+// layer 0 of a level on raw coordinates is never stored: its activation is rebuilt by the SAME two MFMA steps on the SAME operands as in
+// gemm_wsf0_kernel / gemm_wsx_kernel ([x y | z 1] x [s w_x, s w_y | s w_z, t]), one wave per strip of 32 rows
+struct MaskArgs {
+    const float *xyz, *centres;
+    const int32_t *idx;
+    int M, N, S;
+    const float *W0;
+    int ldw0;
+    const float *scale0, *shift0;
+    uint8_t *out;   // M x 64
+};
+__global__ void __launch_bounds__(256) xyz0_mask_kernel(const MaskArgs P) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int strip = blockIdx.x * 4 + wave;
+    if (strip >= P.M / 32) return;
+    const int nidx = P.idx[(size_t)strip * 32 + l31];
+    const float *pt = P.xyz + ((size_t)(strip / P.S) * P.N + nidx) * 3, *ct = P.centres + (size_t)strip * 3;
+    const float rx = __fsub_rn(pt[0], ct[0]), ry_ = __fsub_rn(pt[1], ct[1]), rz_ = __fsub_rn(pt[2], ct[2]);
+    const float za0 = lh ? ry_ : rx, za1 = lh ? 1.f : rz_;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = j * 32 + l31;
+        const float sc = P.scale0[col], sh = P.shift0[col];
+        const float wx = P.W0[col * P.ldw0], wy = P.W0[col * P.ldw0 + 1], wz = P.W0[col * P.ldw0 + 2];
+        const float zb0 = lh ? sc * wy : sc * wx, zb1 = lh ? sh : sc * wz;
+        f32x16 zt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zt[r] = 0.f;
+        zt = __builtin_amdgcn_mfma_f32_32x32x2f32(za0, zb0, zt, 0, 0, 0);
+        zt = __builtin_amdgcn_mfma_f32_32x32x2f32(za1, zb1, zt, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            P.out[((size_t)strip * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)) * 64 + col] = zt[r] > 0.f ? 1 : 0;
+    }
+}
+// a stored layer: the sign of fmaf(Z, scale, shift), which is what every operand loader and mask epilogue of the library evaluates
+__global__ void __launch_bounds__(256) relu_mask_kernel(const float *__restrict__ z, const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, size_t n, int C, uint8_t *__restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % (size_t)C);
+        out[i] = fmaf(z[i], scale[c], shift[c]) > 0.f ? 1 : 0;
+    }
+}
+int launch_relu_mask(const float *z, const float *scale, const float *shift, size_t n, int C, uint8_t *out, hipStream_t st) {
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(2048), dim3(256), 0, st, z, scale, shift, n, C, out);
+    PNPP_CHECK_LAUNCH("relu_mask");
+    return PNPP_OK;
+}
+int launch_xyz0_mask(const AOperand &geo, int M, const float *W0, int ldw0, const float *scale0, const float *shift0, uint8_t *out,
+                     hipStream_t st) {
+    MaskArgs P;
+    P.xyz = geo.xyz, P.centres = geo.new_xyz, P.idx = geo.idx, P.M = M, P.N = geo.N, P.S = geo.S, P.W0 = W0, P.ldw0 = ldw0;
+    P.scale0 = scale0, P.shift0 = shift0, P.out = out;
+    hipLaunchKernelGGL(xyz0_mask_kernel, dim3(cdiv(M / 32, 4)), dim3(256), 0, st, P);
+    PNPP_CHECK_LAUNCH("xyz0_mask");
+    return PNPP_OK;
+}
+
+// compile-time experiment switches of this translation unit (pnpp_build_flags: all zero in a library that ships)
+unsigned wsx_build_flags() { return (WSX_EXP != 0) ? 4u : 0u; }
+
 }  // namespace pnpp

@@ -165,6 +165,16 @@ int launch_wsf0(const AOperand &geo, int M, const float *W0, int ldw0, const dou
 int launch_xyz0_post(const float *dwslab, int workers, int C1, float *dw1, int ld1, const double *stat, const float *W0, int ldw0,
                      const float *gamma0, const float *mean0, const float *istd0, double count, int training, float *dW0, int ld0,
                      float *dgamma0, float *dbeta0, float *dbias0, hipStream_t st);
+// diagnostics (pnpp_sa_saved_relu_mask): the ReLU decisions of a stored layer / of the rebuilt layer 0 of a level on raw coordinates
+int launch_relu_mask(const float *z, const float *scale, const float *shift, size_t n, int C, uint8_t *out, hipStream_t st);
+int launch_xyz0_mask(const AOperand &geo, int M, const float *W0, int ldw0, const float *scale0, const float *shift0, uint8_t *out,
+                     hipStream_t st);
+// per translation unit: bits of pnpp_build_flags() (experiment / stamp switches compiled in; zero in a library that ships)
+unsigned wsx_build_flags();
+unsigned wsp_build_flags();
+unsigned wsq_build_flags();
+unsigned gemm_build_flags();
+unsigned fc_build_flags();
 bool try_launch_mid_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout, int Kd, const Epilogue &E, int *nslab, const AOperand &a2,
                           int Kp, float *slab, int *nsplit_out, int *kp_pad_out, hipStream_t st, int *rc, float *dw_direct = nullptr,
                           int dw_ld = 0);   // dw_direct (Nc x dw_ld, dw_ld == Kp): written in place when one row range suffices; *nsplit_out = 0 then

@@ -619,7 +619,7 @@ static int sa_backward_impl(const pnpp_sa_desc *d, const pnpp_sa_bwd_args *a, hi
 using namespace pnpp;
 
 extern "C" const char *pnpp_last_error(void) { return g_err; }
-extern "C" int pnpp_abi_version(void) { return 3; }
+extern "C" int pnpp_abi_version(void) { return 4; }
 
 extern "C" int pnpp_set_stats_exchange(pnpp_stats_exchange_fn fn, void *user, double *buf, size_t buf_doubles) {
     if (!fn) {
@@ -688,6 +688,21 @@ extern "C" const int32_t *pnpp_sa_saved_argmax(const pnpp_sa_desc *d, const void
     SaGeom g;
     if (sa_geom(d, &g) != PNPP_OK) return nullptr;
     return sa_saved_layout(d, g, const_cast<void *>(saved)).arg;
+}
+extern "C" int pnpp_sa_saved_relu_mask(const pnpp_sa_desc *d, const void *saved, const float *xyz, const float *conv_w0, int layer,
+                                       uint8_t *out, void *stream) {
+    SaGeom g;
+    PNPP_TRY(sa_geom(d, &g));
+    PNPP_REQUIRE(saved && out && layer >= 0 && layer < d->L, PNPP_ERR_ARG, "sa_saved_relu_mask: null pointer or layer %d out of range", layer);
+    const SaSaved sv = sa_saved_layout(d, g, const_cast<void *>(saved));
+    if (layer == 0 && xyz0_applies(g.M, d->D, d->K, d->group_all, d->L, d->C)) {   // never stored: rebuilt as the kernels rebuild it
+        PNPP_REQUIRE(xyz && conv_w0, PNPP_ERR_ARG, "sa_saved_relu_mask: layer 0 of a level on raw coordinates needs xyz and conv_w0");
+        return launch_xyz0_mask(layer0_operand(d, xyz, nullptr, sv), g.M, conv_w0, g.Cin[0], sv.scale[0], sv.shift[0], out, as_stream(stream));
+    }
+    return launch_relu_mask(sv.z[layer], sv.scale[layer], sv.shift[layer], (size_t)g.M * d->C[layer], d->C[layer], out, as_stream(stream));
+}
+extern "C" unsigned pnpp_build_flags(void) {
+    return gemm_build_flags() | wsp_build_flags() | wsx_build_flags() | wsq_build_flags() | fc_build_flags();
 }
 extern "C" int pnpp_sa_group_pair(const pnpp_sa_desc *d1, const pnpp_sa_desc *d2, const float *xyz, const int32_t *centre1,
                                   const int32_t *centre2, void *saved1, float *new_xyz1, void *saved2, float *new_xyz2, void *stream) {

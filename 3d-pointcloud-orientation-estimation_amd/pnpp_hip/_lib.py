@@ -81,6 +81,8 @@ SIGNATURES = {
     "pnpp_sa_saved_neighbours": (_fp, [C.POINTER(SaDesc), _fp]),
     "pnpp_sa_group_pair": (_i, [C.POINTER(SaDesc), C.POINTER(SaDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "pnpp_sa_saved_argmax": (_fp, [C.POINTER(SaDesc), _fp]),
+    "pnpp_sa_saved_relu_mask": (_i, [C.POINTER(SaDesc), _fp, _fp, _fp, _i, _fp, _fp]),
+    "pnpp_build_flags": (C.c_uint, []),
     "pnpp_fc_saved_bytes": (_sz, [C.POINTER(FcDesc)]),
     "pnpp_fc_scratch_bytes": (_sz, [C.POINTER(FcDesc)]),
     "pnpp_fc_forward": (_i, [C.POINTER(FcDesc), C.POINTER(FcFwdArgs), _fp]),
@@ -150,7 +152,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.pnpp_abi_version() != 3:
+        if h.pnpp_abi_version() != 4:
             raise HipExtensionMissing("libpnpp_hip.so ABI version mismatch; rebuild it")
         _lib = h
     return _lib

@@ -317,6 +317,9 @@ class _SetAbstraction(torch.autograd.Function):
         ctx.desc = desc
         ctx.sinks = sinks
         ctx.has_points = points is not None
+        # which kernels a level takes depends on process-wide switches (bf16 operands, SyncBN); a level on raw coordinates keeps no
+        # Z_0 for the generic backward kernels, so its backward pass must run under the switches its forward pass ran under
+        ctx.path_state = (lib.pnpp_get_matmul_precision(), lib.pnpp_stats_exchange_enabled())
         ctx.save_for_backward(xyz, points if points is not None else xyz.new_empty(0), saved, *conv_w, *bn_w, *bn_b)
         if group_all:
             nbr = torch.empty(0, dtype=torch.int32, device=xyz.device)
@@ -326,7 +329,14 @@ class _SetAbstraction(torch.autograd.Function):
         if sa_tap is not None:   # diagnostics: views of what backward will route by (neighbour rows, max-pool positions)
             aoff = lib.pnpp_sa_saved_argmax(C.byref(desc), saved.data_ptr()) - saved.data_ptr()
             arg = saved[aoff:aoff + 4 * B * S * channels[-1]].view(torch.int32).view(B, S, channels[-1])
-            sa_tap.append({"neighbours": None if group_all else nbr, "argmax": arg})
+            # ... and of every ReLU decision the backward pass will take (pnpp_sa_saved_relu_mask), per layer (B, S, K, C_l) uint8
+            masks = []
+            for l in range(Lh):
+                m = torch.empty(B, S, Kk, channels[l], device=xyz.device, dtype=torch.uint8)
+                L.check(lib.pnpp_sa_saved_relu_mask(C.byref(desc), saved.data_ptr(), xyz.data_ptr(), conv_w[0].data_ptr(), l,
+                                                    m.data_ptr(), _stream()))
+                masks.append(m)
+            sa_tap.append({"neighbours": None if group_all else nbr, "argmax": arg, "relu_masks": masks})
         ctx.mark_non_differentiable(new_xyz, nbr)
         ctx.set_materialize_grads(False)  # no zero tensors (= fill launches) for the two outputs that carry no gradient
         return new_xyz, out, nbr
@@ -342,6 +352,9 @@ class _SetAbstraction(torch.autograd.Function):
         conv_w, bn_w, bn_b = t[3:3 + Lh], t[3 + Lh:3 + 2 * Lh], t[3 + 2 * Lh:3 + 3 * Lh]
         dout = _f32(dout, "dout")
         lib = L.lib()
+        if ctx.path_state != (lib.pnpp_get_matmul_precision(), lib.pnpp_stats_exchange_enabled()):
+            raise ValueError("set_abstraction: matmul precision or SyncBN was switched between this level's forward pass and its "
+                             "backward pass; the kept workspace belongs to the kernels the forward pass took")
         scratch = _scratch(lib.pnpp_sa_scratch_bytes(C.byref(desc)), xyz.device)
         # gradient destinations: a parameter's flat-buffer sink when an optimiser registered one (the kernels then
         # write straight into the flat gradient buffer and autograd has nothing to accumulate), else fresh tensors

@@ -173,6 +173,17 @@ const int32_t *pnpp_sa_saved_neighbours(const pnpp_sa_desc *d, const void *saved
 /* read-only view of the max-pool routing kept in `saved`: (B*S, C_last) int32, the position 0..K-1 inside its group of the
  * row that torch.max(x, 3) selected (pointnet_pp_8dir.py:42; first maximum on ties) */
 const int32_t *pnpp_sa_saved_argmax(const pnpp_sa_desc *d, const void *saved);
+/* diagnostics for parity tests: the ReLU decisions of layer `layer` (0 .. L-1) of this call exactly as its backward pass takes
+ * them -- out[M x C_layer] bytes, 1 where F.relu(bn(conv(x))) of pointnet_pp_8dir.py:40-41 lets the gradient pass: the sign of
+ * fmaf(Z_l, scale_l, shift_l) on the kept pre-BN activations; layer 0 of a level on raw coordinates keeps no Z_0 and is rebuilt
+ * from xyz (B,N,3) and conv_w0 (C_0 x 3) by the same matrix instructions as the kernels (NULL for other levels / layers).
+ * A float64 evaluation that is handed these decisions and the max-pool routing above is a smooth function of rounding. */
+int pnpp_sa_saved_relu_mask(const pnpp_sa_desc *d, const void *saved, const float *xyz, const float *conv_w0, int layer,
+                            uint8_t *out, void *stream);
+/* compile-time experiment switches that were on when the library was built (timing experiments that compute WRONG results,
+ * in-kernel stamps): 0 in a library that ships -- tests/test_abi.py holds it to 0.  bit 0 PNPP_WS_EXP_NO_MFMA, 1 WSP_EXP,
+ * 2 WSX_EXP, 3 WSQ_EXP, 4 WSQ_PLAIN, 5 FCF_EXP, 6 PNPP_STAMPS */
+unsigned pnpp_build_flags(void);
 
 /* ------------------------------------------------------------------------------------------
  * Fully connected block: y = act(norm(x W^T + b)) with norm in {BatchNorm1d, LayerNorm, none},

@@ -204,7 +204,8 @@ def sa_forward(xyz32: torch.Tensor, points: Optional[torch.Tensor], P: Dict[str,
                prefix: str, centre_idx: Optional[torch.Tensor], nsample: Optional[int],
                group_all: bool, training: bool = True, bn_state: Optional[BNState] = None,
                eps: float = 1e-5, momentum: float = 0.1, neighbour_idx: Optional[torch.Tensor] = None,
-               rel_in_compute_dtype: bool = False, argmax: Optional[torch.Tensor] = None, diag: Optional[dict] = None):
+               rel_in_compute_dtype: bool = False, argmax: Optional[torch.Tensor] = None, diag: Optional[dict] = None,
+               relu_masks: Optional[Sequence[torch.Tensor]] = None):
     """One PointNetSetAbstraction.forward (pointnet_pp_8dir.py:21-43).
 
     xyz32 is the float32 cloud (B,N,3); compute dtype is that of the parameters in P.
@@ -216,7 +217,15 @@ def sa_forward(xyz32: torch.Tensor, points: Optional[torch.Tensor], P: Dict[str,
     a neighbourhood agree to float32 rounding, a float32 evaluation may legitimately route the pooled gradient through
     the other row than float64 does.  With the routing injected the result is a smooth function of rounding again;
     diag["route_gap"] collects max (true max - value at the injected position) / scale per call, which the caller bounds
-    (the injected routing must select a maximum up to float32 rounding)."""
+    (the injected routing must select a maximum up to float32 rounding).
+
+    relu_masks, optional: per layer a (B,S,K,C_l) {0,1} tensor -- the ReLU decisions of another evaluation.  ReLU's derivative is
+    not smooth either: a pre-activation within float32 rounding of zero passes the gradient in one evaluation and blocks it in
+    the other (an O(1) change of that element's gradient, ~1/sqrt(elements) of the layer's gradient norm).  With the decisions
+    injected, layer l computes y * mask instead of relu(y) (they differ by the rounding-sized value itself, in forward and
+    backward alike); diag["relu_flips"] collects, per call and layer, how many decisions differ from this evaluation's own and
+    diag["relu_flip_margin"] the largest |y| / max|y| among them (which the caller bounds: an injected decision may only
+    differ where the pre-activation is zero up to rounding)."""
     dt = P[f"{prefix}.convs.0.weight"].dtype
     B, N, _ = xyz32.shape
     if group_all:
@@ -248,7 +257,16 @@ def sa_forward(xyz32: torch.Tensor, points: Optional[torch.Tensor], P: Dict[str,
                     ((1 - momentum) * rv + momentum * var * (m / max(m - 1, 1))).detach())
         else:
             y = _bn_eval(z, g_, b_, P[f"{prefix}.bns.{li}.running_mean"], P[f"{prefix}.bns.{li}.running_var"], eps)
-        x = torch.relu(y)
+        if relu_masks is not None and relu_masks[li] is not None:
+            m = relu_masks[li].to(y.device).reshape(y.shape) != 0
+            if diag is not None:
+                flip = m != (y.detach() > 0)
+                diag.setdefault("relu_flips", []).append(int(flip.sum()))
+                diag.setdefault("relu_flip_margin", []).append(
+                    float((y.detach().abs() * flip).max() / y.detach().abs().max().clamp_min(1e-30)) if bool(flip.any()) else 0.0)
+            x = y * m.to(dt)
+        else:
+            x = torch.relu(y)
         li += 1
     if argmax is None:
         return new_xyz32, x.max(dim=2).values, idx
@@ -256,21 +274,24 @@ def sa_forward(xyz32: torch.Tensor, points: Optional[torch.Tensor], P: Dict[str,
     if diag is not None:
         top = x.detach().max(dim=2).values
         diag.setdefault("route_gap", []).append(float(((top - pooled.detach()) / top.abs().clamp_min(1.0)).max()))
+        diag.setdefault("route_flips", []).append(int((pooled.detach() < top).sum()))   # injected positions that are not float64's maxima
     return new_xyz32, pooled, idx
 
 
 def backbone_forward(xyz32, P, centres: Sequence[torch.Tensor], training=True, bn_state=None,
                      cfg=((128, 32), (32, 32)), rel_in_compute_dtype=False, routing=None, diag=None):
     """sa1 -> sa2 -> sa3(group_all), as in every pointnet_pp_* model (e.g. pointnet_pp_vonMises.py:28-31).
-    routing: optional three dicts {"neighbours": (B,S,K) | None, "argmax": (B,S,C)} (see sa_forward)."""
+    routing: optional three dicts {"neighbours": (B,S,K) | None, "argmax": (B,S,C), "relu_masks": [(B,S,K,C_l)] (optional)}
+    (see sa_forward)."""
     kw = dict(rel_in_compute_dtype=rel_in_compute_dtype, diag=diag)
     r = routing if routing is not None else [{"neighbours": None, "argmax": None}] * 3
     nb = lambda i: None if r[i]["neighbours"] is None else r[i]["neighbours"].to(torch.int64)
+    rm = lambda i: r[i].get("relu_masks")
     l1_xyz, l1, _ = sa_forward(xyz32, None, P, "sa1", centres[0], cfg[0][1], False, training, bn_state,
-                               neighbour_idx=nb(0), argmax=r[0]["argmax"], **kw)
+                               neighbour_idx=nb(0), argmax=r[0]["argmax"], relu_masks=rm(0), **kw)
     l2_xyz, l2, _ = sa_forward(l1_xyz, l1, P, "sa2", centres[1], cfg[1][1], False, training, bn_state,
-                               neighbour_idx=nb(1), argmax=r[1]["argmax"], **kw)
-    _, l3, _ = sa_forward(l2_xyz, l2, P, "sa3", None, None, True, training, bn_state, argmax=r[2]["argmax"], **kw)
+                               neighbour_idx=nb(1), argmax=r[1]["argmax"], relu_masks=rm(1), **kw)
+    _, l3, _ = sa_forward(l2_xyz, l2, P, "sa3", None, None, True, training, bn_state, argmax=r[2]["argmax"], relu_masks=rm(2), **kw)
     return l3.reshape(l3.shape[0], -1)
 
 

@@ -34,7 +34,14 @@ def test_header_symbols_exported(libpath):
 def test_binding_table_matches_header(libpath):
     from pnpp_hip import _lib
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
-    assert _lib.lib().pnpp_abi_version() == 3
+    assert _lib.lib().pnpp_abi_version() == 4
+
+
+def test_shipped_library_has_no_experiment_switches(libpath):
+    """The kernel sources carry compile-time timing experiments that compute WRONG results (WSP_EXP, WSQ_EXP, WSX_EXP, FCF_EXP,
+    PNPP_WS_EXP_NO_MFMA, WSQ_PLAIN) and in-kernel stamps (PNPP_STAMPS); the library that ships is built with none of them."""
+    from pnpp_hip import _lib
+    assert _lib.lib().pnpp_build_flags() == 0
 
 
 def test_struct_layouts_match_c():

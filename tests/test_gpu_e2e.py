@@ -3,13 +3,16 @@ fp64 oracle (itself pinned to the fp64 run of the reference, tests/test_oracle_g
 reference's randperm centre draws and dropout mask injected.
 
   G3  |loss_hip - loss_fp64| <= 1e-5
-  G4  flat-gradient relative L2 error vs fp64 <= 3e-3 and no worse than the CPU fp32 path's own error
+  G4  flat-gradient relative L2 error vs fp64 <= 3e-3 when no discrete decision (max-pool route, ReLU) differs from float64's own,
+      and <= ROUTED_GATE against float64 handed the HIP path's decisions, always
 """
 import math
 
 import numpy as np
 import pytest
 import torch
+
+from conftest import FLIP_MARGIN, ROUTE_GAP, ROUTED_GATE, tap_to_routing
 
 pytestmark = pytest.mark.gpu
 
@@ -55,10 +58,23 @@ def test_vonmises_loss_and_grads(oracle, golden, B):
     centres = oracle.replay_centres(B)
     mask = (torch.rand(B, 256, generator=torch.Generator().manual_seed(8)) < 0.5).to(torch.uint8)
 
-    mu, kappa = model(xyz.cuda(), centres=[c.cuda() for c in centres], drop_mask=mask.cuda())
+    ops.sa_tap = []
+    try:
+        mu, kappa = model(xyz.cuda(), centres=[c.cuda() for c in centres], drop_mask=mask.cuda())
+        routing = tap_to_routing(ops.sa_tap)
+    finally:
+        ops.sa_tap = None
     lv = ops.kl_von_mises_single(mu, kappa, mu_gt.cuda(), kappa_gt.cuda())
     loss = lv.mean()
     loss.backward()
+
+    # float64 handed every discrete decision of the HIP path's backbone (max-pool routing, ReLU decisions): smooth in rounding
+    P64r, diag = oracle.cast_params(state, torch.float64), {}
+    mu64r, kap64r = oracle.vonmises_forward(xyz, P64r, centres, mask.float(), True, None, routing=routing, diag=diag)
+    oracle.kl_single(mu64r, kap64r, mu_gt.double(), kappa_gt.double()).mean().backward()
+    differ = sum(diag["relu_flips"]) + sum(diag["route_flips"])
+    e_routed = _flat_err(model, P64r, ZERO_GRAD)
+    assert max(diag["route_gap"]) <= ROUTE_GAP and max(diag["relu_flip_margin"]) <= FLIP_MARGIN, diag
 
     P64 = oracle.cast_params(state, torch.float64)
     st = oracle.BNState()
@@ -78,14 +94,16 @@ def test_vonmises_loss_and_grads(oracle, golden, B):
     # ("same three at B=4"), there the bound is the CPU fp32 path's own distance, 1e-4.
     assert d_hip <= (1e-5 if B >= 32 else 1e-4)
     assert float((mu.detach().cpu().double() - mu64.detach()).abs().max()) < 1e-4
-    # G4 with the path's OWN max-pool routing.  The flat gradient of the backbone is NOT a smooth function of rounding:
-    # max-over-nsample routes each pooled gradient to ONE row, and whenever two candidates are within float32 rounding a
-    # float32 evaluation may pick the other row than float64 does -- an O(1) change in that element, measured 7e-3 ... 8.4e-3
-    # of the flat L2 norm when one such flip happens on this input (without one: 1.2e-4 at B=8, 1.2e-3 at B=32).  So this
-    # gate is "at most one flip", 1e-2; the UNCONDITIONAL 3e-3 gate is the routed one (float64 evaluated with the HIP
-    # routing injected: tests/test_gpu_fullsize.py::test_vonmises_config1_routed_gradient_and_eval, same config), and the
-    # head, which sits behind no arg-max, is held to the tight bound below.  e_cpu is printed as a diagnostic only.
-    assert e_hip <= 1e-2, (e_hip, e_cpu)
+    # G4.  The flat gradient of the backbone is NOT a smooth function of rounding: max-over-nsample routes each pooled gradient to ONE
+    # row and ReLU passes or blocks each element, and wherever a float32 evaluation sits within rounding of such a tie it may decide the
+    # other way than float64 does -- an O(1) change of that element (a max-pool route: up to 8e-3 of the flat L2 norm; a ReLU decision:
+    # 5e-4 ... 1e-3 of its tensor's).  The differing decisions are COUNTED (diag: float64 evaluated with the HIP path's decisions
+    # injected): with none, G4's 3e-3 holds on float64's own decisions; otherwise 1e-2 -- and in every case the gradient agrees with
+    # the decision-injected float64 to ROUTED_GATE, which is the gate that bounds the kernels' arithmetic.  e_cpu is a diagnostic only.
+    print(f"[B={B}] {differ} backbone decisions differ from float64's own ({sum(diag['relu_flips'])} ReLU, {sum(diag['route_flips'])} max-pool); "
+          f"flat gradient relL2 vs decision-injected fp64 {e_routed:.2e}")
+    assert e_routed <= ROUTED_GATE * (1 if B >= 32 else 2), e_routed       # measured 9.3e-6 (B = 32) / 1.5e-5 (B = 8: BatchNorm1d over 8 samples is worse conditioned)
+    assert e_hip <= (3e-3 if differ == 0 else 1e-2), (e_hip, e_cpu, differ)
     for n in ("fc1.weight", "fc2.weight", "fc3.weight", "fc3.bias", "bn1.weight", "bn2.bias"):
         p = dict(model.named_parameters())[n]
         ref = P64[n].grad.reshape(p.shape)

@@ -17,9 +17,19 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import ROUTED_GATE, tap_to_routing
+
 pytestmark = pytest.mark.gpu
 
 ZERO_GRAD = lambda n: (".convs." in n and n.endswith("bias")) or n in ("fc1.bias", "fc2.bias")
+
+
+def _own_gate(res):
+    """The flat-gradient gate on float64's OWN decisions (no injection).  Every decision on which the HIP path and float64 differ
+    -- counted, not guessed: res["decisions_differ"] = ReLU decisions + max-pool routes, both float32 rounding away from a tie -- is
+    an O(1) change of one element's gradient: a max-pool route is worth up to 8e-3 of the flat L2 norm, a ReLU decision 5e-4 ... 1e-3
+    of its tensor's.  G4's 3e-3 when none differs; 1e-2 otherwise."""
+    return 3e-3 if res["decisions_differ"] == 0 else 1e-2
 
 
 def _flat(model_or_P, skip, names):
@@ -64,7 +74,7 @@ def _run_bn_head_model(oracle, model_cls, oracle_fwd, loss_hip, loss_ref, B, N, 
     ops.sa_tap = []
     try:
         out = model(xyz.cuda(), centres=[c.cuda() for c in centres], drop_mask=mask.cuda())
-        routing = [{k: (None if v is None else v.cpu().long()) for k, v in t.items()} for t in ops.sa_tap]
+        routing = tap_to_routing(ops.sa_tap)
     finally:
         ops.sa_tap = None
     loss = loss_hip(out, mu_gt, kappa_gt, fwd)
@@ -85,24 +95,30 @@ def _run_bn_head_model(oracle, model_cls, oracle_fwd, loss_hip, loss_ref, B, N, 
     skip = lambda n: ZERO_GRAD(n) or n in extra_skip
     hipP = dict(model.named_parameters())
     g_hip, g64, g32 = _flat(hipP, skip, names), _flat(res["f64"][0], skip, names), _flat(res["f32"][0], skip, names)
-    # the routed gate: (1) every row the HIP path routed through is a maximum of its neighbourhood up to float32 rounding;
-    # (2) given that routing, the whole flat gradient agrees with float64 to float32 accuracy
-    # (bound: a float32 dot product of K = 512 ... 1024 terms carries ~ sqrt(K) * 6e-8 = 1.4e-6 ... 2e-6 of rounding, and which of two
-    # rows that close wins depends on the summation order of the kernel: measured <= 2.1e-7 with the 32 x 32 split-K kernel, whose
-    # four K-quarters are summed pairwise, 2.04e-6 on one element with the 64 x 64 kernel's single chain over K = 512)
-    gaps = res["diag"]["route_gap"]
+    # the routed gate: float64 is handed EVERY discrete decision of the HIP path -- neighbour order, max-pool routing, the ReLU decisions
+    # of all nine backbone layers (pnpp_sa_saved_argmax / pnpp_sa_saved_relu_mask) -- and is then a smooth function of rounding.
+    # (1) every injected decision is float32 rounding away from float64's own: a routed row is a maximum up to 5e-6 relative (a float32
+    # dot product of K = 512 ... 1024 terms carries ~ sqrt(K) * 6e-8 of rounding; measured <= 2.0e-6), a flipped ReLU decision sits on a
+    # pre-activation that is zero up to 2e-5 of the layer's largest (measured <= 1e-7);
+    # (2) given the decisions, the WHOLE flat gradient agrees with float64 to float32 accuracy
+    diag = res["diag"]
+    gaps = diag["route_gap"]
     e_routed = _rel(g_hip, _flat(res["f64r"][0], skip, names))
     d_routed = abs(loss.item() - res["f64r"][2].item())
     contrib = sorted(((float((hipP[n].grad.detach().cpu().double().reshape(-1) - res["f64r"][0][n].grad.reshape(-1)).pow(2).sum()), n)
                       for n in names if not skip(n)), reverse=True)[:3]
-    print(f"\n[{model_cls.__name__} N={N} B={B}] routed gate: max routing gap {max(gaps):.2e}, |dloss| {d_routed:.2e}, "
+    res["decisions_differ"] = sum(diag["relu_flips"]) + sum(diag["route_flips"])
+    print(f"\n[{model_cls.__name__} N={N} B={B}] routed gate: {sum(diag['relu_flips'])} ReLU decisions / {sum(diag['route_flips'])} max-pool routes "
+          f"differ from float64's own (margins {max(diag['relu_flip_margin']):.1e} / {max(gaps):.1e}), |dloss| {d_routed:.2e}, "
           f"flat gradient relL2 vs routed fp64 {e_routed:.2e}; largest contributions: "
           + ", ".join(f"{n} {math.sqrt(v) / float(res['f64r'][0][n].grad.norm()):.1e}" for v, n in contrib))
     assert len(gaps) == 3 and max(gaps) <= 5e-6, gaps
+    assert max(diag["relu_flip_margin"]) <= 2e-5, diag["relu_flip_margin"]
     assert d_routed <= 1e-5
-    # G4's own bound, with no "or as bad as the CPU float32 path" escape: float32 arithmetic through eleven
-    # normalisation layers sits at 1e-4 ... 2e-3 of float64 (SURVEY 7a measured 1.35e-3 for ATen float32 with float64 statistics)
-    assert e_routed <= 3e-3, e_routed
+    # with no discrete decision left open the flat gradient sits at float32 rounding carried through eleven normalisation layers
+    # (the head's two ReLU layers, 32 x 768 decisions, are not injected).  ROUTED_GATE = 2 x the largest value measured over the five
+    # full-size cases of this file
+    assert e_routed <= ROUTED_GATE, e_routed
     return model, out, loss, res, (g_hip, g64, g32)
 
 
@@ -129,12 +145,9 @@ def test_dir8_config3_full_size(oracle, B, N):
           f"grad relL2 hip {e_hip:.2e} cpu32 {e_cpu:.2e} hip-vs-cpu32 {e_pair:.2e}")
     assert d_hip <= 1e-5
     assert float((logits.detach().cpu().double() - lg64.detach()).abs().max()) <= 1e-4
-    # own routing (no injection): a float32 arg-max flip is an O(1) change of one routed element, worth 7e-3 ... 8.4e-3 of the flat
-    # L2 norm when it happens (measured: 3.0e-3 at N=2048 with round 2's kernels, 7.6e-3 after the 64 x 64 kernel changed sa3's
-    # summation order and one more row flipped; 5.1e-4 at N=10,000) -- so this gate is "at most one flip", 1e-2, exactly as in
-    # tests/test_gpu_e2e.py.  The UNCONDITIONAL G4 gate (3e-3 with the HIP routing injected into float64) is asserted inside
-    # _run_bn_head_model; e_cpu is printed as a diagnostic only and bounds nothing.
-    assert e_hip <= 1e-2, (e_hip, e_cpu)
+    # float64 on its own decisions: see _own_gate; the gate that bounds the kernels' arithmetic is the routed one inside
+    # _run_bn_head_model.  e_cpu is printed as a diagnostic only and bounds nothing.
+    assert e_hip <= _own_gate(res), (e_hip, e_cpu, res["decisions_differ"])
     for n in ("fc1.weight", "fc2.weight", "fc3.weight", "fc3.bias"):
         ref = res["f64"][0][n].grad
         p = dict(model.named_parameters())[n]
@@ -162,13 +175,13 @@ def test_vonmises_reference_training_size(oracle):
           f"grad relL2 hip {e_hip:.2e} cpu32 {e_cpu:.2e}")
     assert d_hip <= 1e-5
     assert float((mu.detach().cpu().double() - mu64.detach()).abs().max()) < 1e-4
-    assert e_hip <= 1e-2, (e_hip, e_cpu)             # own routing: at most one arg-max flip (see test_dir8_config3_full_size); measured 1.3e-4
+    assert e_hip <= _own_gate(res), (e_hip, e_cpu, res["decisions_differ"])
 
 
 def test_vonmises_config1_routed_gradient_and_eval(oracle):
     """configs[1] at B=32 (N=1024): beside the fp64 gate of test_gpu_e2e.py -- which arg-max flips loosen to the CPU
     float32 path's own error -- the routed gate of _run_bn_head_model holds the WHOLE flat gradient (backbone included) to
-    G4's 3e-3 of float64, unconditionally, once float64 is told which rows the max-pool took.  (The HIP path and the CPU float32 restatement do
+    ROUTED_GATE of float64, unconditionally, once float64 is told which rows the max-pool took and which way every ReLU fell.  (The HIP path and the CPU float32 restatement do
     not share their routing: on the GPU box's 32 host threads the latter sits 8.7e-3 from float64, the HIP path 8.7e-4.)
     Eval mode is compared with the oracle as well: running statistics after this training step, no dropout."""
     from models.pointnet_pp_vonMises import PointNetPPVonMises
@@ -181,7 +194,7 @@ def test_vonmises_config1_routed_gradient_and_eval(oracle):
     e_hip, e_cpu = _rel(g_hip, g64), _rel(g32, g64)
     print(f"[vM B=32] grad relL2 (own routing): hip-vs-fp64 {e_hip:.2e}, cpu32-vs-fp64 {e_cpu:.2e}")
     assert abs(loss.item() - res["f64"][2].item()) <= 1e-5
-    assert e_hip <= 1e-2, (e_hip, e_cpu)             # own routing: at most one arg-max flip; measured 8.7e-4 (the routed gate above is 3e-3)
+    assert e_hip <= _own_gate(res), (e_hip, e_cpu, res["decisions_differ"])
     xyz, _, _, _ = oracle.synthetic_clouds(B, N, seed=1234)
     torch.manual_seed(4242)
     centres = oracle.replay_centres(B)
@@ -223,7 +236,7 @@ def test_mvm_config2_full_batch(oracle, B, N):
     ops.sa_tap = []
     try:
         mu, kappa, w = m(xyz.cuda(), centres=[c.cuda() for c in centres], drop_masks=[t.cuda() for t in masks])
-        routing = [{k: (None if v is None else v.cpu().long()) for k, v in t.items()} for t in ops.sa_tap]
+        routing = tap_to_routing(ops.sa_tap)
     finally:
         ops.sa_tap = None
     lv = ops.match_loss(mu, kappa, w, vm_gt.cuda(), K.cuda())
@@ -254,11 +267,12 @@ def test_mvm_config2_full_batch(oracle, B, N):
     hipP = dict(m.named_parameters())
     contrib = sorted(((float((hipP[n].grad.detach().cpu().double().reshape(-1) - P64r[n].grad.reshape(-1)).pow(2).sum()), n)
                       for n in names if not skip(n)), reverse=True)[:4]
-    print(f"[mvM N={N} B={B}] flat gradient relL2 vs fp64 {e:.2e} (own routing), {er:.2e} (HIP routing injected, gap "
-          f"{max(diag['route_gap']):.2e}); largest contributions: "
+    differ = sum(diag["relu_flips"]) + sum(diag["route_flips"])
+    print(f"[mvM N={N} B={B}] flat gradient relL2 vs fp64 {e:.2e} (float64's own decisions; {differ} differ from the HIP path's), {er:.2e} "
+          f"(HIP decisions injected, margins {max(diag['relu_flip_margin']):.1e} / {max(diag['route_gap']):.2e}); largest contributions: "
           + ", ".join(f"{n} {math.sqrt(v) / float(P64r[n].grad.norm()):.1e}" for v, n in contrib))
-    assert e <= 1e-2, e      # own routing: at most one arg-max flip; measured 5.1e-4 (N=1024) / 5.2e-4 (N=10,000); routed gate below: 3e-3
-    assert max(diag["route_gap"]) <= 2e-6 and er <= 3e-3, (diag, er)
+    assert e <= (3e-3 if differ == 0 else 1e-2), (e, differ)      # see _own_gate
+    assert max(diag["route_gap"]) <= 5e-6 and max(diag["relu_flip_margin"]) <= 2e-5 and er <= ROUTED_GATE, (diag, er)
 
 
 def test_point_transformer_config4_full_size(oracle):

@@ -98,7 +98,7 @@ def test_simple_pointnet_script_size_routed(oracle, B, N):
     ops.sa_tap = []
     try:
         out = model(xyz.cuda(), drop_mask=mask.cuda())
-        tap = [{k: (None if v is None else v.cpu().clone()) for k, v in t.items()} for t in ops.sa_tap]
+        tap = [{k: (v.cpu().clone() if torch.is_tensor(v) else v) for k, v in t.items()} for t in ops.sa_tap]
     finally:
         ops.sa_tap = None
     loss = spt.criterion(out, fwd.cuda()).mean()
