@@ -120,7 +120,7 @@ def test_simple_pointnet_script_size_routed(oracle, B, N):
     rel = math.sqrt(num / den)
     print(f"\n[simple B={B} N={N}] loss hip {float(loss):.8f} fp64 {float(l64):.8f} routed flat-grad relL2 {rel:.2e} "
           f"route gap {max(diag['route_gap']):.1e}")
-    assert rel <= 3e-3
+    assert rel <= 5e-5        # measured 2.7e-6 (10,000 points x 16) / 8.1e-6 (777 x 3); round 3 gated this at 3e-3
 
 
 def test_simple_pointnet_script_trains(tmp_path, monkeypatch, capsys):
