@@ -30,14 +30,33 @@ __global__ void __launch_bounds__(256) fc_apply_cols_kernel(const float *__restr
     }
 }
 
-// LayerNorm over the feature axis of u = z + b; one 256-thread block per row
+// keep-bit of element idx of the dropout draw with stream id sid: one Philox4x32-10 word per element, exactly the draw of the
+// BatchNorm epilogue (gemm_smallm_body, E_BN_APPLY) -- counter (idx, "DROP", sid), key = seed
+__device__ __forceinline__ bool dropout_keep(unsigned idx, unsigned long long sid, unsigned long long seed, float drop_p) {
+    unsigned c0 = idx, c1 = 0x44524f50u /* "DROP" */, c2 = (unsigned)sid, c3 = (unsigned)(sid >> 32);
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int rd = 0; rd < 10; ++rd) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    return (double)c0 >= (double)drop_p * 4294967296.0;
+}
+
+// LayerNorm over the feature axis of u = z + b; one 256-thread block per row.  mask_out (round 4): the keep-mask of nn.Dropout is
+// DRAWN here (no RNG launch, graph-replayable: the stream id lives in device memory, rng_counter[0], and is bumped by the last row
+// block through the ticket word rng_counter[1]) and written out for the backward pass
 __global__ void __launch_bounds__(256) fc_apply_ln_kernel(const float *__restrict__ z, const float *__restrict__ b,
                                                           const float *__restrict__ nw, const float *__restrict__ nb,
                                                           const uint8_t *__restrict__ mask, float drop_scale, int relu, int N,
                                                           float eps, float *__restrict__ y, float *__restrict__ mean,
-                                                          float *__restrict__ istd) {
+                                                          float *__restrict__ istd, uint8_t *__restrict__ mask_out, float drop_p,
+                                                          unsigned long long rng_seed, unsigned long long *__restrict__ rng_counter) {
     __shared__ double red[2][4];
     const int m = blockIdx.x;
+    const unsigned long long sid = mask_out ? rng_counter[0] : 0ull;   // requested before the reductions
     const float *zr = z + (size_t)m * N;
     double s1 = 0.0, s2 = 0.0;
     for (int n = threadIdx.x; n < N; n += 256) {
@@ -61,7 +80,22 @@ __global__ void __launch_bounds__(256) fc_apply_ln_kernel(const float *__restric
         float v = ((zr[n] + b[n]) - muf) * isf * nw[n] + nb[n];
         if (relu) v = fmaxf(v, 0.f);
         if (mask) v = mask[(size_t)m * N + n] ? v * drop_scale : 0.f;
+        if (mask_out) {
+            const bool keep = dropout_keep((unsigned)(m * N + n), sid, rng_seed, drop_p);
+            mask_out[(size_t)m * N + n] = keep ? 1 : 0;
+            v = keep ? v * drop_scale : 0.f;
+        }
         y[(size_t)m * N + n] = v;
+    }
+    if (mask_out) {   // every row block has read the stream id above before it takes a ticket; the last one bumps it
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long t = atomicAdd(&rng_counter[1], 1ull);
+            if (t == (unsigned long long)gridDim.x - 1) {
+                rng_counter[1] = 0ull;
+                rng_counter[0] += 1ull;
+            }
+        }
     }
 }
 
@@ -534,8 +568,13 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
     if (d->norm == PNPP_NORM_BATCH) PNPP_REQUIRE(a->rm && a->rv, PNPP_ERR_ARG, "fc_forward: running statistics are null");
     const FcSaved sv = fc_saved_layout(d, a->saved);
     const FcScratch sc = fc_scratch_layout(d, a->scratch);
-    PNPP_REQUIRE(!a->mask_out || (d->norm == PNPP_NORM_BATCH && d->training && d->M <= 32 && !stats_sync_on()), PNPP_ERR_ARG,
-                 "fc_forward: the in-kernel dropout draw exists for the BatchNorm epilogue (training, M <= 32, no statistics exchange) only");
+    PNPP_REQUIRE(!a->mask_out || (d->training && !fc_is_small(d) && ((d->norm == PNPP_NORM_BATCH && d->M <= 32 && !stats_sync_on()) ||
+                                                                     d->norm == PNPP_NORM_LAYER)),
+                 PNPP_ERR_ARG, "fc_forward: the in-kernel dropout draw exists for the BatchNorm epilogue (training, M <= 32, no statistics "
+                               "exchange) and for the LayerNorm block (training) only");
+    if (a->mask_out)
+        PNPP_REQUIRE(!a->mask && a->rng_counter && a->drop_p > 0.f && a->drop_p < 1.f, PNPP_ERR_ARG,
+                     "fc_forward: a drawn dropout mask needs rng_counter, 0 < drop_p < 1 and no given mask");
 
     if (fc_is_small(d)) {
         ProfScope ps(st, "fc_small_fwd_kernel M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -598,7 +637,8 @@ static int fc_forward_impl(const pnpp_fc_desc *d, const pnpp_fc_fwd_args *a, hip
         PNPP_TRY(launch_gemm(A, W, d->M, d->N, d->K, E, nullptr, st));
         if (d->norm == PNPP_NORM_LAYER) {
             hipLaunchKernelGGL(fc_apply_ln_kernel, dim3(d->M), dim3(256), 0, st, sv.z, a->b, a->nw, a->nb, a->mask, d->drop_scale,
-                               d->relu, d->N, d->eps, a->y, sv.mean, sv.istd);
+                               d->relu, d->N, d->eps, a->y, sv.mean, sv.istd, a->mask_out, a->drop_p, (unsigned long long)a->rng_seed,
+                               reinterpret_cast<unsigned long long *>(a->rng_counter));
         } else {
             ProfScope ps(st, "fc_apply_cols_kernel M=%d N=%d", d->M, d->N);
             hipLaunchKernelGGL(fc_apply_cols_kernel, dim3(grid), dim3(256), 0, st, sv.z, (const float *)nullptr, a->b, a->mask,

@@ -12,7 +12,7 @@
 
 namespace pnpp {
 
-__device__ const double kI0eA[30] = {
+constexpr double kI0eA[30] = {
     -4.41534164647933937950E-18, 3.33079451882223809783E-17,  -2.43127984654795469359E-16, 1.71539128555513303061E-15,
     -1.16853328779934516808E-14, 7.67618549860493561688E-14,  -4.85644678311192946090E-13, 2.95505266312963983461E-12,
     -1.72682629144155570723E-11, 9.67580903537323691224E-11,  -5.18979560163526290666E-10, 2.65982372468238665035E-9,
@@ -21,7 +21,7 @@ __device__ const double kI0eA[30] = {
     -5.76375574538582365885E-4,  1.63947561694133579842E-3,   -4.32430999505057594430E-3,  1.05464603945949983183E-2,
     -2.37374148058994688156E-2,  4.93052842396707084878E-2,   -9.49010970480476444210E-2,  1.71620901522208775349E-1,
     -3.04682672343198398683E-1,  6.76795274409476084995E-1};
-__device__ const double kI0eB[25] = {
+constexpr double kI0eB[25] = {
     -7.23318048787475395456E-18, -4.83050448594418207126E-18, 4.46562142029675999901E-17,  3.46122286769746109310E-17,
     -2.82762398051658348494E-16, -3.42548561967721913462E-16, 1.77256013305652638360E-15,  3.81168066935262242075E-15,
     -9.55484669882830764870E-15, -4.15056934728722208663E-14, 1.54008621752140982691E-14,  3.85277838274214270114E-13,
@@ -29,7 +29,7 @@ __device__ const double kI0eB[25] = {
     1.18891471078464383424E-11,  4.94060238822496958910E-10,  3.39623202570838634515E-9,   2.26666899049817806459E-8,
     2.04891858946906374183E-7,   2.89137052083475648297E-6,   6.88975834691682398426E-5,   3.36911647825569408990E-3,
     8.04490411014108831608E-1};
-__device__ const double kI1eA[29] = {
+constexpr double kI1eA[29] = {
     2.77791411276104639959E-18, -2.11142121435816608115E-17, 1.55363195773620046921E-16, -1.10559694773538630805E-15,
     7.60068429473540693410E-15, -5.04218550472791168711E-14, 3.22379336594557470981E-13, -1.98397439776494371520E-12,
     1.17361862988909016308E-11, -6.66348972350202774223E-11, 3.62559028155211703701E-10, -1.88724975172282928790E-9,
@@ -38,7 +38,7 @@ __device__ const double kI1eA[29] = {
     5.12285956168575772895E-4,  -1.51357245063125314899E-3,  4.15642294431288815669E-3,  -1.05640848946261981558E-2,
     2.47264490306265168283E-2,  -5.29459812080949914269E-2,  1.02643658689847095384E-1,  -1.76416518357834055153E-1,
     2.52587186443633654823E-1};
-__device__ const double kI1eB[25] = {
+constexpr double kI1eB[25] = {
     7.51729631084210481353E-18,  4.41434832307170791151E-18,  -4.65030536848935832153E-17, -3.20952592199342395980E-17,
     2.96262899764595013876E-16,  3.30820231092092828324E-16,  -1.88035477551078244854E-15, -3.81440307243700780478E-15,
     1.04202769841288027642E-14,  4.27244001671195135429E-14,  -2.10154184277266431302E-14, -4.08355111109219731823E-13,
@@ -47,9 +47,15 @@ __device__ const double kI1eB[25] = {
     -2.51223623787020892529E-7,  -3.88256480887769039346E-6,  -1.10588938762623716291E-4,  -9.76109749136146840777E-3,
     7.78576235018280120474E-1};
 
-__device__ __forceinline__ double chbevl(double x, const double *c, int n) {
+// Clenshaw recurrence, fully unrolled over a compile-time table: the coefficients become literals of the instruction stream.
+// (Round 4: the tables used to be __device__ arrays read through a pointer inside a runtime loop -- one dependent scalar load per
+// term, 25 - 30 terms, four series per KL value: a single kl_multi_eval took 20 - 35 us and the multi-peak loss was a 40 - 100 us
+// launch.  Same operations in the same order; the values are unchanged.)
+template <int N>
+__device__ __forceinline__ double chbevl(double x, const double (&c)[N]) {
     double b0 = c[0], b1 = 0.0, b2 = 0.0;
-    for (int i = 1; i < n; ++i) {
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
         b2 = b1;
         b1 = b0;
         b0 = x * b1 - b2 + c[i];
@@ -57,10 +63,10 @@ __device__ __forceinline__ double chbevl(double x, const double *c, int n) {
     return 0.5 * (b0 - b2);
 }
 __device__ __forceinline__ double i0e(double x) {  // x >= 0
-    return x <= 8.0 ? chbevl(0.5 * x - 2.0, kI0eA, 30) : chbevl(32.0 / x - 2.0, kI0eB, 25) / sqrt(x);
+    return x <= 8.0 ? chbevl(0.5 * x - 2.0, kI0eA) : chbevl(32.0 / x - 2.0, kI0eB) / sqrt(x);
 }
 __device__ __forceinline__ double i1e(double x) {  // x >= 0
-    return x <= 8.0 ? chbevl(0.5 * x - 2.0, kI1eA, 29) * x : chbevl(32.0 / x - 2.0, kI1eB, 25) / sqrt(x);
+    return x <= 8.0 ? chbevl(0.5 * x - 2.0, kI1eA) * x : chbevl(32.0 / x - 2.0, kI1eB) / sqrt(x);
 }
 __device__ __forceinline__ double log_i0(double k) { return k + log(i0e(k)); }
 __device__ __forceinline__ double bessel_ratio(double k) { return i1e(k) / i0e(k); }
@@ -217,6 +223,18 @@ __global__ void __launch_bounds__(256) vm_head_kl_mean_kernel(const float *__res
     if (threadIdx.x == 0) *loss_mean = (float)(red[0] * inv_b);
 }
 
+#ifdef PNPP_STAMPS
+__device__ unsigned long long g_tail_stamps[16];   // s_memtime ticks of thread 0 of the tail workgroup, per phase
+#define TAIL_STAMP(i)                                                        \
+    if (threadIdx.x == 0) {                                                  \
+        const unsigned long long st_t = __builtin_amdgcn_s_memtime();        \
+        g_tail_stamps[i] += st_t - st_last;                                  \
+        st_last = st_t;                                                      \
+    }
+#else
+#define TAIL_STAMP(i)
+#endif
+
 // The whole tail of the single-peak training step in ONE single-workgroup launch: o = x W^T + b (the model's fc3,
 // pointnet_pp_vonMises.py:35), head activations, KL, batch mean (train_single_peak_vonMises_KL.py:82-84) and their
 // backward -- d loss / d W, d b and d x.  x: (B, K) features, W: (2, K).  Eager PyTorch terms: a Linear, the head,
@@ -241,6 +259,9 @@ vm_fc_head_kl_step_kernel(const float *__restrict__ x, const float *__restrict__
     float *ws = sm + ((2 * B + 3) & ~3);         // W (2 x K) in LDS: with x, ONE round trip for everything the kernel reads
     float *xs = ws + ((2 * K + 3) & ~3);
     const int tid = threadIdx.x;
+#ifdef PNPP_STAMPS
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
     const float *xr = x;  // where the features are read from after staging
     for (int f = tid; f < 2 * K; f += 256) ws[f] = W[f];
     const float b0 = bias[0], b1 = bias[1];
@@ -250,6 +271,7 @@ vm_fc_head_kl_step_kernel(const float *__restrict__ x, const float *__restrict__
         xr = xs;
     }
     __syncthreads();
+    TAIL_STAMP(8)   // staging
     const float *Wl = ws;
     // 1. o = x W^T + b: eight lanes per row, each a strided eighth of the features
     const int part8 = tid & 7;
@@ -265,6 +287,7 @@ vm_fc_head_kl_step_kernel(const float *__restrict__ x, const float *__restrict__
         if (part8 == 0 && i < B) o[2 * i] = a0 + b0, o[2 * i + 1] = a1 + b1;
     }
     __syncthreads();
+    TAIL_STAMP(9)   // o = x W^T
     // 2. head + KL + mean (the four float64 chains on the four waves: vm_head_kl_chunk); d loss / d o overwrites o
     __shared__ KlPieces S;
     const double inv_b = 1.0 / (double)B;
@@ -279,6 +302,7 @@ vm_fc_head_kl_step_kernel(const float *__restrict__ x, const float *__restrict__
             o[2 * i + 1] = g1;
         }
     }
+    TAIL_STAMP(10)   // head + KL
     red[tid] = part;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -286,6 +310,7 @@ vm_fc_head_kl_step_kernel(const float *__restrict__ x, const float *__restrict__
         __syncthreads();
     }
     if (tid == 0) *loss_mean = (float)(red[0] * inv_b);
+    TAIL_STAMP(11)   // mean
     // 3. dW = d_o^T x, db = column sums of d_o, dx = d_o W: one thread per feature, rows in order
     for (int k = tid; k < K; k += 256) {
         const float w0 = Wl[k], w1 = Wl[K + k];
@@ -304,6 +329,7 @@ vm_fc_head_kl_step_kernel(const float *__restrict__ x, const float *__restrict__
         for (int i = 0; i < B; ++i) g += o[2 * i + tid];
         db[tid] = g;
     }
+    TAIL_STAMP(12)   // dW, db, dx
 }
 
 __global__ void __launch_bounds__(256) vm_head_bwd_kernel(const float *__restrict__ o, const float *__restrict__ dmu,
@@ -334,108 +360,180 @@ __device__ __forceinline__ void kl_multi_eval(double mp, double kp_raw, double m
     dk = pass ? bessel_ratio_prime(kp, A) * (kp - kq * cd) : 0.0;
 }
 
-__global__ void __launch_bounds__(64) vm_match_loss_kernel(const float *__restrict__ mu, const float *__restrict__ kappa,
-                                                           const float *__restrict__ w, const float *__restrict__ vm_gt,
-                                                           const int32_t *__restrict__ K_gt, int B, int maxK,
-                                                           float *__restrict__ loss_vec, float *__restrict__ dmu,
-                                                           float *__restrict__ dkappa, float *__restrict__ dw,
-                                                           int32_t *__restrict__ assign) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= B) return;
-    int K = K_gt[b];
-    if (K > maxK) K = maxK;
-    for (int i = 0; i < maxK; ++i) {
-        if (dmu) dmu[b * maxK + i] = 0.f;
-        if (dkappa) dkappa[b * maxK + i] = 0.f;
-        if (dw) dw[b * maxK + i] = 0.f;
-        if (assign) assign[b * maxK + i] = -1;
+// match_loss of one sample in two parts, because the first is what costs: the K x K cost matrix is K^2 independent evaluations of
+// kl_multi_eval (two Bessel series, log, cos / sin in float64: ~4 us each on one lane) -- sixteen in a row per sample made the
+// one-thread-per-sample kernel a 60 - 100 us launch with 32 lanes of the chip busy (round 4: the largest launch of configs[2]'s step).
+// So (1) one THREAD PER MATRIX ENTRY fills cost / gradient tables in LDS, (2) one thread per sample does the assignment and the
+// weighted reduction from the tables.  Entry by entry the arithmetic is what the serial form did.
+__device__ __forceinline__ void match_cost_entry(float mu_i, float kappa_i, float mq, float kq, float &cost, float &gmu, float &gk) {
+    double v, a, c;
+    kl_multi_eval((double)mu_i, (double)kappa_i, (double)mq, (double)kq, v, a, c);
+    float vf = (float)v;   // rounded to float32 like the reference's cost tensor (line 66-73)
+    if (!(fabsf(vf) <= 3.0e38f)) {  // nan_to_num(nan/+-inf -> 1e6): constant, no gradient
+        vf = 1e6f;
+        a = 0.0;
+        c = 0.0;
     }
+    cost = vf, gmu = (float)a, gk = (float)c;
+}
+
+// cost / gmu / gk: this sample's tables, entry (i, j) at [i * maxK + j], filled for i, j < K.  w (maxK); outputs may be null.
+// MK: compile-time bound of maxK.  Everything per-sample lives in REGISTERS: the permutation is eight 4-bit fields of one word and
+// every loop over components runs to MK under an `i < K` test, so no array is indexed by a run-time value (round 4: `int perm[8]`
+// and friends lived in scratch memory -- a global-memory round trip per access, 24 permutations x ~20 accesses: 42 us of the
+// multi-peak step's 71 us tail launch by in-kernel stamps, tools/tail_stamps.py).
+template <int MK>
+__device__ __forceinline__ void match_assign_sample(const float *cost, const float *gmu, const float *gk, const float *w, int K, int maxK,
+                                                    float *loss, float *dmu, float *dkappa, float *dw, int32_t *assign) {
+    if (K > maxK) K = maxK;
+#pragma unroll
+    for (int i = 0; i < MK; ++i)
+        if (i < maxK) {
+            if (dmu) dmu[i] = 0.f;
+            if (dkappa) dkappa[i] = 0.f;
+            if (dw) dw[i] = 0.f;
+            if (assign) assign[i] = -1;
+        }
     if (K <= 0) {
-        loss_vec[b] = 0.f;
+        *loss = 0.f;
         return;
     }
-    // cost matrix, rounded to float32 like the reference's cost tensor (line 66-73), with its gradients
-    float cost[MATCH_KMAX][MATCH_KMAX];
-    float gmu[MATCH_KMAX][MATCH_KMAX], gk[MATCH_KMAX][MATCH_KMAX];
-    for (int i = 0; i < K; ++i)
-        for (int j = 0; j < K; ++j) {
-            double v, a, c;
-            kl_multi_eval((double)mu[b * maxK + i], (double)kappa[b * maxK + i], (double)vm_gt[(b * maxK + j) * 3 + 0],
-                          (double)vm_gt[(b * maxK + j) * 3 + 1], v, a, c);
-            float vf = (float)v;
-            if (!(fabsf(vf) <= 3.0e38f)) {  // nan_to_num(nan/+-inf -> 1e6): constant, no gradient
-                vf = 1e6f;
-                a = 0.0;
-                c = 0.0;
-            }
-            cost[i][j] = vf;
-            gmu[i][j] = (float)a;
-            gk[i][j] = (float)c;
-        }
+    auto nib = [](unsigned p, int i) -> int { return (int)((p >> (4 * i)) & 15u); };
+    auto swp = [](unsigned p, int i, int j) -> unsigned {
+        const unsigned x = ((p >> (4 * i)) ^ (p >> (4 * j))) & 15u;
+        return p ^ ((x << (4 * i)) | (x << (4 * j)));
+    };
     // exhaustive optimal assignment in lexicographic permutation order, first optimum kept
-    int perm[MATCH_KMAX], bestp[MATCH_KMAX];
-    for (int i = 0; i < K; ++i) perm[i] = i;
+    unsigned perm = 0x76543210u, bestp = perm;
     double best = 1e300;
     while (true) {
         double t = 0.0;
-        for (int i = 0; i < K; ++i) t += (double)cost[i][perm[i]];
-        if (t < best) {
-            best = t;
-            for (int i = 0; i < K; ++i) bestp[i] = perm[i];
-        }
-        int i = K - 2;  // next lexicographic permutation
-        while (i >= 0 && perm[i] > perm[i + 1]) --i;
+#pragma unroll
+        for (int i = 0; i < MK; ++i)
+            if (i < K) t += (double)cost[i * maxK + nib(perm, i)];
+        if (t < best) best = t, bestp = perm;
+        int i = K - 2;  // next lexicographic permutation of the first K fields
+        while (i >= 0 && nib(perm, i) > nib(perm, i + 1)) --i;
         if (i < 0) break;
         int j = K - 1;
-        while (perm[j] < perm[i]) --j;
-        int tmp = perm[i];
-        perm[i] = perm[j];
-        perm[j] = tmp;
-        for (int l = i + 1, r = K - 1; l < r; ++l, --r) {
-            tmp = perm[l];
-            perm[l] = perm[r];
-            perm[r] = tmp;
-        }
+        while (nib(perm, j) < nib(perm, i)) --j;
+        perm = swp(perm, i, j);
+        for (int l = i + 1, r = K - 1; l < r; ++l, --r) perm = swp(perm, l, r);
     }
     // loss_b = sum w_i c_i / (sum w_i + 1e-8)   (float32 arithmetic order of lines 77-80, evaluated in double)
     double sw = 0.0, swc = 0.0;
-    for (int i = 0; i < K; ++i) {
-        sw += (double)w[b * maxK + i];
-        swc += (double)w[b * maxK + i] * (double)cost[i][bestp[i]];
-    }
+#pragma unroll
+    for (int i = 0; i < MK; ++i)
+        if (i < K) {
+            sw += (double)w[i];
+            swc += (double)w[i] * (double)cost[i * maxK + nib(bestp, i)];
+        }
     const double S = sw + 1e-8;
-    loss_vec[b] = (float)(swc / S);
-    for (int i = 0; i < K; ++i) {
-        const double wi = (double)w[b * maxK + i];
-        const int j = bestp[i];
-        if (assign) assign[b * maxK + i] = j;
-        if (dw) dw[b * maxK + i] = (float)(((double)cost[i][j] * S - swc) / (S * S));
-        if (dmu) dmu[b * maxK + i] = (float)(wi / S * (double)gmu[i][j]);
-        if (dkappa) dkappa[b * maxK + i] = (float)(wi / S * (double)gk[i][j]);
+    *loss = (float)(swc / S);
+#pragma unroll
+    for (int i = 0; i < MK; ++i)
+        if (i < K) {
+            const double wi = (double)w[i];
+            const int j = nib(bestp, i);
+            if (assign) assign[i] = j;
+            if (dw) dw[i] = (float)(((double)cost[i * maxK + j] * S - swc) / (S * S));
+            if (dmu) dmu[i] = (float)(wi / S * (double)gmu[i * maxK + j]);
+            if (dkappa) dkappa[i] = (float)(wi / S * (double)gk[i * maxK + j]);
+        }
+}
+
+// a 256-thread workgroup takes 256 / maxK^2 samples (16 at max_K = 4)
+__global__ void __launch_bounds__(256) vm_match_loss_kernel(const float *__restrict__ mu, const float *__restrict__ kappa,
+                                                            const float *__restrict__ w, const float *__restrict__ vm_gt,
+                                                            const int32_t *__restrict__ K_gt, int B, int maxK, int spb,
+                                                            float *__restrict__ loss_vec, float *__restrict__ dmu,
+                                                            float *__restrict__ dkappa, float *__restrict__ dw,
+                                                            int32_t *__restrict__ assign) {
+    __shared__ float tab[3][256];   // cost, gmu, gk: [sample in block][i][j]
+    const int kk = maxK * maxK, b0 = blockIdx.x * spb, tid = threadIdx.x;
+    if (tid < spb * kk) {
+        const int s = tid / kk, ij = tid - s * kk, i = ij / maxK, j = ij - i * maxK, b = b0 + s;
+        if (b < B) {
+            const int K = min(K_gt[b], maxK);
+            if (i < K && j < K)
+                match_cost_entry(mu[(size_t)b * maxK + i], kappa[(size_t)b * maxK + i], vm_gt[((size_t)b * maxK + j) * 3],
+                                 vm_gt[((size_t)b * maxK + j) * 3 + 1], tab[0][tid], tab[1][tid], tab[2][tid]);
+        }
+    }
+    __syncthreads();
+    if (tid < spb && b0 + tid < B) {
+        const int b = b0 + tid;
+        const size_t o = (size_t)b * maxK;
+        match_assign_sample<MATCH_KMAX>(&tab[0][tid * kk], &tab[1][tid * kk], &tab[2][tid * kk], w + o, K_gt[b], maxK, loss_vec + b, dmu ? dmu + o : nullptr,
+                            dkappa ? dkappa + o : nullptr, dw ? dw + o : nullptr, assign ? assign + o : nullptr);
     }
 }
 
 // ---- multi-peak output head, pointnet_pp_mvM.py:91-125 ---------------------------------------------
+// one sample: pi_raw (K), mu_raw (K x 2), kappa_raw (K) -> mu, kappa, weight (K)
+__device__ __forceinline__ void mvm_head_sample(const float *pi_raw, const float *mu_raw, const float *kappa_raw, int K, float temp,
+                                                float kappa_max, float *mu, float *kappa, float *weight) {
+    double mx = -1e300;
+    for (int k = 0; k < K; ++k) mx = fmax(mx, (double)pi_raw[k] / (double)temp);
+    double se = 0.0;
+    for (int k = 0; k < K; ++k) se += exp((double)pi_raw[k] / (double)temp - mx);
+    for (int k = 0; k < K; ++k) {
+        weight[k] = (float)(exp((double)pi_raw[k] / (double)temp - mx) / se);
+        const float c0 = mu_raw[k * 2], s0 = mu_raw[k * 2 + 1];
+        const float nrm = fmaxf(sqrtf(c0 * c0 + s0 * s0), 1e-4f);  // F.normalize(eps=1e-4)
+        float c = c0 / nrm, s = s0 / nrm;
+        if (sqrtf(c * c + s * s) < 1e-3f) c = 1.f, s = 0.f;        // degenerate direction -> mu = 0
+        mu[k] = (float)atan2((double)s, (double)c);
+        const double kr = (double)kappa_raw[k];
+        const double sp = (kr > 20.0 ? kr : log1p(exp(kr))) + 1e-6;
+        kappa[k] = (float)fmin(sp, (double)kappa_max);
+    }
+}
+
 __global__ void __launch_bounds__(64) mvm_head_kernel(const float *__restrict__ pi_raw, const float *__restrict__ mu_raw,
                                                       const float *__restrict__ kappa_raw, int B, int K, float temp,
                                                       float kappa_max, float *__restrict__ mu, float *__restrict__ kappa,
                                                       float *__restrict__ weight) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
-    double mx = -1e300;
-    for (int k = 0; k < K; ++k) mx = fmax(mx, (double)pi_raw[b * K + k] / (double)temp);
-    double se = 0.0;
-    for (int k = 0; k < K; ++k) se += exp((double)pi_raw[b * K + k] / (double)temp - mx);
+    const size_t o = (size_t)b * K;
+    mvm_head_sample(pi_raw + o, mu_raw + 2 * o, kappa_raw + o, K, temp, kappa_max, mu + o, kappa + o, weight + o);
+}
+
+// one sample: gradients w.r.t. the raw head outputs from (dmu, dkappa, dweight)
+__device__ __forceinline__ void mvm_head_bwd_sample(const float *mu_raw, const float *kappa_raw, const float *weight, const float *dmu,
+                                                    const float *dkappa, const float *dweight, int K, float temp, float kappa_max,
+                                                    float *dpi_raw, float *dmu_raw, float *dkappa_raw) {
+    double dot = 0.0;
+    for (int k = 0; k < K; ++k) dot += (double)weight[k] * (double)dweight[k];
     for (int k = 0; k < K; ++k) {
-        weight[b * K + k] = (float)(exp((double)pi_raw[b * K + k] / (double)temp - mx) / se);
-        const float c0 = mu_raw[(b * K + k) * 2], s0 = mu_raw[(b * K + k) * 2 + 1];
-        const float nrm = fmaxf(sqrtf(c0 * c0 + s0 * s0), 1e-4f);  // F.normalize(eps=1e-4)
-        float c = c0 / nrm, s = s0 / nrm;
-        if (sqrtf(c * c + s * s) < 1e-3f) c = 1.f, s = 0.f;        // degenerate direction -> mu = 0
-        mu[b * K + k] = (float)atan2((double)s, (double)c);
-        const double kr = (double)kappa_raw[b * K + k];
+        const double wk = (double)weight[k];
+        dpi_raw[k] = (float)(wk * ((double)dweight[k] - dot) / (double)temp);
+        // atan2(s, c) with (c, s) = r / max(|r|, eps)
+        const double r0 = (double)mu_raw[k * 2], r1 = (double)mu_raw[k * 2 + 1];
+        const double n = sqrt(r0 * r0 + r1 * r1);
+        const double den = fmax(n, 1e-4);
+        const double c = r0 / den, s = r1 / den;
+        const double n2 = c * c + s * s;
+        double g0 = 0.0, g1 = 0.0;
+        if (sqrt(n2) >= 1e-3) {
+            const double gm = (double)dmu[k];
+            const double dc = -s / n2 * gm, ds = c / n2 * gm;  // d atan2 / d(c, s)
+            if (n >= 1e-4) {                                   // u = r/|r|: (I - u u^T)/|r|
+                const double proj = dc * c + ds * s;
+                g0 = (dc - c * proj) / n;
+                g1 = (ds - s * proj) / n;
+            } else {                                           // u = r/eps
+                g0 = dc / 1e-4;
+                g1 = ds / 1e-4;
+            }
+        }
+        dmu_raw[k * 2] = (float)g0;
+        dmu_raw[k * 2 + 1] = (float)g1;
+        const double kr = (double)kappa_raw[k];
         const double sp = (kr > 20.0 ? kr : log1p(exp(kr))) + 1e-6;
-        kappa[b * K + k] = (float)fmin(sp, (double)kappa_max);
+        const double sig = kr > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-kr));
+        dkappa_raw[k] = (float)(sp <= (double)kappa_max ? (double)dkappa[k] * sig : 0.0);
     }
 }
 
@@ -447,37 +545,159 @@ mvm_head_bwd_kernel(const float *__restrict__ pi_raw, const float *__restrict__ 
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
     (void)pi_raw;
-    double dot = 0.0;
-    for (int k = 0; k < K; ++k) dot += (double)weight[b * K + k] * (double)dweight[b * K + k];
-    for (int k = 0; k < K; ++k) {
-        const double wk = (double)weight[b * K + k];
-        dpi_raw[b * K + k] = (float)(wk * ((double)dweight[b * K + k] - dot) / (double)temp);
-        // atan2(s, c) with (c, s) = r / max(|r|, eps)
-        const double r0 = (double)mu_raw[(b * K + k) * 2], r1 = (double)mu_raw[(b * K + k) * 2 + 1];
-        const double n = sqrt(r0 * r0 + r1 * r1);
-        const double den = fmax(n, 1e-4);
-        const double c = r0 / den, s = r1 / den;
-        const double n2 = c * c + s * s;
-        double g0 = 0.0, g1 = 0.0;
-        if (sqrt(n2) >= 1e-3) {
-            const double gm = (double)dmu[b * K + k];
-            const double dc = -s / n2 * gm, ds = c / n2 * gm;  // d atan2 / d(c, s)
-            if (n >= 1e-4) {                                   // u = r/|r|: (I - u u^T)/|r|
-                const double proj = dc * c + ds * s;
-                g0 = (dc - c * proj) / n;
-                g1 = (ds - s * proj) / n;
-            } else {                                           // u = r/eps
-                g0 = dc / 1e-4;
-                g1 = ds / 1e-4;
-            }
-        }
-        dmu_raw[(b * K + k) * 2] = (float)g0;
-        dmu_raw[(b * K + k) * 2 + 1] = (float)g1;
-        const double kr = (double)kappa_raw[b * K + k];
-        const double sp = (kr > 20.0 ? kr : log1p(exp(kr))) + 1e-6;
-        const double sig = kr > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-kr));
-        dkappa_raw[b * K + k] = (float)(sp <= (double)kappa_max ? (double)dkappa[b * K + k] * sig : 0.0);
+    const size_t o = (size_t)b * K;
+    mvm_head_bwd_sample(mu_raw + 2 * o, kappa_raw + o, weight + o, dmu + o, dkappa + o, dweight + o, K, temp, kappa_max, dpi_raw + o,
+                        dmu_raw + 2 * o, dkappa_raw + o);
+}
+
+// The whole tail of the multi-peak training step in ONE single-workgroup launch (round 4): the three output heads
+// o = x [W_pi; W_mu; W_kappa]^T + b (models/pointnet_pp_mvM.py:91-96), the head activations (:91-125), match_loss
+// (train_multi_peaks_vonMises_KL.py:54-81), its batch mean (:229) and their backward -- d loss / d W, d b of the three heads and d x.
+// x: (B, K) features; the heads' weights are (KC x K), (2 KC x K), (KC x K).  In eager PyTorch terms: three Linears, the head, the loss, a
+// mean and a dozen autograd nodes; as separate launches of this library: 3 x fc_small_fwd, mvm_head, vm_match_loss, torch's mean and
+// its backward, three elementwise multiplies, mvm_head_bwd, 3 x fc_small_bwd.  Per-sample arithmetic is that of the standalone kernels
+// (the same device functions, float32 values at the same places); the mean is a fixed-order float64 tree.  Workgroups 1 .. carry the
+// next step's centre draw, as in vm_fc_head_kl_step_kernel.
+template <int KC>
+__global__ void __launch_bounds__(256)
+mvm_fc_head_match_step_kernel(const float *__restrict__ x, const float *__restrict__ Wpi, const float *__restrict__ bpi,
+                              const float *__restrict__ Wmu, const float *__restrict__ bmu, const float *__restrict__ Wkap,
+                              const float *__restrict__ bkap, const float *__restrict__ vm_gt, const int32_t *__restrict__ K_gt, int B,
+                              int K, float temp, float kappa_max, float *__restrict__ loss_mean, float *__restrict__ dWpi,
+                              float *__restrict__ dbpi, float *__restrict__ dWmu, float *__restrict__ dbmu, float *__restrict__ dWkap,
+                              float *__restrict__ dbkap, float *__restrict__ dx, float *__restrict__ mu_out, float *__restrict__ kappa_out,
+                              float *__restrict__ weight_out, const SampleJob J) {
+    constexpr int NO = 4 * KC;   // outputs per sample: pi (KC) | mu (2 KC) | kappa (KC)
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // o[B][NO] (then d_o in place), ws[NO][K], xs[B][K]
+    if (blockIdx.x > 0) {
+        __shared__ int nc_s;
+        sample_random_body(J.seed_lo, J.seed_hi, J.str_lo, J.str_hi, J.str_dev, J.N1, J.npoint1, J.out1, J.B, J.N2, J.npoint2, J.out2,
+                           (int)blockIdx.x - 1, (int)gridDim.x - 1, reinterpret_cast<unsigned long long *>(sm), nc_s);
+        return;
     }
+    __shared__ double red[256];
+    float *o = sm;
+    float *ws = sm + (((size_t)B * NO + 3) & ~(size_t)3);
+    float *xs = ws + (size_t)NO * K;
+    const int tid = threadIdx.x;
+#ifdef PNPP_STAMPS
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
+    // one round trip for everything the kernel reads: the heads' weight rows in output order, their biases, the features
+    for (int f = tid; f < NO * K; f += 256) {   // (the address is selected, not the loaded value: one unconditional load per element)
+        const int n = f / K, k = f - n * K;
+        const float *src = n < KC ? Wpi + (size_t)n * K + k : n < 3 * KC ? Wmu + (size_t)(n - KC) * K + k : Wkap + (size_t)(n - 3 * KC) * K + k;
+        ws[f] = *src;
+    }
+    float bias_n = 0.f;
+    if (tid < NO) bias_n = tid < KC ? bpi[tid] : tid < 3 * KC ? bmu[tid - KC] : bkap[tid - 3 * KC];
+    {
+        const int n4 = (B * K) >> 2;
+        for (int f = tid; f < n4; f += 256) reinterpret_cast<float4 *>(xs)[f] = reinterpret_cast<const float4 *>(x)[f];
+    }
+    __shared__ float bias_s[NO];
+    if (tid < NO) bias_s[tid] = bias_n;
+    __syncthreads();
+    TAIL_STAMP(0)   // staging
+    // 1. o = x W^T + b: eight lanes per row, each a strided eighth of the features, NO accumulators per lane
+    const int part8 = tid & 7;
+    for (int i = tid >> 3; i < ((B + 31) & ~31); i += 32) {
+        const int ic = min(i, B - 1);
+        float acc[NO];
+#pragma unroll
+        for (int n = 0; n < NO; ++n) acc[n] = 0.f;
+        for (int k = part8; k < K; k += 8) {
+            const float xv = xs[(size_t)ic * K + k];
+#pragma unroll
+            for (int n = 0; n < NO; ++n) acc[n] = fmaf(xv, ws[n * K + k], acc[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+#pragma unroll
+            for (int m = 4; m >= 1; m >>= 1) acc[n] += __shfl_xor(acc[n], m);
+            if (part8 == 0 && i < B) o[(size_t)i * NO + n] = acc[n] + bias_s[n];
+        }
+    }
+    __syncthreads();
+    // 2. head (one thread per sample), the K x K cost matrices (one thread per ENTRY: match_cost_entry), then per sample the assignment,
+    // the mean's factor 1 / B (a float32 multiply, as autograd applies it) and the head's backward; d loss / d o overwrites o.
+    // Tables in LDS, reusing nothing the other steps read: hm[B][3 KC] = mu | kappa | weight, tb[3][B][KC^2] = cost | gmu | gk.
+    TAIL_STAMP(1)   // o = x W^T
+    float *hm = xs + (size_t)B * K;
+    float *tb = hm + (size_t)B * 3 * KC;
+    const float gf = 1.0f / (float)B;
+    for (int b = tid; b < B; b += 256) {
+        const float *raw = o + (size_t)b * NO;
+        mvm_head_sample(raw, raw + KC, raw + 3 * KC, KC, temp, kappa_max, hm + (size_t)b * 3 * KC, hm + (size_t)b * 3 * KC + KC,
+                        hm + (size_t)b * 3 * KC + 2 * KC);
+    }
+    __syncthreads();
+    TAIL_STAMP(2)   // head forward
+    for (int e = tid; e < B * KC * KC; e += 256) {
+        const int b = e / (KC * KC), ij = e - b * (KC * KC), i = ij / KC, j = ij - i * KC;
+        const int Kb = min(K_gt[b], KC);
+        if (i < Kb && j < Kb)
+            match_cost_entry(hm[(size_t)b * 3 * KC + i], hm[(size_t)b * 3 * KC + KC + i], vm_gt[((size_t)b * KC + j) * 3],
+                             vm_gt[((size_t)b * KC + j) * 3 + 1], tb[e], tb[(size_t)B * KC * KC + e], tb[(size_t)2 * B * KC * KC + e]);
+    }
+    __syncthreads();
+    TAIL_STAMP(3)   // cost entries
+    double part = 0.0;
+    for (int b = tid; b < B; b += 256) {
+        float raw[NO], dmu[KC], dk[KC], dw[KC], lv;
+#pragma unroll
+        for (int n = 0; n < NO; ++n) raw[n] = o[(size_t)b * NO + n];
+        const float *mu = hm + (size_t)b * 3 * KC, *kap = mu + KC, *wt = mu + 2 * KC;
+        match_assign_sample<KC>(tb + (size_t)b * KC * KC, tb + (size_t)(B + b) * KC * KC, tb + (size_t)(2 * B + b) * KC * KC, wt, K_gt[b], KC, &lv,
+                            dmu, dk, dw, nullptr);
+        part += (double)lv;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            if (mu_out) mu_out[(size_t)b * KC + k] = mu[k], kappa_out[(size_t)b * KC + k] = kap[k], weight_out[(size_t)b * KC + k] = wt[k];
+            dmu[k] *= gf, dk[k] *= gf, dw[k] *= gf;
+        }
+        float d[NO];
+        mvm_head_bwd_sample(raw + KC, raw + 3 * KC, wt, dmu, dk, dw, KC, temp, kappa_max, d, d + KC, d + 3 * KC);
+#pragma unroll
+        for (int n = 0; n < NO; ++n) o[(size_t)b * NO + n] = d[n];
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) *loss_mean = (float)(red[0] / (double)B);
+    TAIL_STAMP(4)   // assignment + head backward + mean
+    // 3. dW = d_o^T x, db = column sums of d_o, dx = d_o W: one thread per feature, rows in order
+    for (int k = tid; k < K; k += 256) {
+        float wv[NO], g[NO];
+#pragma unroll
+        for (int n = 0; n < NO; ++n) wv[n] = ws[n * K + k], g[n] = 0.f;
+        for (int i = 0; i < B; ++i) {
+            const float xv = xs[(size_t)i * K + k];
+            float dxv = 0.f;
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+                const float dn = o[(size_t)i * NO + n];
+                g[n] = fmaf(dn, xv, g[n]);
+                dxv = fmaf(dn, wv[n], dxv);
+            }
+            if (dx) dx[(size_t)i * K + k] = dxv;
+        }
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+            float *dst = n < KC ? dWpi + (size_t)n * K : n < 3 * KC ? dWmu + (size_t)(n - KC) * K : dWkap + (size_t)(n - 3 * KC) * K;
+            dst[k] = g[n];
+        }
+    }
+    if (tid < NO) {
+        float gsum = 0.f;
+        for (int i = 0; i < B; ++i) gsum += o[(size_t)i * NO + tid];
+        float *dst = tid < KC ? dbpi + tid : tid < 3 * KC ? dbmu + (tid - KC) : dbkap + (tid - 3 * KC);
+        *dst = gsum;
+    }
+    TAIL_STAMP(5)   // dW, db, dx
 }
 
 // ---- soft-label cross entropy, train_8dir_KL.py:60-68 ----------------------------------------------
@@ -823,9 +1043,66 @@ extern "C" int pnpp_vm_match_loss(const float *mu, const float *kappa, const flo
     PNPP_REQUIRE(mu && kappa && w && vm_gt && K_gt && loss_vec, PNPP_ERR_ARG, "vm_match_loss: null pointer");
     PNPP_REQUIRE(B > 0 && maxK > 0, PNPP_ERR_ARG, "vm_match_loss: non-positive size");
     PNPP_REQUIRE(maxK <= MATCH_KMAX, PNPP_ERR_ARG, "vm_match_loss: max_K=%d exceeds the supported maximum %d", maxK, MATCH_KMAX);
-    hipLaunchKernelGGL(vm_match_loss_kernel, dim3(cdiv(B, 64)), dim3(64), 0, as_stream(stream), mu, kappa, w, vm_gt, K_gt, B,
-                       maxK, loss_vec, dmu, dkappa, dw, assign);
+    const int spb = 256 / (maxK * maxK);   // samples per workgroup: one thread per cost-matrix entry
+    hipLaunchKernelGGL(vm_match_loss_kernel, dim3(cdiv(B, spb)), dim3(256), 0, as_stream(stream), mu, kappa, w, vm_gt, K_gt, B,
+                       maxK, spb, loss_vec, dmu, dkappa, dw, assign);
     PNPP_CHECK_LAUNCH("vm_match_loss");
+    return PNPP_OK;
+}
+
+extern "C" int pnpp_mvm_fc_head_match_step(const float *x, const float *w_pi, const float *b_pi, const float *w_mu, const float *b_mu,
+                                           const float *w_kappa, const float *b_kappa, const float *vm_gt, const int32_t *K_gt, int B, int K,
+                                           int maxK, float temp, float kappa_max, float *loss_mean, float *dw_pi, float *db_pi, float *dw_mu,
+                                           float *db_mu, float *dw_kappa, float *db_kappa, float *dx, float *mu, float *kappa, float *weight,
+                                           uint64_t seed, uint64_t *stream_id_dev, uint64_t offset, int Bs, int N1, int npoint1,
+                                           int32_t *out1, int N2, int npoint2, int32_t *out2, void *stream) {
+    PNPP_REQUIRE(x && w_pi && b_pi && w_mu && b_mu && w_kappa && b_kappa && vm_gt && K_gt && loss_mean && dw_pi && db_pi && dw_mu && db_mu &&
+                     dw_kappa && db_kappa,
+                 PNPP_ERR_ARG, "mvm_fc_head_match_step: null pointer");
+    PNPP_REQUIRE(B > 0 && K > 0 && (K & 3) == 0 && ((uintptr_t)x & 15) == 0, PNPP_ERR_ARG,
+                 "mvm_fc_head_match_step: B must be positive, K a positive multiple of 4, x 16-byte aligned");
+    PNPP_REQUIRE(maxK == 4 || maxK == 8, PNPP_ERR_ARG, "mvm_fc_head_match_step: max_K must be 4 or 8 (got %d); other widths take the separate launches", maxK);
+    PNPP_REQUIRE(!mu || (kappa && weight), PNPP_ERR_ARG, "mvm_fc_head_match_step: mu, kappa, weight come together");
+    const int NO = 4 * maxK;
+    // o[B][NO] | ws[NO][K] | xs[B][K] | mu, kappa, weight [B][3 max_K] | cost, gmu, gk [3][B][max_K^2]
+    size_t lds = ((((size_t)B * NO + 3) & ~(size_t)3) + (size_t)NO * K + (size_t)B * K + (size_t)B * 3 * maxK + (size_t)3 * B * maxK * maxK) *
+                 sizeof(float);
+    SampleJob J;
+    int grid = 1;
+    if (Bs > 0) {   // the next step's centre draw rides in this launch (sampling.CentreRing)
+        PNPP_REQUIRE(stream_id_dev && out1 && out2 && N1 > 0 && npoint1 > 0 && N2 > 0 && npoint2 > 0, PNPP_ERR_ARG,
+                     "mvm_fc_head_match_step: bad sampler arguments");
+        PNPP_REQUIRE(npoint1 <= N1 && npoint2 <= N2, PNPP_ERR_RANGE, "sample_random_dev2: npoint exceeds N");
+        const int Nmax = N1 > N2 ? N1 : N2;
+        const size_t lds_s = (size_t)(Nmax + 1) * sizeof(unsigned long long);
+        if (lds_s > lds) lds = lds_s;
+        J.seed_lo = (unsigned)seed, J.seed_hi = (unsigned)(seed >> 32), J.str_lo = (unsigned)offset, J.str_hi = (unsigned)(offset >> 32);
+        J.str_dev = reinterpret_cast<unsigned long long *>(stream_id_dev);
+        J.B = Bs, J.N1 = N1, J.npoint1 = npoint1, J.N2 = N2, J.npoint2 = npoint2, J.out1 = out1, J.out2 = out2;
+        grid = 1 + 2 * Bs;
+    }
+    // features, the 4 max_K weight rows, the outputs and the match tables live in LDS (the reference head, B = 32: 59 KB)
+    PNPP_REQUIRE(lds <= 96 * 1024, PNPP_ERR_RANGE, "mvm_fc_head_match_step: %zu bytes of LDS exceed 96 KB (B=%d, K=%d, max_K=%d)", lds, B, K, maxK);
+    {   // more than the 64 KB a launch gets without asking
+        static bool granted[2] = {false, false};
+        const int which = maxK == 4 ? 0 : 1;
+        if (!granted[which]) {
+            const void *fn = maxK == 4 ? (const void *)mvm_fc_head_match_step_kernel<4> : (const void *)mvm_fc_head_match_step_kernel<8>;
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            granted[which] = true;
+        }
+    }
+    ProfScope ps(as_stream(stream), "mvm_fc_head_match_step_kernel B=%d K=%d maxK=%d%s", B, K, maxK, Bs > 0 ? " + sample_random" : "");
+    if (maxK == 4) {
+        hipLaunchKernelGGL(mvm_fc_head_match_step_kernel<4>, dim3(grid), dim3(256), lds, as_stream(stream), x, w_pi, b_pi, w_mu, b_mu, w_kappa,
+                           b_kappa, vm_gt, K_gt, B, K, temp, kappa_max, loss_mean, dw_pi, db_pi, dw_mu, db_mu, dw_kappa, db_kappa, dx, mu, kappa,
+                           weight, J);
+    } else {
+        hipLaunchKernelGGL(mvm_fc_head_match_step_kernel<8>, dim3(grid), dim3(256), lds, as_stream(stream), x, w_pi, b_pi, w_mu, b_mu, w_kappa,
+                           b_kappa, vm_gt, K_gt, B, K, temp, kappa_max, loss_mean, dw_pi, db_pi, dw_mu, db_mu, dw_kappa, db_kappa, dx, mu, kappa,
+                           weight, J);
+    }
+    PNPP_CHECK_LAUNCH("mvm_fc_head_match_step");
     return PNPP_OK;
 }
 
@@ -995,3 +1272,16 @@ extern "C" int pnpp_sumsq(const float *x, size_t n, double *out, void *scratch, 
     PNPP_CHECK_LAUNCH("sumsq");
     return PNPP_OK;
 }
+
+#ifdef PNPP_STAMPS
+extern "C" int pnpp_debug_tail_stamps(unsigned long long *out16, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(pnpp::g_tail_stamps), z, sizeof(z));
+    } else {
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(out16, HIP_SYMBOL(pnpp::g_tail_stamps), 16 * sizeof(unsigned long long));
+    }
+    return 0;
+}
+#endif

@@ -9,7 +9,7 @@ import math
 import torch
 import torch.nn as nn
 
-from pnpp_hip import ops
+from pnpp_hip import ops, sampling
 from .pointnet_pp_8dir import PointNetSetAbstraction, stacked_levels
 
 _BACKBONE = ((128, 32, 0, (64, 64, 128), False), (32, 32, 128, (128, 128, 256), False), (None, None, 256, (256, 512, 1024), True))
@@ -48,19 +48,46 @@ class PointNetPPMvM(nn.Module):
             for t in (self.head_pi.weight, self.head_pi.bias, self.head_mu.weight, self.head_mu.bias, self.head_kappa.bias):
                 t.zero_()                                  # kappa = softplus(W x) at the start
 
+    _presampled = None
+
+    def use_presampled(self, ring) -> None:
+        """ring: a pnpp_hip.sampling.CentreRing whose buffers hold the centres of the next forward pass (drawn one step ahead by
+        the previous step's tail launch, `loss_backward(next_centres=ring.job())`); None: draw at the start of the step."""
+        self._presampled = ring
+
     def _global_feat(self, pts: torch.Tensor, centres=None, drop_masks=(None, None)) -> torch.Tensor:
+        B = pts.size(0)
+        if centres is None and self._presampled is not None and self.training and self._presampled.B == B:
+            centres = self._presampled.centres
         c1, c2 = centres if centres is not None else (None, None)
+        if centres is None and self.sa1.sampler == "device" and self.sa2.sampler == "device":
+            # neither draw depends on data: both levels' centres from one launch (same centres as the per-level draws)
+            c1, c2 = sampling.device_random_centres_pair(B, pts.size(1), self.sa1.npoint, self.sa1.npoint, self.sa2.npoint, pts.device)
         _, _, l2_xyz, l2_pts = stacked_levels(self.sa1, self.sa2, pts, c1, c2)
         feat = self.sa3(l2_xyz, l2_pts)[1].flatten(1)
         for fc, ln, mask in ((self.fc1, self.ln1, drop_masks[0]), (self.fc2, self.ln2, drop_masks[1])):
             feat = ops.fc_block(feat, fc, ln, relu=True, dropout=self.drop, training=self.training, mask=mask)
         return feat
 
+    def features(self, xyz: torch.Tensor, centres=None, drop_masks=(None, None)) -> torch.Tensor:
+        """(B,N,3) | (B,3,N) -> (B,256): everything in front of the three output heads (reference lines 75-84)."""
+        return self._global_feat(_as_points_last(xyz).contiguous(), centres, drop_masks)
+
     def forward(self, xyz: torch.Tensor, centres=None, drop_masks=(None, None)):
-        feat = self._global_feat(_as_points_last(xyz).contiguous(), centres, drop_masks)
+        feat = self.features(xyz, centres, drop_masks)
         raw = [ops.fc_block(feat, head, training=self.training) for head in (self.head_pi, self.head_mu, self.head_kappa)]
         # softmax(pi/temp); normalize(eps=1e-4) + degenerate fallback + atan2; softplus + 1e-6, clamp_max -- one kernel
         return ops.mvm_head(raw[0], raw[1], raw[2], self.temp, self.kappa_max)
+
+    def loss_backward(self, xyz: torch.Tensor, vm_gt: torch.Tensor, K_gt: torch.Tensor, centres=None, drop_masks=(None, None),
+                      next_centres=None, outputs=False):
+        """forward(xyz) -> match_loss(mu, kappa, weight, vm_gt, K_gt).mean() -> loss.backward() of one training step
+        (train_multi_peaks_vonMises_KL.py:224-234) with the three output heads, the head activations, the loss, its mean and their
+        backward in ONE launch (ops.mvm_heads_match_loss_backward).  Returns the detached mean loss (and mu, kappa, weight with
+        outputs=True); gradients are where loss.backward() would have put them."""
+        feat = self.features(xyz, centres, drop_masks)
+        return ops.mvm_heads_match_loss_backward(feat, self.head_pi, self.head_mu, self.head_kappa, vm_gt, K_gt, self.temp, self.kappa_max,
+                                                 next_centres=next_centres, outputs=outputs)
 
 
 @torch.no_grad()

@@ -95,6 +95,7 @@ SIGNATURES = {
     "pnpp_vm_head_bwd": (_i, [_fp, _fp, _fp, _i, _fp, _fp]),
     "pnpp_vm_kl_single": (_i, [_fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp]),
     "pnpp_vm_match_loss": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "pnpp_mvm_fc_head_match_step": (_i, [_fp] * 9 + [_i, _i, _i, _f, _f] + [_fp] * 11 + [_u64, _fp, _u64, _i, _i, _i, _fp, _i, _i, _fp, _fp]),
     "pnpp_mvm_head": (_i, [_fp, _fp, _fp, _i, _i, _f, _f, _fp, _fp, _fp, _fp]),
     "pnpp_mvm_head_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _f, _f, _fp, _fp, _fp, _fp]),
     "pnpp_soft_ce": (_i, [_fp, _fp, _i, _i, _fp, _fp, _fp]),

@@ -32,7 +32,7 @@ SOURCES = {
     "gemm_wsp_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_wsx_kernels.hip": [],
     "gemm_wsq_kernels.hip": [],
-    "loss_kernels.hip": [],
+    "loss_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "sa_api.hip": [],
     "fc_api.hip": [],
     "transformer_kernels.hip": [],

@@ -516,8 +516,9 @@ def fc_block(x, linear, norm=None, relu=False, dropout=None, training=True, mask
     draw = None
     if training and mask is None and dropout is not None and dropout.p > 0:
         from . import dist as _pdist
-        if kind == L.NORM_BATCH and x.shape[0] <= 32 and x.is_cuda and not _pdist.sync_batchnorm_enabled():
-            # the BatchNorm epilogue draws it in the kernel (SyncBN takes the unfused route: the mask comes from torch)
+        if x.is_cuda and ((kind == L.NORM_BATCH and x.shape[0] <= 32 and not _pdist.sync_batchnorm_enabled()) or
+                          (kind == L.NORM_LAYER and dropout.p < 1.0)):
+            # the BatchNorm epilogue / the LayerNorm pass draws it in the kernel (SyncBN takes the unfused route: the mask comes from torch)
             draw = (dropout.p, torch.initial_seed(), _dropout_counter(x.device))
             drop_scale = 1.0 / (1.0 - dropout.p)
         else:
@@ -695,6 +696,61 @@ def vm_fc_head_kl_loss_backward(x, linear, mu_gt, kappa_gt, next_centres=None) -
     if dx is not None:
         torch.autograd.backward([x], [dx])
     return loss
+
+
+def mvm_heads_match_loss_backward(x, head_pi, head_mu, head_kappa, vm_gt, K_gt, temp, kappa_max, next_centres=None, outputs=False):
+    """The three output heads of PointNetPPMvM on features `x` (B,K), the head activations, `match_loss(...).mean()` and
+    `loss.backward()` in ONE launch (models/pointnet_pp_mvM.py:91-125 + train_multi_peaks_vonMises_KL.py:54-81, :229-234): the
+    heads' gradients land in their .grad (or the optimiser's flat buffer), the gradient of x seeds the rest of the backward pass.
+    Returns the detached mean loss (and mu, kappa, weight with outputs=True).  Equals
+    match_loss(*mvm_head(fc_block(x, head_pi), fc_block(x, head_mu), fc_block(x, head_kappa), ...), vm_gt, K_gt).mean() + backward()
+    to float32 rounding; max_K other than 4 / 8 or heads too wide for the launch's LDS take exactly that route."""
+    x32, vm_gt = _f32(x, "x"), _f32(vm_gt, "vm_gt")
+    K32 = _i32(K_gt, "K_gt")
+    B, K = x32.shape
+    maxK = head_pi.weight.shape[0]
+    heads = (head_pi, head_mu, head_kappa)
+    fits = maxK in (4, 8) and K % 4 == 0 and 4 * (4 * maxK * (B + K) + B * K + 3 * B * maxK * (1 + maxK)) <= 96 * 1024
+    if (head_mu.weight.shape[0] != 2 * maxK or head_kappa.weight.shape[0] != maxK or any(h.weight.shape[1] != K for h in heads)
+            or tuple(vm_gt.shape) != (B, maxK, 3)):
+        raise ValueError("mvm_heads_match_loss_backward: heads must map K -> max_K / 2 max_K / max_K and vm_gt must be (B, max_K, 3)")
+    if not fits:
+        if next_centres is not None:
+            seed, counter, offset, Bs, N1, c1, N2, c2 = next_centres
+            L.check(L.lib().pnpp_sample_random_dev2(int(seed) & (2**64 - 1), counter.data_ptr(), int(offset), Bs, N1, c1.shape[1],
+                                                    c1.data_ptr(), N2, c2.shape[1], c2.data_ptr(), _stream()))
+        mu, kappa, weight = mvm_head(*[fc_block(x, h, training=True) for h in heads], temp, kappa_max)
+        loss = match_loss(mu, kappa, weight, vm_gt, K_gt).mean()
+        loss.backward()
+        loss = loss.detach()
+        return (loss, mu.detach(), kappa.detach(), weight.detach()) if outputs else loss
+    ws = [_f32(h.weight, "weight") for h in heads]
+    bs = [_f32(h.bias, "bias") for h in heads]
+    loss = torch.empty((), device=x32.device, dtype=torch.float32)
+    sinks = [grad_sink(p) for h in heads for p in (h.weight, h.bias)]
+    grads = [sinks[i] if sinks[i] is not None else torch.empty_like(t) for i, t in enumerate(t for pair in zip(ws, bs) for t in pair)]
+    dx = torch.empty_like(x32) if x.requires_grad else None
+    outs = [torch.empty(B, maxK, device=x32.device, dtype=torch.float32) for _ in range(3)] if outputs else [None] * 3
+    if next_centres is not None:   # sampling.CentreRing.job(): the next step's centre draw rides in this launch's idle CUs
+        seed, counter, offset, Bs, N1, c1, N2, c2 = next_centres
+        samp = (int(seed) & (2**64 - 1), counter.data_ptr(), int(offset), Bs, N1, c1.shape[1], c1.data_ptr(), N2, c2.shape[1], c2.data_ptr())
+    else:
+        samp = (0, None, 0, 0, 0, 0, None, 0, 0, None)
+    L.check(L.lib().pnpp_mvm_fc_head_match_step(x32.data_ptr(), ws[0].data_ptr(), bs[0].data_ptr(), ws[1].data_ptr(), bs[1].data_ptr(),
+                                                ws[2].data_ptr(), bs[2].data_ptr(), vm_gt.data_ptr(), K32.data_ptr(), B, K, maxK, float(temp),
+                                                float(kappa_max), loss.data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(),
+                                                grads[2].data_ptr(), grads[3].data_ptr(), grads[4].data_ptr(), grads[5].data_ptr(), _p(dx),
+                                                _p(outs[0]), _p(outs[1]), _p(outs[2]), *samp, _stream()))
+    params = [p for h in heads for p in (h.weight, h.bias)]
+    for p, g, sink in zip(params, grads, sinks):
+        if sink is None and p.requires_grad:                         # plain autograd semantics: accumulate into .grad
+            if p.grad is None:
+                p.grad = g.view_as(p)
+            else:
+                p.grad.add_(g.view_as(p))
+    if dx is not None:
+        torch.autograd.backward([x], [dx])
+    return (loss, *outs) if outputs else loss
 
 
 class _MatchLoss(torch.autograd.Function):

@@ -91,16 +91,17 @@ class FlatAdam:
         """L2 norm of the whole gradient as a 0-dim float64 tensor on the device (no host sync)."""
         return self._sumsq().clone().sqrt_()[0]
 
-    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+    def clip_grad_norm_(self, max_norm: float, return_norm: bool = True) -> Optional[torch.Tensor]:
         """torch.nn.utils.clip_grad_norm_(parameters, max_norm) semantics (train_multi_peaks_vonMises_KL.py:235) with no
         host round trip: the sum of squares is reduced on the device now and the NEXT step()/step_dev() reads it there and
         folds min(1, max_norm / (norm + 1e-6)) into its gradient scale (the gradient buffer itself is left untouched --
         the update consumes it once).  Under data parallelism call it after the all-reduce: the norm that is clipped is
         that of grad_scale * flat_g, i.e. of the mean gradient.  Returns the buffer's own L2 norm as a 0-dim float64 device
-        tensor (multiply by grad_scale for the mean gradient's); reading it is the caller's sync, not this method's."""
+        tensor (multiply by grad_scale for the mean gradient's); reading it is the caller's sync, not this method's.
+        return_norm=False skips that tensor (two small launches) when the caller does not look at the norm."""
         self._sumsq()
         self._pending_clip = float(max_norm)
-        return self._ss.sqrt()[0]
+        return self._ss.sqrt()[0] if return_norm else None
 
     def step(self, grad_scale: float = 1.0, zero_grad: bool = False) -> None:
         """zero_grad=True clears the flat gradient buffer in the same launch (the next iteration's zero_grad())."""

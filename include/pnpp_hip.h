@@ -281,6 +281,17 @@ int pnpp_vm_match_loss(const float *mu, const float *kappa, const float *w, cons
                        int B, int maxK, float *loss_vec, float *dmu, float *dkappa, float *dw, int32_t *assign,
                        void *stream);
 
+/* The whole tail of the multi-peak training step in ONE launch: the three output heads o = x [W_pi; W_mu; W_kappa]^T + b
+ * (models/pointnet_pp_mvM.py:91-96), the head activations (:91-125), match_loss (train_multi_peaks_vonMises_KL.py:54-81), its batch
+ * mean (:229) and their backward.  x (B,K) features; w_pi (max_K,K), w_mu (2 max_K,K), w_kappa (max_K,K); max_K 4 or 8.
+ * Writes loss_mean (1), the heads' weight / bias gradients, dx (B,K; may be NULL) and optionally mu, kappa, weight (B,max_K).
+ * Bs > 0: the next step's centre draw rides in the same launch (arguments as pnpp_sample_random_dev2); Bs = 0: none. */
+int pnpp_mvm_fc_head_match_step(const float *x, const float *w_pi, const float *b_pi, const float *w_mu, const float *b_mu,
+                                const float *w_kappa, const float *b_kappa, const float *vm_gt, const int32_t *K_gt, int B, int K,
+                                int maxK, float temp, float kappa_max, float *loss_mean, float *dw_pi, float *db_pi, float *dw_mu,
+                                float *db_mu, float *dw_kappa, float *db_kappa, float *dx, float *mu, float *kappa, float *weight,
+                                uint64_t seed, uint64_t *stream_id_dev, uint64_t offset, int Bs, int N1, int npoint1, int32_t *out1,
+                                int N2, int npoint2, int32_t *out2, void *stream);
 /* pointnet_pp_mvM.py:91-125: raw head outputs -> (mu, kappa, weight) and the backward of that map.
  * pi_raw (B,K), mu_raw (B,2K), kappa_raw (B,K). */
 int pnpp_mvm_head(const float *pi_raw, const float *mu_raw, const float *kappa_raw, int B, int K, float temp,

@@ -320,3 +320,79 @@ def test_vm_fc_head_kl_loss_backward_equals_the_unfused_ops(ops, B, K):
     loss.backward()
     assert abs(float(la) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
     assert _rel(ga[0].cpu(), W.grad) < 2e-5 and _rel(ga[1].cpu(), b.grad) < 2e-5 and _rel(ga[2].cpu(), x64.grad) < 2e-5
+
+
+@pytest.mark.parametrize("B,K,maxK", [(32, 256, 4), (7, 64, 4), (24, 128, 8), (40, 256, 4), (16, 64, 5)])
+def test_mvm_heads_match_loss_backward_equals_the_unfused_ops(ops, oracle, B, K, maxK):
+    """The multi-peak step's tail in one launch (three output heads, head activations, match_loss, mean, their backward:
+    models/pointnet_pp_mvM.py:91-125, train_multi_peaks_vonMises_KL.py:54-81, :229-234) against the separate launches it fuses and
+    against float64 autograd of the oracle's expressions.  (40 x 256 and max_K = 5 do not fit / are not instantiated: the op takes
+    the separate launches itself.)"""
+    torch.manual_seed(B + K)
+    heads = [nn.Linear(K, n).cuda() for n in (maxK, 2 * maxK, maxK)]
+    x = torch.randn(B, K, device="cuda") * 0.5
+    g = torch.Generator().manual_seed(B)
+    Kgt = torch.randint(0, maxK + 1, (B,), generator=g)
+    vm = torch.zeros(B, maxK, 3)
+    vm[:, :, 0] = (torch.rand(B, maxK, generator=g) * 2 - 1) * 3.1
+    vm[:, :, 1] = torch.rand(B, maxK, generator=g) * 20 + 0.5
+    vm[:, :, 2] = 1.0 / maxK
+    temp, kmax = 0.7, 80.0
+    xa = x.clone().requires_grad_(True)
+    la, mu_a, kap_a, w_a = ops.mvm_heads_match_loss_backward(xa, *heads, vm.cuda(), Kgt.cuda(), temp, kmax, outputs=True)
+    ga = [p.grad.clone() for h in heads for p in (h.weight, h.bias)] + [xa.grad.clone()]
+    for h in heads:
+        h.zero_grad(set_to_none=True)
+    xb = x.clone().requires_grad_(True)
+    mu_b, kap_b, w_b = ops.mvm_head(*[ops.fc_block(xb, h, training=True) for h in heads], temp, kmax)
+    lb = ops.match_loss(mu_b, kap_b, w_b, vm.cuda(), Kgt.cuda()).mean()
+    lb.backward()
+    gb = [p.grad.clone() for h in heads for p in (h.weight, h.bias)] + [xb.grad.clone()]
+    assert not la.requires_grad and abs(float(la) - float(lb)) <= 2e-6 * max(1.0, abs(float(lb)))
+    for a, b in ((mu_a, mu_b), (kap_a, kap_b), (w_a, w_b)):
+        assert _rel(a.cpu().numpy(), b.detach().cpu().numpy()) < 2e-6
+    for a, b in zip(ga, gb):
+        assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
+    # float64: the oracle's head + match_loss on the same raw outputs
+    x64 = x.double().cpu().requires_grad_(True)
+    P = {n: (h.weight.detach().double().cpu().requires_grad_(True), h.bias.detach().double().cpu().requires_grad_(True))
+         for n, h in zip(("pi", "mu", "kappa"), heads)}
+    raw = {n: x64 @ W.t() + b for n, (W, b) in P.items()}
+    weight = torch.softmax(raw["pi"] / temp, -1)
+    v = raw["mu"].view(B, maxK, 2)
+    u = v / v.norm(dim=-1, keepdim=True).clamp_min(1e-4)
+    mu64 = torch.atan2(u[..., 1], u[..., 0])
+    kap64 = (torch.nn.functional.softplus(raw["kappa"]) + 1e-6).clamp_max(kmax)
+    l64 = oracle.match_loss(mu64, kap64, weight, vm.double(), Kgt).mean()
+    l64.backward()
+    assert abs(float(la) - float(l64)) <= 1e-5 * max(1.0, abs(float(l64)))
+    ref = [t.grad for n in ("pi", "mu", "kappa") for t in P[n]] + [x64.grad]
+    for a, r in zip(ga, ref):
+        assert _rel(a.cpu().numpy(), r.numpy()) < 5e-5
+
+
+def test_layernorm_block_draws_its_dropout_mask_in_the_kernel(ops):
+    """Training, LayerNorm head block (models/pointnet_pp_mvM.py:82-83, dropout p = 0.4 twice): the keep-mask comes from the
+    LayerNorm pass's own counter-based generator (no bernoulli_ launch, graph-replayable); Bernoulli(1 - p), a fresh draw per call,
+    and forward / backward are exactly the block with that mask given."""
+    torch.manual_seed(5)
+    M, K, N, p = 32, 1024, 512, 0.4
+    lin, ln, drop = nn.Linear(K, N).cuda(), nn.LayerNorm(N).cuda(), nn.Dropout(p)
+    x = torch.randn(M, K, device="cuda", requires_grad=True)
+    y = ops.fc_block(x, lin, ln, relu=False, dropout=drop, training=True)
+    y2 = ops.fc_block(x.detach(), lin, ln, relu=False, dropout=drop, training=True)
+    keep, keep2 = (y != 0), (y2 != 0)
+    rate = float(keep.float().mean())
+    assert abs(rate - (1 - p)) < 5 * math.sqrt(p * (1 - p) / (M * N)), rate
+    assert float((keep != keep2).float().mean()) > 0.3
+    assert float(keep.float().mean(0).min()) > 0.2 and float(keep.float().mean(1).min()) > 0.45
+    up = torch.randn(M, N, device="cuda")
+    (y * up).sum().backward()
+    g1 = (x.grad.clone(), lin.weight.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone())
+    x.grad = None
+    lin.zero_grad(), ln.zero_grad()
+    y3 = ops.fc_block(x, lin, ln, relu=False, dropout=drop, training=True, mask=keep.to(torch.uint8))
+    assert torch.equal(y3, y)
+    (y3 * up).sum().backward()
+    for a, b in zip(g1, (x.grad, lin.weight.grad, ln.weight.grad, ln.bias.grad)):
+        assert torch.equal(a, b)

@@ -51,7 +51,18 @@ def main():
         xyz = xyz.to(dev)
         inputs = [xyz, vm_gt, K]
 
+        # the step's tail -- three output heads, head activations, match_loss, mean, their backward -- is ONE launch, which also
+        # carries the next step's centre draw (PNPP_FUSED_TAIL=0: the separate launches; same arithmetic)
+        fused_tail = os.environ.get("PNPP_FUSED_TAIL", "1") != "0"
+        ring = None
+        if fused_tail:
+            from pnpp_hip import sampling
+            ring = sampling.CentreRing(B, N, model.sa1.npoint, model.sa2.npoint, dev)
+            model.use_presampled(ring)
+
         def loss_fn(x, g, k):
+            if fused_tail:
+                return model.loss_backward(x, g, k, next_centres=ring.job())
             mu, kappa, w = model(x)
             return ops.match_loss(mu, kappa, w, g, k).mean()
         clip = 1.0
@@ -83,16 +94,17 @@ def main():
     def step():
         loss = graphed(*inputs)
         if clip is not None:
-            opt.clip_grad_norm_(clip)
+            opt.clip_grad_norm_(clip, return_norm=False)
         opt.step(zero_grad=True)
         return loss
 
     def eager_step():
         opt.zero_grad()
         loss = loss_fn(*inputs)
-        loss.backward()
+        if loss.requires_grad:
+            loss.backward()
         if clip is not None:
-            opt.clip_grad_norm_(clip)
+            opt.clip_grad_norm_(clip, return_norm=False)
         opt.step()
         return loss
 
