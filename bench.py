@@ -95,18 +95,25 @@ class Ctrl:
     communicator -- a rank whose device hangs can still tell the others, and nobody waits on the communicator that hung."""
 
     def __init__(self, world):
-        self.world, self.group = world, None
+        self.world, self.group, self.device = world, None, None
         if world > 1:
             import datetime
             import torch.distributed as tdist
             # always a group of its own (also when the data plane is gloo): a helper thread may be stuck inside a data-plane collective
-            self.group = tdist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: never resolve the host name (it may not resolve here)
+            try:
+                self.group = tdist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+            except Exception as e:   # no gloo transport on this box: agree over the data plane (enough for the host-issued schedules)
+                print(f"[bench] control plane falls back to the {tdist.get_backend()} group: {type(e).__name__}: {e}", file=sys.stderr)
+                self.group = None
+                if tdist.get_backend() == "nccl":
+                    self.device = torch.device("cuda", torch.cuda.current_device())
 
     def _reduce(self, x, op):
         if self.world == 1:
             return float(x)
         import torch.distributed as tdist
-        t = torch.tensor([float(x)], dtype=torch.float64)
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)
         tdist.all_reduce(t, op=getattr(tdist.ReduceOp, op), group=self.group)
         return float(t)
 
