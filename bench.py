@@ -62,7 +62,7 @@ SAFE_SCHEDULES = ("single", "overlap")
 CAPTURED_SCHEDULES = ("captured_single", "captured_overlap")
 DP_SCHEDULES = CAPTURED_SCHEDULES + SAFE_SCHEDULES
 SCHEDULE_MODE_PREFIX = {"captured_overlap": "ONE hipGraph (fwd + bwd, the two", "captured_single": "ONE hipGraph (fwd + bwd + the captured",
-                        "overlap": "two hipGraphs", "single": "hipGraph(fwd+loss+bwd) + eager"}
+                        "overlap": "two hipGraphs", "single": "hipGraph(fwd+loss+bwd) + eager", "eager": "eager"}
 
 
 def run_bounded(fn, limit_s, thread_setup=None):
@@ -622,6 +622,8 @@ def measure_schedules(args, world, ctrl, trial, fence, want_captured):
          step 1 and leaves without touching the GPU again.
     Returns {"name", "elapsed" (max over ranks, s), "loss", "cand"}."""
     trial.safe(SAFE_SCHEDULES)
+    if not trial.trial_ms:   # stream capture itself does not work here: a number from eager launches rather than no number
+        trial.safe(("eager",))
     assert trial.trial_ms, f"no data-parallel schedule could be built: {trial.failed}"
 
     def run(name, bounded):
@@ -643,7 +645,7 @@ def measure_schedules(args, world, ctrl, trial, fence, want_captured):
             el, loss = val
         return {"name": name, "elapsed": ctrl.max(el), "loss": loss, "cand": cand}
 
-    result = run(trial.best(SAFE_SCHEDULES), bounded=False)
+    result = run(trial.best(SAFE_SCHEDULES + ("eager",)), bounded=False)
     if want_captured:
         trial.optional(CAPTURED_SCHEDULES)
         best = trial.best()
@@ -821,7 +823,8 @@ def main():
         # pins one, PNPP_DP_CAPTURED=1 adds the captured ones behind the secured measurement (measure_schedules).
         capturable = tdist.get_backend() == "nccl"         # RCCL launches are stream work; gloo goes through the host
         want_captured = os.environ.get("PNPP_DP_CAPTURED") == "1"
-        trial = ScheduleTrial(lambda name: build_step(model, opt, xyz, mu_gt, kappa_gt, world, True, schedule=name),
+        trial = ScheduleTrial(lambda name: build_step(model, opt, xyz, mu_gt, kappa_gt, world, name != "eager",
+                                                      schedule=None if name == "eager" else name),
                               lambda step, n: timed(step, n, fence)[0], ctrl,
                               bounded_s=float(os.environ.get("PNPP_DP_BOUNDED_S", "60")),
                               thread_setup=lambda: torch.cuda.set_device(dev))
