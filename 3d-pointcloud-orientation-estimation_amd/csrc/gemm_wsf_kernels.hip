@@ -30,6 +30,21 @@ __device__ __forceinline__ f32x4 wsf_load4(__amdgpu_buffer_rsrc_t r, unsigned la
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)s_off, 0));
 }
 
+#ifndef WSF_EXP   // timing experiments (wrong results): 1 no output stores, 2 no MFMA loop, 4 no operand transform (copy), 8 no statistics / pooling arithmetic
+#define WSF_EXP 0
+#endif
+#ifdef PNPP_STAMPS
+__device__ unsigned long long g_wsf_stamps[4][8];   // [instantiation][phase]: s_memtime ticks of wave 0 of workgroup 8 (no extra waits)
+#define WSF_STAMP(i)                                                   \
+    if (st_on) {                                                       \
+        const unsigned long long st_t = __builtin_amdgcn_s_memtime();  \
+        st_acc[i] += st_t - st_last;                                   \
+        st_last = st_t;                                                \
+    }
+#else
+#define WSF_STAMP(i)
+#endif
+
 // KD in {64, 128}; NT column tiles (of 32) per wave; AX = A_PLAIN or A_BNRELU; EM = E_STORE or E_STORE_STATS
 template <int KD, int NT, int AX, int EM>
 __global__ void __launch_bounds__(256, 2)
@@ -51,6 +66,11 @@ gemm_wsf_kernel(const float *__restrict__ A, int lda, const float *__restrict__ 
         col_blk = i % ncol, worker = (i / ncol) * 8 + xcd;
     }
     const int n0 = col_blk * BN;
+#ifdef PNPP_STAMPS
+    const bool st_on = blockIdx.x == 8 && wave == 0;
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
 
     // per-channel constants of this lane's column group (k = 64 c + 4 q .. + 3): registers for the whole kernel
     const int q4 = 4 * (lane & 15), rb = lane >> 4;   // staging map: column group lane % 16, rows lane / 16 + 4 i
@@ -107,6 +127,7 @@ gemm_wsf_kernel(const float *__restrict__ A, int lda, const float *__restrict__ 
         }
     }
     __syncthreads();   // the weight panel is complete; from here on the waves run on their own
+    WSF_STAMP(0)   // prologue
 
     const float *arow = As + l31 * 64;
     const int ga = (4 * lh) ^ swz(l31);
@@ -123,13 +144,14 @@ gemm_wsf_kernel(const float *__restrict__ A, int lda, const float *__restrict__ 
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 f32x4 v = ra[c][i];
-                if constexpr (AX == A_BNRELU) {
+                if constexpr (AX == A_BNRELU && !(WSF_EXP & 4)) {
                     v[0] = fmaxf(fmaf(v[0], sc[c].x, sh[c].x), 0.f), v[1] = fmaxf(fmaf(v[1], sc[c].y, sh[c].y), 0.f);
                     v[2] = fmaxf(fmaf(v[2], sc[c].z, sh[c].z), 0.f), v[3] = fmaxf(fmaf(v[3], sc[c].w, sh[c].w), 0.f);
                 }
                 const int r = rb + 4 * i;
                 *reinterpret_cast<f32x4 *>(As + r * 64 + (q4 ^ swz(r))) = v;
             }
+            WSF_STAMP(1)   // staging (incl. the wait for the strip's loads)
             if (c == NC - 1 && strip + stride < nstrips) fetch(strip + stride);   // the next strip flies during the MFMAs
             // k = 64 c + 8 t + 4 lh + u: one ds_read_b128 of the strip per t, one of the panel per t and column tile
             const float *brow[NT];
@@ -155,16 +177,21 @@ gemm_wsf_kernel(const float *__restrict__ A, int lda, const float *__restrict__ 
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf].w, fb[buf][j].w, acc[j], 0, 0, 0);
                 }
             };
-            ld(0, 0);
+            if (!(WSF_EXP & 2)) {
+                ld(0, 0);
 #pragma unroll
-            for (int t = 0; t < 8; t += 2) {
-                ld(1, t + 1);
-                mm(0);
-                if (t + 2 < 8) ld(0, t + 2);
-                mm(1);
+                for (int t = 0; t < 8; t += 2) {
+                    ld(1, t + 1);
+                    mm(0);
+                    if (t + 2 < 8) ld(0, t + 2);
+                    mm(1);
+                }
             }
+            WSF_STAMP(2)   // product
         }
-        // epilogue of the strip: 16 rows of one column per lane and column tile
+        // epilogue of the strip: 16 rows of one column per lane and column tile.  (Round 4: the same tile sent through the wave's own
+        // strip buffer and stored as 16 bytes per lane -- whole 128-byte lines, a quarter of the store instructions -- measured 29.5 - 30.0
+        // us against 29.2 us on the sa1 launch: what the stores cost here is their 67 MB, not their issue.)
         float *tb = E.c + (size_t)(strip * 32 + 4 * lh) * E.ldc + n0 + l31;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -172,11 +199,10 @@ gemm_wsf_kernel(const float *__restrict__ A, int lda, const float *__restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[j][r];
-                tb[(size_t)((r & 3) + 8 * (r >> 2)) * E.ldc + j * 32] = v;
-                t1 += v;
-                t2 = fmaf(v, v, t2);
+                if (!(WSF_EXP & 1)) tb[(size_t)((r & 3) + 8 * (r >> 2)) * E.ldc + j * 32] = v;
+                if (!(WSF_EXP & 8)) t1 += v, t2 = fmaf(v, v, t2);
             }
-            if constexpr (EM == E_STORE_STATS) {
+            if constexpr (EM == E_STORE_STATS && !(WSF_EXP & 8)) {
                 s1[j] += (double)t1, s2[j] += (double)t2;
                 if (E.pool_ext) {   // the strip is one neighbourhood: extreme pre-BN value per column and its first row
                     float mx = sg[j] * acc[j][0];
@@ -195,6 +221,7 @@ gemm_wsf_kernel(const float *__restrict__ A, int lda, const float *__restrict__ 
                 }
             }
         }
+        WSF_STAMP(3)   // epilogue: stores, statistics, pooling
     }
 
     if constexpr (EM == E_STORE_STATS) {
@@ -214,6 +241,14 @@ gemm_wsf_kernel(const float *__restrict__ A, int lda, const float *__restrict__ 
             E.slab[((size_t)worker * 2 + which) * Nout + n0 + cl] = t;
         }
     }
+    WSF_STAMP(4)   // tail
+#ifdef PNPP_STAMPS
+    if (st_on && lane == 0) {
+        const int which = (KD == 128 ? 2 : 0) + (Nout >= 256 || (KD == 64 && Nout >= 128) ? 1 : 0);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) g_wsf_stamps[which][i] += st_acc[i];
+    }
+#endif
 }
 
 // A/B switch: PNPP_NO_WSF=1 keeps the forward products on gemm_ws_kernel
@@ -285,4 +320,24 @@ bool try_launch_wsf(const AOperand &A, const BOperand &B, int M, int Nout, int K
     return true;
 }
 
+#ifdef PNPP_STAMPS
+#define PNPP_WSF_STAMPS_BIT 64u
+#else
+#define PNPP_WSF_STAMPS_BIT 0u
+#endif
+unsigned wsf_build_flags() { return ((WSF_EXP != 0) ? 128u : 0u) | PNPP_WSF_STAMPS_BIT; }
+
 }  // namespace pnpp
+
+#ifdef PNPP_STAMPS
+extern "C" int pnpp_debug_wsf_stamps(unsigned long long *out32, int reset) {
+    if (reset) {
+        unsigned long long z[32] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(pnpp::g_wsf_stamps), z, sizeof(z));
+    } else {
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(out32, HIP_SYMBOL(pnpp::g_wsf_stamps), 32 * sizeof(unsigned long long));
+    }
+    return 0;
+}
+#endif

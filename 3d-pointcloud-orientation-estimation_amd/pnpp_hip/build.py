@@ -28,7 +28,7 @@ SOURCES = {
     "gemm_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_bf16_kernels.hip": [],
     "gemm_mid_kernels.hip": [],
-    "gemm_wsf_kernels.hip": [],
+    "gemm_wsf_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []) + ([f"-DWSF_EXP={os.environ['PNPP_WSF_EXP']}"] if os.environ.get("PNPP_WSF_EXP") else []),
     "gemm_wsp_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_wsx_kernels.hip": [],
     "gemm_wsq_kernels.hip": [],
