@@ -1,0 +1,551 @@
+// gemm_wsd3_kernels.hip -- the fused backward product of a grouped level's LAST layer (dA + ReLU mask + BatchNorm-backward sums + dW in
+// one launch) with the float32 products formed on the bf16 matrix pipe from exact three-way operand splits (gemm_wsf3_kernels.hip has
+// the arithmetic), as a PAIR of waves per 32-row strip: one wave builds dZ and multiplies it with the weights, its partner on the
+// same SIMD accumulates the weight gradient from the same LDS image.
+//
+// Reference: the autograd backward of conv -> BatchNorm -> ReLU -> max over the 32 neighbours (models/pointnet_pp_8dir.py:40-42):
+//   dZ_l     = BatchNorm-backward(dY_l, Z_l),  dY_l rebuilt from the pooled gradient and the arg-max rows (A_DZ_POOL)
+//   dY_{l-1} = (dZ_l W_l) masked by ReLU'(layer l-1), + its BatchNorm-backward column sums
+//   dW_l     = dZ_l^T relu(bn(Z_{l-1}))
+//
+// Why pairs.  With split products a strip's two products are 2 x 96 bf16 MFMAs = 6,144 cycles of the matrix pipe, and building the
+// operands (BatchNorm-backward, three-way splits, ReLU mask, sums) is about as many cycles of vector issue.  A bf16 MFMA holds the
+// vector issue for 8 of its 32 cycles, so the two kinds of work CAN overlap on a SIMD -- but only from two waves: one wave per SIMD
+// (gemm_wsp_kernel's form: all dW accumulators of a strip owner are 128 registers) runs them back to back and waits out every LDS
+// latency alone (a first version of this kernel in that form ran 48.4 us against the float32 kernel's 50.4).  Two waves per SIMD
+// leave 256 registers each, which one wave's share of BOTH products does not fit.  So the products are split between two waves:
+//   P (waves 0-3): streams Z_l one strip ahead, computes dZ (one compare + select + FMA per element), splits it, writes the chunk
+//                  image (three bf16 planes of [32 rows][64 channels]) to LDS, multiplies it with the weight panel (dA), masks,
+//                  stores dY_{l-1} and collects the BatchNorm-backward sums;
+//   C (waves 4-7): takes relu(bn(z_{l-1})) of the strip from registers in accumulator layout (eight consecutive registers are one
+//                  32x32x16 operand), reads the SAME image transposed (ds_read_b64_tr_b16, rows in the accumulator layout's order)
+//                  and accumulates dW for the whole launch.
+// Wave w and wave w + 4 of a workgroup sit on the same SIMD and share two image buffers and two counters in LDS: `ready` (chunks P has
+// published) and `done` (chunks C has finished reading).  P writes chunk k into buffer k & 1 once done >= k - 1; C reads it once
+// ready >= k + 1.  LDS operations of one wave complete in order and the counters only grow, so there is no cycle to wait in; the
+// polls are bounded all the same (a timed-out poll sets *err and goes on: wrong numbers, never a hang).
+// Image layout as gemm_wsp3: 16-byte group g of row r at g ^ x(r), x(r) = 4 bit1(r) + bits3:2(r): conflict-free row reads and
+// transposed reads.
+// Shapes: (K = C_l, N = C_{l-1}) = (128, 64) [SA1] and (256, 128) [SA2]; 64 or 32 output columns per workgroup so that the dW tiles of
+// the C wave are 128 registers either way.
+#include <stdlib.h>
+
+#include "kernels.h"
+
+namespace pnpp {
+
+typedef __bf16 wd3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wd3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wd3_f32x2 __attribute__((ext_vector_type(2)));
+typedef short wd3_s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned wd3_pk(float lo, float hi) {
+    const wd3_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wd3_bf16x2));
+}
+__device__ __forceinline__ float wd3_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float wd3_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+__device__ __forceinline__ void wd3_split4(const f32x4 v, uint2 &h, uint2 &m, uint2 &l) {
+    h.x = wd3_pk(v[0], v[1]), h.y = wd3_pk(v[2], v[3]);
+    float r0 = v[0] - wd3_lo(h.x), r1 = v[1] - wd3_hi(h.x), r2 = v[2] - wd3_lo(h.y), r3 = v[3] - wd3_hi(h.y);
+    m.x = wd3_pk(r0, r1), m.y = wd3_pk(r2, r3);
+    r0 -= wd3_lo(m.x), r1 -= wd3_hi(m.x), r2 -= wd3_lo(m.y), r3 -= wd3_hi(m.y);
+    l.x = wd3_pk(r0, r1), l.y = wd3_pk(r2, r3);
+}
+__device__ __forceinline__ wd3_bf16x8 wd3_op(uint4 v) { return __builtin_bit_cast(wd3_bf16x8, v); }
+__device__ __forceinline__ uint2 wd3_tr(const unsigned char *p) {   // ds_read_b64_tr_b16: 4 rows x 16 columns per 16 lanes, transposed
+    const wd3_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wd3_s16x4 *)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wd3_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), (short)0, 0xfffffffe, 0x00020000);
+}
+__device__ __forceinline__ f32x4 wd3_load4(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned s_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)s_off, 0));
+}
+__device__ __forceinline__ float wd3_load1(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned s_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)s_off, 0));
+}
+typedef __attribute__((address_space(3))) volatile unsigned wd3_flag;   // a counter in LDS (ds_read_b32 / ds_write_b32, never flat)
+__device__ int g_wsd3_timeouts;   // set by a poll that gave up (pnpp_debug_wsd3_timeouts)
+// waits until *f >= target (f: an LDS counter that only grows); false after ~2^20 polls
+__device__ __forceinline__ bool wd3_wait(wd3_flag *f, unsigned target) {
+    bool ok = true;
+    unsigned spins = 0;
+    while ((unsigned)__builtin_amdgcn_readfirstlane((int)*f) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 20)) {
+            ok = false;
+            break;
+        }
+    }
+    asm volatile("" ::: "memory");
+    return ok;
+}
+// publishes a counter value after every LDS operation of this wave issued so far has completed
+__device__ __forceinline__ void wd3_post(wd3_flag *f, unsigned v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    *f = v;
+}
+
+#ifdef PNPP_STAMPS
+__device__ unsigned long long g_wsd3_stamps[2][2][8];   // [KD == 256][P, C][phase]: s_memtime ticks of pair 0 of workgroup 8
+#define WD3_STAMP(i)                                                   \
+    if (st_on) {                                                       \
+        const unsigned long long st_t = __builtin_amdgcn_s_memtime();  \
+        st_acc[i] += st_t - st_last;                                   \
+        st_last = st_t;                                                \
+    }
+#else
+#define WD3_STAMP(i)
+#endif
+
+template <int KD, int BN>
+__global__ void __launch_bounds__(512, 1)
+gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, int Nout, int ncol, const Epilogue E) {
+    constexpr int NC = KD / 64, CT = KD / 32, NT = BN / 32;
+    constexpr int WPITCH = KD * 2, WPLANE = BN * WPITCH;     // bytes: row and plane of the weight panel [n][k]
+    constexpr int APLANE = 32 * 128, ABUF = 3 * APLANE;      // bytes: plane and buffer (three planes) of a dZ chunk image
+    constexpr int APAIR = 2 * ABUF;                          // two buffers per wave pair
+    constexpr int OFF_IMG = 3 * WPLANE, OFF_CST = OFF_IMG + 4 * APAIR, OFF_FLG = OFF_CST + 3 * KD * 4;
+    static_assert(NC % 2 == 0, "chunk k of a strip uses buffer k & 1");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    unsigned char *Wp = lds3;
+    float *Tc = reinterpret_cast<float *>(lds3 + OFF_CST);   // [3][KD]: g, a, b of dZ = g dY + a Z + b
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave < 4;
+    const int pair = wave & 3;
+    unsigned char *Ap = lds3 + OFF_IMG + pair * APAIR;
+    wd3_flag *f_ready = (wd3_flag *)(lds3 + OFF_FLG) + 2 * pair, *f_done = f_ready + 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    auto xs = [](int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); };   // chunk XOR of image row r
+    auto xw = [](int n) { return n & 15; };                                  // chunk XOR of panel row n
+
+    const int nworkers = gridDim.x / ncol;
+    int col_blk = blockIdx.x % ncol, worker = blockIdx.x / ncol;
+    if ((nworkers & 7) == 0) {   // XCD-aware: the column blocks of one worker share an L2
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        col_blk = i % ncol, worker = (i / ncol) * 8 + xcd;
+    }
+    const int n0 = col_blk * BN;
+    const int nstrips = M / 32, stride = nworkers * 4;
+    int strip = worker * 4 + pair;
+    const __amdgpu_buffer_rsrc_t resP = wd3_rsrc(E.zp);
+    const __amdgpu_buffer_rsrc_t resNull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A.z), (short)0, 0, 0x00020000);
+    // accumulator positions of a strip of layer l-1 (z_{l-1} in, dY_{l-1} out): row 4 lh + (r & 3) + 8 (r >> 2), column n0 + 32 j + l31
+    const unsigned oq = 4u * ((unsigned)(4 * lh) * (unsigned)Nout + (unsigned)(n0 + l31));
+    // (the lane part `oq` is ONE register; the (column tile, register) part is uniform and rides in the instruction's scalar offset --
+    //  32 per-position address registers were what this kernel spilled, and a spilled address serialises the loads behind vmcnt(0))
+    auto quni = [&](int j, int r) -> unsigned { return 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * Nout + 32 * j); };
+    float e_sc[NT], e_sh[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) e_sc[j] = E.scale[n0 + j * 32 + l31], e_sh[j] = E.shift[n0 + j * 32 + l31];
+
+    // ---- prologue, all eight waves: counters, the constant table, the weight panel ----
+    if (tid < 8) ((wd3_flag *)(lds3 + OFF_FLG))[tid] = 0u;
+    for (int c = tid; c < KD; c += 512) {
+        const float g = A.cst[c], mu = A.cst[A.C + c], is = A.cst[2 * A.C + c], c1 = A.cst[3 * A.C + c], c2 = A.cst[4 * A.C + c];
+        const float a = -g * is * c2;
+        Tc[c] = g, Tc[KD + c] = a, Tc[2 * KD + c] = -g * c1 - a * mu;
+    }
+    {   // W is (KD x Nout) row-major; image [n][k] of columns n0 .. n0 + BN - 1 in three bf16 planes (lane = column n: four dword loads
+        // of consecutive rows k, split, one 8-byte store per plane)
+        constexpr int NWF = (KD / 4) * BN / 512;
+        f32x4 tw[NWF];
+#pragma unroll
+        for (int j = 0; j < NWF; ++j) {
+            const int f = tid + 512 * j, nl = f % BN, k4 = 4 * (f / BN);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tw[j][e] = W[(size_t)(k4 + e) * ldw + n0 + nl];
+        }
+#pragma unroll
+        for (int j = 0; j < NWF; ++j) {
+            const int f = tid + 512 * j, nl = f % BN, k4 = 4 * (f / BN);
+            uint2 h, m, l;
+            wd3_split4(tw[j], h, m, l);
+            unsigned char *dst = Wp + nl * WPITCH + 16 * ((k4 >> 3) ^ xw(nl)) + 2 * (k4 & 7);
+            *reinterpret_cast<uint2 *>(dst) = h;
+            *reinterpret_cast<uint2 *>(dst + WPLANE) = m;
+            *reinterpret_cast<uint2 *>(dst + 2 * WPLANE) = l;
+        }
+    }
+    __syncthreads();
+
+#ifdef PNPP_STAMPS
+    const bool st_on = blockIdx.x == 8 && pair == 0;
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
+    f32x16 dw[CT][NT];            // C waves
+    double s1[NT], s2[NT];        // P waves
+    bool timed_out = false;
+
+    if (producer) {
+        // =========================== P: dZ image, dA, epilogue ===========================
+        const int q = lane & 15, q4 = 4 * q, rb = lane >> 4;   // staging map: channels 64 c + 4 q .. + 3, rows rb + 4 i
+        const __amdgpu_buffer_rsrc_t resZ = wd3_rsrc(A.z), resY = wd3_rsrc(A.a), resI = wd3_rsrc(A.arg), resC = wd3_rsrc(E.c);
+        const unsigned oa0 = 4u * ((unsigned)rb * (unsigned)KD + (unsigned)q4);
+        f32x4 rz[2][8], rdm[2];   // two chunk register sets in flight
+        int4 rarg[2];
+        float zq[NT][16];
+        auto fetch_chunk = [&](bool have, int s, int c) {   // chunk c of strip s into register set c & 1
+            const __amdgpu_buffer_rsrc_t rZ = have ? resZ : resNull, rY = have ? resY : resNull, rI = have ? resI : resNull;
+            const unsigned so = (unsigned)s * (32u * KD * 4u) + 256u * (unsigned)c;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rz[c & 1][i] = wd3_load4(rZ, oa0, so + (unsigned)i * (4u * KD * 4u));
+            const unsigned sg = (unsigned)s * (KD * 4u) + 256u * (unsigned)c;   // one row of the pooled tables per strip
+            rdm[c & 1] = wd3_load4(rY, 4u * (unsigned)q4, sg);
+            rarg[c & 1] = __builtin_bit_cast(int4, wd3_load4(rI, 4u * (unsigned)q4, sg));
+        };
+        {
+            const bool have = strip < nstrips;
+            fetch_chunk(have, strip, 0);
+            fetch_chunk(have, strip, 1);
+            const __amdgpu_buffer_rsrc_t rP = have ? resP : resNull;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zq[j][r] = wd3_load1(rP, oq, (unsigned)strip * (32u * (unsigned)Nout * 4u) + quni(j, r));
+        }
+        double e_mu[NT], e_is[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            e_mu[j] = (double)E.mu[n0 + j * 32 + l31], e_is[j] = (double)E.istd[n0 + j * 32 + l31];
+            s1[j] = s2[j] = 0.0;
+        }
+        // LDS offsets of this lane inside a chunk-image plane: staging (row rb + 4 i: x(r) = 4 bit1(rb) + (i & 3)) and row reads
+        unsigned wofs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wofs[i] = (unsigned)(rb * 128 + 16 * ((q >> 1) ^ (((rb >> 1) & 1) << 2 | i)) + 8 * (q & 1));
+        const unsigned arow = (unsigned)(l31 * 128);
+        const int ax = xs(l31);
+        const unsigned char *brow[NT];
+        int bx[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            brow[j] = Wp + (j * 32 + l31) * WPITCH;
+            bx[j] = xw(j * 32 + l31);
+        }
+#ifdef WD3_PRIO
+        __builtin_amdgcn_s_setprio(WD3_PRIO);
+#endif
+        unsigned kbase = 0;   // chunks of the strips before this one
+        // ---- stage chunk c of strip s (sequence number k) into buffer c & 1: dZ in registers, split, three 8-byte stores per group; then
+        // the register set is free and the chunk two ahead goes out ----
+        auto stage = [&](int c, unsigned k, int s, bool more2, int s2) {   // (more2, s2): the strip the chunk two ahead belongs to
+            unsigned char *Ab = Ap + (c & 1) * ABUF;
+            const float4 cg = *reinterpret_cast<const float4 *>(Tc + 64 * c + q4), ca = *reinterpret_cast<const float4 *>(Tc + KD + 64 * c + q4);
+            const float4 cb = *reinterpret_cast<const float4 *>(Tc + 2 * KD + 64 * c + q4);
+            const f32x4 dm = rdm[c & 1];
+            const int4 ar = rarg[c & 1];
+            float4 bt;   // b + g dm: what the arg-max row of a channel starts from
+            bt.x = fmaf(cg.x, dm[0], cb.x), bt.y = fmaf(cg.y, dm[1], cb.y), bt.z = fmaf(cg.z, dm[2], cb.z), bt.w = fmaf(cg.w, dm[3], cb.w);
+            WD3_STAMP(0)   // constants, pooled tables
+            if (k >= 2) timed_out |= !wd3_wait(f_done, k - 1);   // the partner has finished with this buffer
+            WD3_STAMP(1)   // wait for the buffer
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 z = rz[c & 1][i];
+                const int r = rb + 4 * i;
+                f32x4 v;
+                v[0] = fmaf(ca.x, z[0], r == ar.x ? bt.x : cb.x), v[1] = fmaf(ca.y, z[1], r == ar.y ? bt.y : cb.y);
+                v[2] = fmaf(ca.z, z[2], r == ar.z ? bt.z : cb.z), v[3] = fmaf(ca.w, z[3], r == ar.w ? bt.w : cb.w);
+                uint2 h, m, l;
+                wd3_split4(v, h, m, l);
+                unsigned char *dst = Ab + wofs[i & 3] + i * 512;
+                *reinterpret_cast<uint2 *>(dst) = h;
+                *reinterpret_cast<uint2 *>(dst + APLANE) = m;
+                *reinterpret_cast<uint2 *>(dst + 2 * APLANE) = l;
+            }
+            WD3_STAMP(2)   // staging
+            wd3_post(f_ready, k + 1);
+            if (c + 2 < NC) fetch_chunk(true, s, c + 2);
+            else fetch_chunk(more2, s2, c + 2 - NC);
+            WD3_STAMP(3)   // publish + next loads issued
+        };
+        if (strip < nstrips) stage(0, 0u, strip, strip + stride < nstrips, strip + stride);
+        for (; strip < nstrips; strip += stride, kbase += NC) {
+            const bool more = strip + stride < nstrips;
+            const int snext = strip + stride;
+            f32x16 acc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const unsigned char *Ab = Ap + (c & 1) * ABUF;
+                if (c > 0) stage(c, kbase + c, strip, more, snext);
+                // ---- dA += dZ_chunk W_chunk: step t covers k = 64 c + 16 t + 8 lh + (0 .. 7) ----
+                // one fragment set: the partner wave covers this wave's LDS latency (and 256 registers do not hold two)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int g = 2 * t + lh;
+                    uint4 fa[3], fb[NT][3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) fa[p] = *reinterpret_cast<const uint4 *>(Ab + p * APLANE + arow + 16 * (g ^ ax));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            fb[j][p] = *reinterpret_cast<const uint4 *>(brow[j] + p * WPLANE + 16 * ((8 * c + g) ^ bx[j]));
+                    const wd3_bf16x8 ah = wd3_op(fa[0]), am = wd3_op(fa[1]), al = wd3_op(fa[2]);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const wd3_bf16x8 bh = wd3_op(fb[j][0]), bm = wd3_op(fb[j][1]), bl = wd3_op(fb[j][2]);
+                        f32x16 d = acc[j];   // the small products first, the leading one last
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, d, 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, d, 0, 0, 0);
+                    }
+                }
+                WD3_STAMP(4)   // dA product of the chunk (issue; the last MFMAs may still run)
+            }
+            // the next strip's first chunk goes to the partner BEFORE this strip's epilogue: the partner multiplies while this wave
+            // stores, and the wait for that chunk's operands has only the other chunk's loads behind it (behind the epilogue's 64 memory
+            // operations the compiler can no longer count and waits for everything)
+            if (more) stage(0, kbase + NC, snext, snext + stride < nstrips, snext + stride);
+            // ---- epilogue: mask, store, BatchNorm-backward sums of layer l-1; each z_{l-1} register is re-loaded for the next strip
+            // right behind its use ----
+            {
+                const unsigned sc_off = (unsigned)strip * (32u * (unsigned)Nout * 4u), sn_off = (unsigned)snext * (32u * (unsigned)Nout * 4u);
+                const __amdgpu_buffer_rsrc_t nP = more ? resP : resNull;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float z0 = zq[j][r];
+                        const float v = fmaf(z0, e_sc[j], e_sh[j]) > 0.f ? acc[j][r] : 0.f;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), resC, (int)oq, (int)(sc_off + quni(j, r)), 0);
+                        t1 += v;
+                        t2 = fmaf(v, z0, t2);
+                        zq[j][r] = wd3_load1(nP, oq, sn_off + quni(j, r));
+                    }
+                    const double d1 = (double)t1;   // sum v xhat = istd (sum v z - mu sum v), finished in float64
+                    s1[j] += d1, s2[j] += e_is[j] * ((double)t2 - e_mu[j] * d1);
+                }
+            }
+            WD3_STAMP(5)   // epilogue
+        }
+    } else {
+        // =========================== C: dW from the partner's image ===========================
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dw[i][j][r] = 0.f;
+        float zq[NT][16];
+        {
+            const __amdgpu_buffer_rsrc_t rP = strip < nstrips ? resP : resNull;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zq[j][r] = wd3_load1(rP, oq, (unsigned)strip * (32u * (unsigned)Nout * 4u) + quni(j, r));
+        }
+        unsigned tofs[2][2][2];   // transposed reads [c-tile of the chunk][step s][block]: rows 16 s + 8 blk + 4 lh + qq, columns 32 it + l31
+        {
+            const int gi = lane & 15, qq = gi >> 2, pp = gi & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int r = 16 * s + 8 * b + 4 * lh + qq, ch = 4 * it + 2 * g1 + (pp >> 1);
+                        tofs[it][s][b] = (unsigned)(r * 128 + 16 * (ch ^ xs(r)) + 8 * (pp & 1));
+                    }
+        }
+        unsigned kbase = 0;
+        for (; strip < nstrips; strip += stride, kbase += NC) {
+            const bool more = strip + stride < nstrips;
+            // ---- relu(bn(z_{l-1})) of the strip: the dW product's B fragments straight from the registers; then the registers take the
+            // next strip's values ----
+            uint4 bfr[NT][2][3];   // [column tile][step][piece]
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float act[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) act[r] = fmaxf(fmaf(zq[j][r], e_sc[j], e_sh[j]), 0.f);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    f32x4 v0, v1;
+                    v0[0] = act[8 * s + 0], v0[1] = act[8 * s + 1], v0[2] = act[8 * s + 2], v0[3] = act[8 * s + 3];
+                    v1[0] = act[8 * s + 4], v1[1] = act[8 * s + 5], v1[2] = act[8 * s + 6], v1[3] = act[8 * s + 7];
+                    uint2 h0, m0, l0, h1, m1, l1;
+                    wd3_split4(v0, h0, m0, l0);
+                    wd3_split4(v1, h1, m1, l1);
+                    bfr[j][s][0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    bfr[j][s][1] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+                    bfr[j][s][2] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                }
+            }
+            {
+                const __amdgpu_buffer_rsrc_t nP = more ? resP : resNull;
+                const unsigned sn_off = (unsigned)(strip + stride) * (32u * (unsigned)Nout * 4u);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zq[j][r] = wd3_load1(nP, oq, sn_off + quni(j, r));
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const unsigned char *Ab = Ap + (c & 1) * ABUF;
+                WD3_STAMP(0)   // activation fragments (first chunk) / loop turn-around
+                timed_out |= !wd3_wait(f_ready, kbase + c + 1);
+                WD3_STAMP(1)   // wait for the chunk
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        uint4 ta[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            const uint2 lo = wd3_tr(Ab + p * APLANE + tofs[it][s][0]), hi = wd3_tr(Ab + p * APLANE + tofs[it][s][1]);
+                            ta[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        }
+                        if (it == 1 && s == 1) wd3_post(f_done, kbase + c + 1);   // the last reads of this buffer have landed
+                        const wd3_bf16x8 ah = wd3_op(ta[0]), am = wd3_op(ta[1]), al = wd3_op(ta[2]);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const wd3_bf16x8 bh = wd3_op(bfr[j][s][0]), bm = wd3_op(bfr[j][s][1]), bl = wd3_op(bfr[j][s][2]);
+                            f32x16 d = dw[2 * c + it][j];
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, d, 0, 0, 0);
+                            dw[2 * c + it][j] = d;
+                        }
+                    }
+                WD3_STAMP(2)   // transposed reads + dW products of the chunk
+            }
+        }
+    }
+#ifdef PNPP_STAMPS
+    if (st_on && lane == 0)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_wsd3_stamps[KD == 256][producer ? 0 : 1][i] += st_acc[i];
+#endif
+    if (timed_out && lane == 0) atomicExch(&g_wsd3_timeouts, 1);
+
+    // ---- tails: one dW partial per workgroup (the four C waves' tiles added through LDS), the column statistics of the P waves ----
+    __syncthreads();   // every wave is done with the panel and the images
+    constexpr int NTILE = CT * NT;
+    f32x4 *red = reinterpret_cast<f32x4 *>(lds3);                    // [tile][C wave][r4][lane]
+    double *dred = reinterpret_cast<double *>(lds3 + NTILE * 4 * 4 * 64 * 16);   // [P wave][2][BN]
+    if (!producer) {
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 v;
+                    v[0] = dw[i][j][4 * r4], v[1] = dw[i][j][4 * r4 + 1], v[2] = dw[i][j][4 * r4 + 2], v[3] = dw[i][j][4 * r4 + 3];
+                    red[(((i * NT + j) * 4 + pair) * 4 + r4) * 64 + lane] = v;
+                }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const double a = s1[j] + shfl_xor_f64(s1[j], 32), b = s2[j] + shfl_xor_f64(s2[j], 32);
+            if (lh == 0) dred[(pair * 2 + 0) * BN + j * 32 + l31] = a, dred[(pair * 2 + 1) * BN + j * 32 + l31] = b;
+        }
+    }
+    __syncthreads();
+    {
+        float *wb = E.dwslab + (size_t)worker * KD * E.dw_ld + n0;
+        for (int t = wave; t < NTILE; t += 8) {   // tile t = (c-tile i, column tile j)
+            const int i = t / NT, j = t % NT;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 a0 = red[((t * 4 + 0) * 4 + r4) * 64 + lane], a1 = red[((t * 4 + 1) * 4 + r4) * 64 + lane];
+                const f32x4 a2 = red[((t * 4 + 2) * 4 + r4) * 64 + lane], a3 = red[((t * 4 + 3) * 4 + r4) * 64 + lane];
+                const int c0 = i * 32 + 8 * r4 + 4 * lh;
+                float *o = wb + (size_t)c0 * E.dw_ld + j * 32 + l31;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[(size_t)e * E.dw_ld] = (a0[e] + a1[e]) + (a2[e] + a3[e]);
+            }
+        }
+        if (tid < 2 * BN) {
+            const int which = tid / BN, cl = tid % BN;
+            const double t = (dred[(0 * 2 + which) * BN + cl] + dred[(1 * 2 + which) * BN + cl]) +
+                             (dred[(2 * 2 + which) * BN + cl] + dred[(3 * 2 + which) * BN + cl]);
+            E.slab[((size_t)worker * 2 + which) * Nout + n0 + cl] = t;
+        }
+    }
+}
+
+template <int KD, int BN>
+static void wsd3_launch(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int workers, int ncol, hipStream_t st) {
+    constexpr size_t main_b = (size_t)3 * BN * KD * 2 + (size_t)4 * 2 * 3 * 32 * 128 + (size_t)3 * KD * 4 + 64;
+    constexpr size_t red_b = (size_t)(KD / 32) * (BN / 32) * 4 * 4 * 64 * 16 + (size_t)4 * 2 * BN * 8;
+    constexpr size_t lds = main_b > red_b ? main_b : red_b;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kfn = gemm_wsd3_kernel<KD, BN>;
+    static bool granted = false;
+    if (!granted) {
+        (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        granted = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(workers * ncol), dim3(512), lds, st, A, B.b, B.ldb, M, Nout, ncol, E);
+}
+
+bool wsd3_applies(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E) {
+    if (!split_products() || matmul_precision() != 0) return false;
+    if (M < 8192 || M % 32 != 0 || !((Kd == 128 && Nout == 64) || (Kd == 256 && Nout == 128))) return false;
+    if (A.mode != A_DZ_POOL || A.K != 32) return false;
+    if (E.mode != E_MASK_STATS || !E.dwslab || E.dw_ld < Nout) return false;
+    if (B.trans || B.perm_D >= 0 || (B.rows > 0 && B.rows != Kd) || B.ldb < Nout) return false;
+    if (A.lda != Kd || A.C != Kd || E.ldc != Nout) return false;
+    if ((((uintptr_t)A.a | (uintptr_t)A.z | (uintptr_t)A.arg | (uintptr_t)E.zp | (uintptr_t)E.c | (uintptr_t)A.cst) & 15) != 0) return false;
+    if ((unsigned long long)M * (unsigned)Kd * 4ull >= 0xfffffff0ull) return false;   // 32-bit buffer offsets
+    return true;
+}
+
+bool try_launch_wsd3(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc,
+                     int *dw_slabs) {
+    *rc = PNPP_OK;
+    if (!dw_slabs || !wsd3_applies(A, B, M, Nout, Kd, E)) return false;
+    const int nstrips = M / 32, ncol = Kd == 128 ? Nout / 64 : Nout / 32;
+    int workers = 256 / ncol;   // one workgroup of eight waves per CU
+    if (workers * 4 > nstrips) workers = (nstrips + 3) / 4;
+    if (workers > kMaxStatBlocks) workers = kMaxStatBlocks;
+    if (nslab) *nslab = workers;
+    *dw_slabs = workers;
+    ProfScope ps(st, "gemm_wsd3_kernel<%d,%d> M=%d N=%d K=%d grid=%dx1", Kd, Kd == 128 ? 64 : 32, M, Nout, Kd, workers * ncol);
+    if (Kd == 128) wsd3_launch<128, 64>(A, B, M, Nout, E, workers, ncol, st);
+    else wsd3_launch<256, 32>(A, B, M, Nout, E, workers, ncol, st);
+    if (hipGetLastError() != hipSuccess) {
+        set_error("gemm_wsd3: launch failed");
+        *rc = PNPP_ERR_LAUNCH;
+    }
+    return true;
+}
+
+int wsd3_timeouts() {
+    int v = 0;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_wsd3_timeouts), sizeof(int));
+    return v;
+}
+
+}  // namespace pnpp
+
+extern "C" int pnpp_debug_wsd3_timeouts(void) { return pnpp::wsd3_timeouts(); }
+#ifdef PNPP_STAMPS
+extern "C" int pnpp_debug_wsd3_stamps(unsigned long long *out32, int reset) {
+    if (reset) {
+        unsigned long long z[32] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(pnpp::g_wsd3_stamps), z, sizeof(z));
+    } else {
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(out32, HIP_SYMBOL(pnpp::g_wsd3_stamps), 32 * sizeof(unsigned long long));
+    }
+    return 0;
+}
+#endif

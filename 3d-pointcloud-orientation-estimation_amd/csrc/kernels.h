@@ -141,6 +141,20 @@ bool try_launch_mid_gemm(const AOperand &A, const BOperand &B, int M, int Nout, 
 bool mid_gemm_pools(const AOperand &A, int M, int Nout, int Kd);
 // gemm_wsf_kernels.hip: forward products of the grouped levels on wave-private row strips (no barrier in the tile loop)
 bool try_launch_wsf(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc);
+bool wsf_applies(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E);
+// gemm_wsf3_kernels.hip: the same launches with the float32 products formed on the bf16 matrix pipe from exact three-way operand
+// splits (six bf16 x bf16 products per float32 product, float32 accumulation); pnpp_set_split_products / PNPP_SPLIT_PRODUCTS
+int split_products();
+void set_split_products(int on);
+bool try_launch_wsf3(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc);
+// gemm_wsd3_kernels.hip: the fused backward product of a level's last layer (pooled gradient), split products, a producer and a consumer
+// wave per strip
+bool try_launch_wsd3(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc,
+                     int *dw_slabs);
+int wsd3_timeouts();
+// gemm_wsp3_kernels.hip: the fused backward product (dA + mask + sums + dW) of a grouped layer with 128 output channels, same arithmetic
+bool try_launch_wsp3(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc,
+                     int *dw_slabs);
 // gemm_wsp_kernels.hip: the fused backward product (dA + mask + sums + dW) of a grouped layer with a 64-channel input, wave-private strips
 bool try_launch_wsp(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc,
                     int *dw_slabs);

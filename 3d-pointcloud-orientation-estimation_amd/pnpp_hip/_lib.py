@@ -83,6 +83,7 @@ SIGNATURES = {
     "pnpp_sa_saved_argmax": (_fp, [C.POINTER(SaDesc), _fp]),
     "pnpp_sa_saved_relu_mask": (_i, [C.POINTER(SaDesc), _fp, _fp, _fp, _i, _fp, _fp]),
     "pnpp_build_flags": (C.c_uint, []),
+    "pnpp_debug_wsd3_timeouts": (_i, []),
     "pnpp_fc_saved_bytes": (_sz, [C.POINTER(FcDesc)]),
     "pnpp_fc_scratch_bytes": (_sz, [C.POINTER(FcDesc)]),
     "pnpp_fc_forward": (_i, [C.POINTER(FcDesc), C.POINTER(FcFwdArgs), _fp]),
@@ -122,6 +123,8 @@ SIGNATURES = {
     "pnpp_set_stats_exchange": (_i, [STATS_EXCHANGE_FN, C.c_void_p, C.c_void_p, _sz]),
     "pnpp_stats_exchange_enabled": (_i, []),
     "pnpp_get_matmul_precision": (_i, []),
+    "pnpp_set_split_products": (_i, [_i]),
+    "pnpp_get_split_products": (_i, []),
     "pnpp_adam_step": (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _f, _f, _f, _f, _fp]),
     "pnpp_adam_step_zero": (_i, [_fp, _fp, _fp, _fp, _sz, _i, _f, _f, _f, _f, _f, _fp]),
     "pnpp_adam_step_dev": (_i, [_fp, _fp, _fp, _fp, _sz, _fp, _f, _f, _f, _f, _f, _i, _fp]),

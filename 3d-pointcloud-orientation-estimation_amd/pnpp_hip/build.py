@@ -23,12 +23,18 @@ ARCH = "gfx950"
 COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed"]
 # per-file extra flags: the index kernels pin the reference's float32 rounding sequence, so the
 # compiler must not introduce fused multiply-adds of its own there
+# the split-product kernels: packed float32 vector instructions (what the SLP vectoriser makes of the operand splits) issue slower beside
+# MFMAs than the scalar forms (measured: 47.9 -> 42.1 us on the sa1 launch)
+_NOSLP = [] if os.environ.get("PNPP_SLP") else ["-fno-slp-vectorize"]
 SOURCES = {
     "index_kernels.hip": ["-ffp-contract=off"],
     "gemm_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_bf16_kernels.hip": [],
     "gemm_mid_kernels.hip": [],
     "gemm_wsf_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []) + ([f"-DWSF_EXP={os.environ['PNPP_WSF_EXP']}"] if os.environ.get("PNPP_WSF_EXP") else []),
+    "gemm_wsf3_kernels.hip": _NOSLP,
+    "gemm_wsp3_kernels.hip": _NOSLP,
+    "gemm_wsd3_kernels.hip": _NOSLP + (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_wsp_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_wsx_kernels.hip": [],
     "gemm_wsq_kernels.hip": [],
@@ -63,8 +69,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
-            jobs.append([hipcc, *COMMON, *extra, "-c", s, "-o", o])
+        cmd = [hipcc, *COMMON, *extra, "-c", s, "-o", o]
+        stale_flags = not os.path.exists(o + ".cmd") or open(o + ".cmd").read() != " ".join(cmd)   # an object belongs to its command line
+        if force or stale_flags or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
+            jobs.append(cmd)
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -72,6 +80,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stderr[-4000:])
         if verbose and r.stderr:
             sys.stderr.write(r.stderr)
+        if "-c" in cmd:
+            with open(cmd[-1] + ".cmd", "w") as f:
+                f.write(" ".join(cmd))
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:

@@ -113,6 +113,20 @@ def get_matmul_precision() -> str:
     return "bf16" if L.lib().pnpp_get_matmul_precision() else "f32"
 
 
+def set_float32_products(mode: str) -> None:
+    """How the float32 products of the grouped layers' large GEMMs are formed: 'split' (default: six exact bf16 x bf16 partial products
+    of three-way operand splits on the bf16 matrix pipe, float32 accumulation -- float32 results to float32 rounding, 2.67 x the
+    float32 MFMA rate; csrc/gemm_wsf3_kernels.hip) or 'mfma' (v_mfma_f32_32x32x2_f32).  Process-wide; unrelated to
+    set_matmul_precision, which ROUNDS operands to one bfloat16."""
+    if mode not in ("split", "mfma"):
+        raise ValueError(f"float32 products must be 'split' or 'mfma', got {mode!r}")
+    L.check(L.lib().pnpp_set_split_products(1 if mode == "split" else 0))
+
+
+def get_float32_products() -> str:
+    return "split" if L.lib().pnpp_get_split_products() else "mfma"
+
+
 # ------------------------------------------------------------------------------------------------
 # index primitives
 # ------------------------------------------------------------------------------------------------
@@ -319,7 +333,7 @@ class _SetAbstraction(torch.autograd.Function):
         ctx.has_points = points is not None
         # which kernels a level takes depends on process-wide switches (bf16 operands, SyncBN); a level on raw coordinates keeps no
         # Z_0 for the generic backward kernels, so its backward pass must run under the switches its forward pass ran under
-        ctx.path_state = (lib.pnpp_get_matmul_precision(), lib.pnpp_stats_exchange_enabled())
+        ctx.path_state = (lib.pnpp_get_matmul_precision(), lib.pnpp_stats_exchange_enabled(), lib.pnpp_get_split_products())
         ctx.save_for_backward(xyz, points if points is not None else xyz.new_empty(0), saved, *conv_w, *bn_w, *bn_b)
         if group_all:
             nbr = torch.empty(0, dtype=torch.int32, device=xyz.device)
@@ -352,7 +366,7 @@ class _SetAbstraction(torch.autograd.Function):
         conv_w, bn_w, bn_b = t[3:3 + Lh], t[3 + Lh:3 + 2 * Lh], t[3 + 2 * Lh:3 + 3 * Lh]
         dout = _f32(dout, "dout")
         lib = L.lib()
-        if ctx.path_state != (lib.pnpp_get_matmul_precision(), lib.pnpp_stats_exchange_enabled()):
+        if ctx.path_state != (lib.pnpp_get_matmul_precision(), lib.pnpp_stats_exchange_enabled(), lib.pnpp_get_split_products()):
             raise ValueError("set_abstraction: matmul precision or SyncBN was switched between this level's forward pass and its "
                              "backward pass; the kept workspace belongs to the kernels the forward pass took")
         scratch = _scratch(lib.pnpp_sa_scratch_bytes(C.byref(desc)), xyz.device)

@@ -38,6 +38,9 @@ N_POINTS = 1024
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32x32x2_f32)
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: BF16 dense (the opt-in bf16-operand variant's kernels)
+# float32 products formed as six exact bf16 x bf16 partial products (csrc/gemm_wsf3_kernels.hip): float32-equivalent FLOP/s of the bf16 pipe
+MFMA_SPLIT_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
+SPLIT_KERNELS = ("gemm_wsf3_kernel", "gemm_wsp3_kernel", "gemm_wsd3_kernel")
 FLOPS_PER_CLOUD = 0.8542e9     # 3 x 2 x 142,369,280 MAC, forward + backward, independent of N
 BYTES_PER_CLOUD = 34.6e6       # 5 E + 3 G float32 words + xyz / indices
 
@@ -313,7 +316,11 @@ def kernel_cost(tag: str):
         m = re.search(pattern, text)
         return tuple(int(x) for x in m.groups()) if m else None
 
-    if tag.startswith(("gemm_wsp_kernel", "gemm_wsq_kernel")):
+    if tag.startswith("gemm_wsp3_kernel") and ",A4>" in tag:
+        # the same fused product with a DENSE upstream gradient (a grouped level's middle layer): dY_l and Z_l read once
+        M, N, K = ints(r"M=(\d+) N=(\d+) K=(\d+)")
+        return 4.0 * M * N * K, 4.0 * (2.0 * M * K + 2.0 * M * N + 2.0 * K * N)
+    if tag.startswith(("gemm_wsp_kernel", "gemm_wsq_kernel", "gemm_wsp3_kernel", "gemm_wsd3_kernel")):
         # the fused backward product of a level's last layer on gemm_wsp / gemm_wsq: dA (+ ReLU mask, sums) and dW in one launch;
         # Z_l and z_{l-1} read once, dY_{l-1} written once, the weights read and dW written once.  The kernel's own dW partial
         # slabs (one per workgroup) are NOT algorithmic bytes: they show up in `traffic` (round 3 counted them here and read 1.035 x;
@@ -371,6 +378,22 @@ def kernel_cost(tag: str):
         M, N, K = ints(r"M=(\d+) N=(\d+) K=(\d+)")
         dzm, = ints(r"<A(\d),")
         return 2.0 * M * N * K, 4.0 * M * N * (2 if dzm == 4 else 1) + 4.0 * M
+    if tag.startswith("attention_"):
+        # models/point_transformer.py's self-attention (head width 16, csrc/transformer_kernels.hip ATT_DH): 2 flops per MAC of
+        # the N x N products each pass forms (forward: S, PV; dQ pass: S, dP, dQ; dK/dV pass: S, dP, dV, dK); q, k, v (and o, do, the
+        # row statistics in the backward passes) read once, the result written once -- the N x N matrices never leave the chip
+        bnh = ints(r"B=(\d+) N=(\d+) H=(\d+)")
+        if not bnh:
+            return None
+        B, N, H = bnh
+        pair, row = 2.0 * B * H * N * N * 16.0, 4.0 * B * N * H * 16.0
+        if tag.startswith("attention_fwd_kernel"):
+            return 2.0 * pair, 4.0 * row + 4.0 * B * N * H
+        if tag.startswith("attention_bwd_dq_kernel"):
+            return 3.0 * pair, 6.0 * row + 8.0 * B * N * H
+        if tag.startswith("attention_bwd_dkv_kernel"):
+            return 4.0 * pair, 7.0 * row + 8.0 * B * N * H
+        return None
     if tag.startswith("adam_kernel") or tag.startswith("adam"):
         n = ints(r"n=(\d+)")
         return (0.0, 28.0 * n[0]) if n else None            # p, g, m, v read; p, m, v written
@@ -379,7 +402,8 @@ def kernel_cost(tag: str):
         return None
     M, N, K = mnk
     flops = 2.0 * M * N * K
-    if tag.startswith(("gemm_kernel", "gemm_ws_kernel", "gemm_wsb_kernel", "gemm_wsf_kernel", "gemm_smallm_kernel", "gemm_mid_kernel")):
+    if tag.startswith(("gemm_kernel", "gemm_ws_kernel", "gemm_wsb_kernel", "gemm_wsf_kernel", "gemm_wsf3_kernel", "gemm_smallm_kernel",
+                       "gemm_mid_kernel")):
         a, e = ints(r"A(\d),E(\d)")
         byts = 4.0 * (M * N + K * N)                      # write C, read weights
         byts += 4.0 * M * K * (2 if a == 4 else 1)        # read A (dy and z for the BatchNorm-backward operand; A5: z only,
@@ -411,41 +435,19 @@ def csrc_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def roofline_leg(step, nsteps=5):
-    """Instrumented pass: HIP events around every launch, aggregated per (kernel, shape) tag."""
-    from pnpp_hip import _lib
-    import ctypes
-    lib = _lib.lib()
-    torch.cuda.synchronize()
-    lib.pnpp_profile_enable(1)
-    for _ in range(nsteps):
-        step()
-    torch.cuda.synchronize()
-    buf = ctypes.create_string_buffer(1 << 16)
-    ntag = lib.pnpp_profile_report(buf, len(buf))
-    lib.pnpp_profile_enable(0)
-    rows = []
-    for line in buf.value.decode().splitlines():
-        tag, cnt, ms = line.split("\t")
-        rows.append((tag, int(cnt), float(ms)))
-    if ntag <= 0 or not rows:
-        return None, [], None
-    rows.sort(key=lambda r: -r[2])
+def dominant_roofline(rows, nsteps):
+    """The `roofline` object of the bench line for the costliest kernel that has a cost model.  rows: (tag, launches, total ms)
+    as pnpp_profile_report gives them, over `nsteps` steps."""
     total = sum(r[2] for r in rows)
-    table = [{"kernel": t, "launches": c, "avg_us": 1e3 * ms / c, "share": ms / total} for t, c, ms in rows[:12]]
-    dump = os.environ.get("PNPP_BENCH_DUMP")
-    if dump:                                               # full per-kernel table for offline analysis
-        with open(dump, "w") as f:
-            f.write(f"# total kernel ms per step {total / nsteps:.4f}\n")
-            for t, c, ms in rows:
-                f.write(f"{1e3 * ms / nsteps:9.1f} us/step  {c / nsteps:4.1f} x {1e3 * ms / c:8.1f} us  {t}\n")
+    rows = sorted(rows, key=lambda r: -r[2])
     for tag, cnt, ms in rows:                              # dominant kernel that has a cost model
         cost = kernel_cost(tag)
         if cost is None:
             continue
         flops, byts = cost
         sec = ms * 1e-3 / cnt
-        peak_tf = MFMA_BF16_PEAK_TFLOPS if tag.startswith("gemm_wsb_kernel") else MFMA_F32_PEAK_TFLOPS
+        peak_tf = (MFMA_BF16_PEAK_TFLOPS if tag.startswith("gemm_wsb_kernel") else MFMA_SPLIT_PEAK_TFLOPS if tag.startswith(SPLIT_KERNELS)
+                   else MFMA_F32_PEAK_TFLOPS)
         t_mfma, t_hbm = flops / (peak_tf * 1e12), byts / (HBM_PEAK_GBS * 1e9)
         if t_mfma >= t_hbm:
             ach = flops / sec / 1e12
@@ -474,8 +476,39 @@ def roofline_leg(step, nsteps=5):
                     roof["traffic_stale"] = f"profiles/pmc_traffic.json was taken at {meta.get('git')} with other kernel sources"
             except Exception:
                 pass
-        return roof, table, total / nsteps
-    return None, table, total / nsteps
+        return roof
+    return None
+
+
+def roofline_leg(step, nsteps=5):
+    """Instrumented pass: HIP events around every launch, aggregated per (kernel, shape) tag."""
+    from pnpp_hip import _lib
+    import ctypes
+    lib = _lib.lib()
+    torch.cuda.synchronize()
+    lib.pnpp_profile_enable(1)
+    for _ in range(nsteps):
+        step()
+    torch.cuda.synchronize()
+    buf = ctypes.create_string_buffer(1 << 16)
+    ntag = lib.pnpp_profile_report(buf, len(buf))
+    lib.pnpp_profile_enable(0)
+    rows = []
+    for line in buf.value.decode().splitlines():
+        tag, cnt, ms = line.split("\t")
+        rows.append((tag, int(cnt), float(ms)))
+    if ntag <= 0 or not rows:
+        return None, [], None
+    rows.sort(key=lambda r: -r[2])
+    total = sum(r[2] for r in rows)
+    table = [{"kernel": t, "launches": c, "avg_us": 1e3 * ms / c, "share": ms / total} for t, c, ms in rows[:12]]
+    dump = os.environ.get("PNPP_BENCH_DUMP")
+    if dump:                                               # full per-kernel table for offline analysis
+        with open(dump, "w") as f:
+            f.write(f"# total kernel ms per step {total / nsteps:.4f}\n")
+            for t, c, ms in rows:
+                f.write(f"{1e3 * ms / nsteps:9.1f} us/step  {c / nsteps:4.1f} x {1e3 * ms / c:8.1f} us  {t}\n")
+    return dominant_roofline(rows, nsteps), table, total / nsteps
 
 
 def cpu_baseline(B, budget_s=16.0):
@@ -744,6 +777,12 @@ def main():
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
                     help="f32 (default, the reference's arithmetic: the headline) or bf16 (opt-in throughput mode: bf16 MFMA operands, "
                          "f32 accumulate, reported under its own metric key)")
+    ap.add_argument("--f32-products", choices=["split", "mfma"], default="split",
+                    help="how the float32 products of the large GEMMs are formed: split (default: six exact bf16 x bf16 partial products of "
+                         "three-way operand splits on the bf16 matrix pipe, float32 accumulate -- float32 results to float32 rounding) or "
+                         "mfma (v_mfma_f32_32x32x2_f32)")
+    ap.add_argument("--no-mfma-variant", action="store_true",
+                    help="skip the second line measured with --f32-products mfma (N = 1, float32 only; reported as f32_mfma_variant)")
     ap.add_argument("--bf16-variant", action="store_true",
                     help="also measure the secondary bf16-operand line (never the headline; off by default since round 4)")
     ap.add_argument("--no-bf16-variant", action="store_true", help="accepted for older command lines: the variant is off by default")
@@ -764,6 +803,7 @@ def main():
 
     _lib.lib()                                             # fail loudly if the HIP extension is missing
     ops.set_matmul_precision(args.precision)
+    ops.set_float32_products(args.f32_products)
     rccl_log = rccl_tuning_log_setup() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None
     rank, local_rank, world = pdist.init_from_env()
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
@@ -789,7 +829,7 @@ def main():
         torch.cuda.synchronize()
 
     def emit(elapsed, final_loss, launch_mode, dp_schedule, exposed_us=None, replicas=None, bf16=None, roof=None, table=(), kernel_ms=None,
-             cpu=None, note=None):
+             cpu=None, note=None, mfma=None):
         ms = 1e3 * elapsed / args.steps
         per_gpu = B * args.steps / elapsed
         out = {
@@ -799,6 +839,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "configs[1]: models/pointnet_pp_vonMises.py single-peak KL, N=1024, batch=32 per GPU, "
                                    "fwd+loss+bwd+allreduce+Adam, random-init weights (seed 42), device-side centre sampling",
+                       "float32_products": ("six exact bf16 x bf16 partial products of three-way operand splits on the bf16 matrix pipe, float32 "
+                                            "accumulate (float32 results to float32 rounding; same parity gates as the float32 MFMA form: "
+                                            "tests/test_gpu_split_products.py)" if args.f32_products == "split" and args.precision == "f32"
+                                            else "v_mfma_f32_32x32x2_f32" if args.precision == "f32" else "n/a (bf16 operands)"),
                        "per_gpu_batch": B, "global_batch": B * world, "points": N_POINTS,
                        "parallelism": f"dp{world}" if world > 1 else "single", "launch": launch_mode,
                        **({"dp_schedule": dp_schedule} if dp_schedule else {})},
@@ -808,7 +852,8 @@ def main():
             # whole step against both roofs: algorithmic FLOPs / bytes per cloud x clouds/s per GPU
             "mfma_fraction": per_gpu * FLOPS_PER_CLOUD / (MFMA_F32_PEAK_TFLOPS * 1e12),
             "hbm_fraction": per_gpu * BYTES_PER_CLOUD / (HBM_PEAK_GBS * 1e9),
-            "kernel_ms_per_step": kernel_ms, **({"bf16_variant": bf16} if bf16 else {}), **({"note": note} if note else {}),
+            "kernel_ms_per_step": kernel_ms, **({"f32_mfma_variant": mfma} if mfma else {}), **({"bf16_variant": bf16} if bf16 else {}),
+            **({"note": note} if note else {}),
             "roofline": roof, "cpu_baseline": cpu, "top_kernels": list(table),
         }
         print(json.dumps(out), flush=True)
@@ -873,6 +918,25 @@ def main():
         exposed_us = 1e6 * (elapsed - ctrl.max(el2)) / args.steps
         pdist.broadcast_flat(opt.flat_p)                   # replicas drifted apart in the local-only steps: not used after this
 
+    # the same step with the float32 products on v_mfma_f32_32x32x2_f32 (what rounds 1-3 measured): beside the headline, so that what
+    # the split products buy -- and that they change nothing else -- is read off one run
+    mfma = None
+    if args.precision == "f32" and args.f32_products == "split" and world == 1 and not args.no_mfma_variant:
+        ops.set_float32_products("mfma")
+        torch.manual_seed(42)
+        mm = PointNetPPVonMises(sampler="device").to(dev).train()
+        om = optim.FlatAdam(mm.parameters(), lr=1e-3)
+        stepm, modem, _ = build_step(mm, om, xyz, mu_gt, kappa_gt, 1, not args.no_graph)
+        for _ in range(args.warmup):
+            stepm()
+        nm = max(20, args.steps // 2)
+        elm, lossm = timed(stepm, nm, fence)
+        ops.set_float32_products("split")
+        mfma = {"metric": "clouds/sec fwd+bwd, pointnet_pp_vonMises N=1024, float32 products on v_mfma_f32_32x32x2_f32",
+                "value": B * nm / elm, "unit": "clouds/s", "ms_per_step": 1e3 * elm / nm, "steps": nm, "dtype": "f32",
+                "final_loss": float(lossm.detach()), "launch": modem}
+        del stepm, mm, om
+
     # secondary line (never the headline, opt-in): the same step with bf16 MFMA operands in the grouped layers' large GEMMs
     bf16 = None
     if args.precision == "f32" and world == 1 and args.bf16_variant and not args.no_bf16_variant:
@@ -901,7 +965,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(B)
-        emit(elapsed, final_loss, launch_mode, dp_schedule, exposed_us, replicas, bf16, roof, table, kernel_ms, cpu)
+        emit(elapsed, final_loss, launch_mode, dp_schedule, exposed_us, replicas, bf16, roof, table, kernel_ms, cpu, mfma=mfma)
     elif rccl_log and os.path.exists(rccl_log):
         os.remove(rccl_log)
     if world > 1:

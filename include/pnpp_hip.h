@@ -377,6 +377,19 @@ int pnpp_set_matmul_precision(int bf16_operands);
 int pnpp_get_matmul_precision(void);
 
 /* ------------------------------------------------------------------------------------------
+ * How the float32 products of the grouped layers' large GEMMs are formed (ABI 5).  0: v_mfma_f32_32x32x2_f32.  1: on the bf16
+ * matrix pipe from EXACT three-way operand splits (a float32 is the sum of three bfloat16 numbers; six bf16 x bf16 products per
+ * float32 product, each exact in float32, float32 accumulation; the three products dropped are below 2^-25 of the product, i.e.
+ * below the rounding of the accumulation): float32 results to float32 rounding -- held to the same parity gates as mode 0 --
+ * at 2.67 x the float32 MFMA rate (csrc/gemm_wsf3_kernels.hip).  Not a reduced-precision mode and unrelated to
+ * pnpp_set_matmul_precision (which rounds operands to ONE bf16).  Process-wide; initial value from PNPP_SPLIT_PRODUCTS.
+ * ---------------------------------------------------------------------------------------- */
+int pnpp_set_split_products(int on);
+int pnpp_get_split_products(void);
+/* diagnostics: non-zero once a bounded LDS poll of the wave-pair kernel (csrc/gemm_wsd3_kernels.hip) has given up in this process */
+int pnpp_debug_wsd3_timeouts(void);
+
+/* ------------------------------------------------------------------------------------------
  * SyncBN (ABI 3; off by default): cross-rank exchange of the train-mode BatchNorm sums under data parallelism, so that a
  * global batch split over ranks normalises exactly like the reference's single process on the concatenated batch
  * (nn.BatchNorm2d / nn.BatchNorm1d in training mode: models/pointnet_pp_8dir.py:40-41, models/pointnet_pp_vonMises.py:32-33).

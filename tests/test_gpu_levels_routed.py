@@ -109,3 +109,10 @@ def test_head_block_kernels(oracle, net, block):
            "d_gamma": _relmax(bn.weight.grad, P[f"bn{block[-1]}.weight"].grad), "d_beta": _relmax(bn.bias.grad, P[f"bn{block[-1]}.bias"].grad)}
     print(f"\n[{block} M={B}] " + ", ".join(f"{k} {v:.2e}" for k, v in res.items()))
     assert max(res.values()) <= GATE, res
+
+
+def test_zz_wave_pair_polls_never_timed_out():
+    """gemm_wsd3_kernel's producer / consumer waves poll LDS counters with a bound; a poll that gave up leaves a mark (and wrong numbers)."""
+    from pnpp_hip import _lib
+    torch.cuda.synchronize()
+    assert _lib.lib().pnpp_debug_wsd3_timeouts() == 0

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Times one training step of the drop-in SimplePointNet (BASELINE configs[0]; simple_pointnet_train.py) on the GPU at the
 configuration BASELINE.json quotes (256 points, batch 4) and at the script's own defaults (10,000 points, batch 16), and
-prints the per-kernel event table of the larger one.  Not the driver's bench line."""
+prints one line per size in bench.py's format (tools/benchline.py: `roofline` for the costliest kernel) and the per-kernel event
+table of the larger one.  Not the driver's bench line."""
 import json
 import os
 import sys
@@ -9,12 +10,13 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "3d-pointcloud-orientation-estimation_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import torch  # noqa: E402
 
 import simple_pointnet_train as spt  # noqa: E402
 import synthetic  # noqa: E402
-from pnpp_hip import _lib as L, optim  # noqa: E402
+from pnpp_hip import optim  # noqa: E402
 
 
 def run(B, N, steps=50, warmup=10, profile=False):
@@ -37,21 +39,12 @@ def run(B, N, steps=50, warmup=10, profile=False):
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    rec = {"workload": f"SimplePointNet fwd+MSE+bwd+Adam, eager launches, B={B} N={N}", "ms_per_step": ms,
-           "clouds_per_s": B / ms * 1e3, "points_per_s": B * N / ms * 1e3}
+    import benchline
+    rows = benchline.profiled_rows(step, 5)
+    rec = benchline.line(f"configs[0]: simple_pointnet_train.py SimplePointNet fwd+MSE+bwd+Adam, eager launches, B={B} N={N}", B, ms * 1e-3,
+                         steps, warmup, rows, 5, points_per_s=B * N / ms * 1e3)
     if profile:
-        lib = L.lib()
-        lib.pnpp_profile_enable(1)
-        for _ in range(5):
-            step()
-        torch.cuda.synchronize()
-        import ctypes
-        buf = ctypes.create_string_buffer(1 << 16)
-        lib.pnpp_profile_report(buf, len(buf))
-        lib.pnpp_profile_enable(0)
-        rows = sorted((ln.split("\t") for ln in buf.value.decode().splitlines()), key=lambda r: -float(r[2]))
-        rec["kernel_table"] = "\n".join(f"{1e3 * float(ms) / 5:9.1f} us/step  {int(c) / 5:4.1f} x {1e3 * float(ms) / int(c):8.1f} us  {t}"
-                                        for t, c, ms in rows)
+        rec["kernel_table"] = "\n".join(f"{1e3 * t_ms / 5:9.1f} us/step  {c / 5:4.1f} x {1e3 * t_ms / c:8.1f} us  {t}" for t, c, t_ms in rows)
     return rec
 
 

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Phase stamps of gemm_wsd3_kernel INSIDE the training step (s_memtime around the phases of the producer and the consumer wave of pair 0
+of workgroup 8, no extra waits).  Needs libpnpp_hip.so built with PNPP_STAMPS=1 (pnpp_hip/build.py) and PNPP_SPLIT_PRODUCTS=1."""
+import ctypes, sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "3d-pointcloud-orientation-estimation_amd"))
+import torch
+from models.pointnet_pp_vonMises import PointNetPPVonMises
+from pnpp_hip import ops, optim, _lib
+torch.manual_seed(0)
+m = PointNetPPVonMises(sampler="device").cuda().train()
+opt = optim.FlatAdam(m.parameters())
+xyz = torch.randn(32, 1024, 3, device="cuda"); mu = torch.zeros(32, device="cuda"); kap = torch.ones(32, device="cuda")
+lib = ctypes.CDLL(_lib.LIB_PATH)
+lib.pnpp_debug_wsd3_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+def step():
+    opt.zero_grad(); ops.vm_head_kl_loss_backward(m.features(xyz), mu, kap); opt.step()
+for _ in range(3): step()
+torch.cuda.synchronize()
+lib.pnpp_debug_wsd3_stamps(None, 1)
+N = 20
+for _ in range(N): step()
+buf = (ctypes.c_ulonglong * 32)()
+lib.pnpp_debug_wsd3_stamps(buf, 0)
+pn = ["constants + tables", "wait for the buffer (partner)", "staging: dZ, split, LDS writes", "publish + next strip's loads issued", "dA products", "epilogue"]
+cn = ["activation fragments / turn-around", "wait for the chunk (partner)", "transposed reads + dW products"]
+for k, tag in ((0, "<128,64> sa1 last layer"), (1, "<256,32> sa2 last layer")):
+    for role, names in ((0, pn), (1, cn)):
+        row = [buf[(k * 2 + role) * 8 + i] for i in range(len(names))]
+        tot = sum(row)
+        print(tag, "producer" if role == 0 else "consumer", f"total {tot / N:.0f} ticks per launch (strip loop only)")
+        for i, n in enumerate(names):
+            print(f"    {n:40s} {row[i] / N:9.0f} ticks  {100 * row[i] / max(tot, 1):5.1f} %")
+print("timeouts:", lib.pnpp_debug_wsd3_timeouts())
