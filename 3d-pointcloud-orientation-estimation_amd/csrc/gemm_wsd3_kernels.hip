@@ -528,6 +528,18 @@ bool try_launch_wsd3(const AOperand &A, const BOperand &B, int M, int Nout, int 
     return true;
 }
 
+#ifdef PNPP_STAMPS
+#define WD3_STAMPS_BIT 64u
+#else
+#define WD3_STAMPS_BIT 0u
+#endif
+#ifdef WD3_PRIO
+#define WD3_PRIO_BIT 256u
+#else
+#define WD3_PRIO_BIT 0u
+#endif
+unsigned wsd3_build_flags() { return WD3_STAMPS_BIT | WD3_PRIO_BIT; }
+
 int wsd3_timeouts() {
     int v = 0;
     (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_wsd3_timeouts), sizeof(int));

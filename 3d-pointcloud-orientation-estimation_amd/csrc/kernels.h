@@ -186,6 +186,7 @@ int launch_xyz0_mask(const AOperand &geo, int M, const float *W0, int ldw0, cons
 // per translation unit: bits of pnpp_build_flags() (experiment / stamp switches compiled in; zero in a library that ships)
 unsigned wsx_build_flags();
 unsigned wsf_build_flags();
+unsigned wsd3_build_flags();
 unsigned wsp_build_flags();
 unsigned wsq_build_flags();
 unsigned gemm_build_flags();

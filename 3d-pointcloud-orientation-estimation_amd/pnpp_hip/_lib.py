@@ -156,7 +156,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.pnpp_abi_version() != 4:
+        if h.pnpp_abi_version() != 5:
             raise HipExtensionMissing("libpnpp_hip.so ABI version mismatch; rebuild it")
         _lib = h
     return _lib

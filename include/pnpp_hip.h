@@ -182,7 +182,7 @@ int pnpp_sa_saved_relu_mask(const pnpp_sa_desc *d, const void *saved, const floa
                             uint8_t *out, void *stream);
 /* compile-time experiment switches that were on when the library was built (timing experiments that compute WRONG results,
  * in-kernel stamps): 0 in a library that ships -- tests/test_abi.py holds it to 0.  bit 0 PNPP_WS_EXP_NO_MFMA, 1 WSP_EXP,
- * 2 WSX_EXP, 3 WSQ_EXP, 4 WSQ_PLAIN, 5 FCF_EXP, 6 PNPP_STAMPS, 7 WSF_EXP */
+ * 2 WSX_EXP, 3 WSQ_EXP, 4 WSQ_PLAIN, 5 FCF_EXP, 6 PNPP_STAMPS, 7 WSF_EXP, 8 WD3_PRIO */
 unsigned pnpp_build_flags(void);
 
 /* ------------------------------------------------------------------------------------------

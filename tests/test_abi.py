@@ -34,7 +34,7 @@ def test_header_symbols_exported(libpath):
 def test_binding_table_matches_header(libpath):
     from pnpp_hip import _lib
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
-    assert _lib.lib().pnpp_abi_version() == 4
+    assert _lib.lib().pnpp_abi_version() == 5
 
 
 def test_shipped_library_has_no_experiment_switches(libpath):

