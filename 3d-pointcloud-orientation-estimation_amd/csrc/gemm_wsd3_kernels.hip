@@ -100,9 +100,11 @@ __device__ unsigned long long g_wsd3_stamps[2][2][8];   // [KD == 256][P, C][pha
 #define WD3_STAMP(i)
 #endif
 
+// ---- form A (K = 256): the producer wave also multiplies dZ with the weights (dA) and runs the epilogue; the consumer wave holds dW
+// (256 x 32 = 128 registers) and has no room for the dA tile beside it ----
 template <int KD, int BN>
 __global__ void __launch_bounds__(512, 1)
-gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, int Nout, int ncol, const Epilogue E) {
+gemm_wsd3a_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, int Nout, int ncol, const Epilogue E) {
     constexpr int NC = KD / 64, CT = KD / 32, NT = BN / 32;
     constexpr int WPITCH = KD * 2, WPLANE = BN * WPITCH;     // bytes: row and plane of the weight panel [n][k]
     constexpr int APLANE = 32 * 128, ABUF = 3 * APLANE;      // bytes: plane and buffer (three planes) of a dZ chunk image
@@ -481,13 +483,370 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
     }
 }
 
+// ---- form B (K = 128): the producer wave only builds the image (vector work), the consumer wave multiplies (both products) and runs
+// the epilogue: dW is 128 x 32 = 64 registers, so the dA tile and a second accumulator for its small products fit beside it ----
+template <int KD, int BN>
+__global__ void __launch_bounds__(512, 1)
+gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, int Nout, int ncol, const Epilogue E) {
+    constexpr int NC = KD / 64, CT = KD / 32;
+    static_assert(BN == 32, "one column tile per workgroup: the consumer wave holds dW (KD x 32) and the dA tile");
+    constexpr bool DW2 = false;                              // a second dW accumulator set (the small products): no registers for it
+    constexpr bool ACC2 = CT <= 4;                           // a second dA accumulator (the small products): where dW is 64 registers
+    constexpr int WPITCH = KD * 2, WPLANE = BN * WPITCH;     // bytes: row and plane of the weight panel [n][k]
+    constexpr int APLANE = 32 * 128, ABUF = 3 * APLANE;      // bytes: plane and buffer (three planes) of a dZ chunk image
+    constexpr int APAIR = 2 * ABUF;                          // two buffers per wave pair
+    constexpr int OFF_IMG = 3 * WPLANE, OFF_CST = OFF_IMG + 4 * APAIR, OFF_FLG = OFF_CST + 3 * KD * 4;
+    static_assert(NC % 2 == 0, "chunk k of a strip uses buffer k & 1");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    unsigned char *Wp = lds3;
+    float *Tc = reinterpret_cast<float *>(lds3 + OFF_CST);   // [3][KD]: g, a, b of dZ = g dY + a Z + b
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave < 4;
+    const int pair = wave & 3;
+    unsigned char *Ap = lds3 + OFF_IMG + pair * APAIR;
+    wd3_flag *f_ready = (wd3_flag *)(lds3 + OFF_FLG) + 2 * pair, *f_done = f_ready + 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    auto xs = [](int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); };   // chunk XOR of image row r
+    auto xw = [](int n) { return n & 15; };                                  // chunk XOR of panel row n
+
+    const int nworkers = gridDim.x / ncol;
+    int col_blk = blockIdx.x % ncol, worker = blockIdx.x / ncol;
+    if ((nworkers & 7) == 0) {   // XCD-aware: the column blocks of one worker share an L2
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        col_blk = i % ncol, worker = (i / ncol) * 8 + xcd;
+    }
+    const int n0 = col_blk * BN;
+    const int nstrips = M / 32, stride = nworkers * 4;
+    int strip = worker * 4 + pair;
+    const __amdgpu_buffer_rsrc_t resNull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A.z), (short)0, 0, 0x00020000);
+
+    // ---- prologue, all eight waves: counters, the constant table, the weight panel ----
+    if (tid < 8) ((wd3_flag *)(lds3 + OFF_FLG))[tid] = 0u;
+    for (int c = tid; c < KD; c += 512) {
+        const float g = A.cst[c], mu = A.cst[A.C + c], is = A.cst[2 * A.C + c], c1 = A.cst[3 * A.C + c], c2 = A.cst[4 * A.C + c];
+        const float a = -g * is * c2;
+        Tc[c] = g, Tc[KD + c] = a, Tc[2 * KD + c] = -g * c1 - a * mu;
+    }
+    {   // W is (KD x Nout) row-major; image [n][k] of columns n0 .. n0 + 31 in three bf16 planes (lane = column n: four dword loads of
+        // consecutive rows k, split, one 8-byte store per plane)
+        constexpr int NWF = (KD / 4) * BN / 512;
+        f32x4 tw[NWF];
+#pragma unroll
+        for (int j = 0; j < NWF; ++j) {
+            const int f = tid + 512 * j, nl = f % BN, k4 = 4 * (f / BN);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tw[j][e] = W[(size_t)(k4 + e) * ldw + n0 + nl];
+        }
+#pragma unroll
+        for (int j = 0; j < NWF; ++j) {
+            const int f = tid + 512 * j, nl = f % BN, k4 = 4 * (f / BN);
+            uint2 h, m, l;
+            wd3_split4(tw[j], h, m, l);
+            unsigned char *dst = Wp + nl * WPITCH + 16 * ((k4 >> 3) ^ xw(nl)) + 2 * (k4 & 7);
+            *reinterpret_cast<uint2 *>(dst) = h;
+            *reinterpret_cast<uint2 *>(dst + WPLANE) = m;
+            *reinterpret_cast<uint2 *>(dst + 2 * WPLANE) = l;
+        }
+    }
+    __syncthreads();
+
+#ifdef PNPP_STAMPS
+    const bool st_on = blockIdx.x == 8 && pair == 0;
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
+    f32x16 dw[CT], dws[DW2 ? CT : 1];   // C waves: the leading products' sums and (DW2) the small products' sums
+    double s1 = 0.0, s2 = 0.0;          // C waves
+    bool timed_out = false;
+
+    if (producer) {
+        // =========================== P: the dZ image, nothing else (vector work only) ===========================
+        const int q = lane & 15, q4 = 4 * q, rb = lane >> 4;   // staging map: channels 64 c + 4 q .. + 3, rows rb + 4 i
+        const __amdgpu_buffer_rsrc_t resZ = wd3_rsrc(A.z), resY = wd3_rsrc(A.a), resI = wd3_rsrc(A.arg);
+        const unsigned oa0 = 4u * ((unsigned)rb * (unsigned)KD + (unsigned)q4);
+        f32x4 rz[2][8], rdm[2];   // two chunk register sets in flight
+        int4 rarg[2];
+        auto fetch_chunk = [&](bool have, int s, int c) {   // chunk c of strip s into register set c & 1
+            const __amdgpu_buffer_rsrc_t rZ = have ? resZ : resNull, rY = have ? resY : resNull, rI = have ? resI : resNull;
+            const unsigned so = (unsigned)s * (32u * KD * 4u) + 256u * (unsigned)c;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rz[c & 1][i] = wd3_load4(rZ, oa0, so + (unsigned)i * (4u * KD * 4u));
+            const unsigned sg = (unsigned)s * (KD * 4u) + 256u * (unsigned)c;   // one row of the pooled tables per strip
+            rdm[c & 1] = wd3_load4(rY, 4u * (unsigned)q4, sg);
+            rarg[c & 1] = __builtin_bit_cast(int4, wd3_load4(rI, 4u * (unsigned)q4, sg));
+        };
+        {
+            const bool have = strip < nstrips;
+            fetch_chunk(have, strip, 0);
+            fetch_chunk(have, strip, 1);
+        }
+        // LDS offsets of this lane inside a chunk-image plane: row rb + 4 i: x(r) = 4 bit1(rb) + (i & 3)
+        unsigned wofs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wofs[i] = (unsigned)(rb * 128 + 16 * ((q >> 1) ^ (((rb >> 1) & 1) << 2 | i)) + 8 * (q & 1));
+        unsigned kbase = 0;   // chunks of the strips before this one
+        for (; strip < nstrips; strip += stride, kbase += NC) {
+            const bool more = strip + stride < nstrips;
+            const int snext = strip + stride;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                // ---- stage chunk c (sequence number kbase + c) into buffer c & 1: dZ in registers, split, three 8-byte stores per group ----
+                unsigned char *Ab = Ap + (c & 1) * ABUF;
+                const float4 cg = *reinterpret_cast<const float4 *>(Tc + 64 * c + q4), ca = *reinterpret_cast<const float4 *>(Tc + KD + 64 * c + q4);
+                const float4 cb = *reinterpret_cast<const float4 *>(Tc + 2 * KD + 64 * c + q4);
+                const f32x4 dm = rdm[c & 1];
+                const int4 ar = rarg[c & 1];
+                float4 bt;   // b + g dm: what the arg-max row of a channel starts from
+                bt.x = fmaf(cg.x, dm[0], cb.x), bt.y = fmaf(cg.y, dm[1], cb.y), bt.z = fmaf(cg.z, dm[2], cb.z), bt.w = fmaf(cg.w, dm[3], cb.w);
+                uint2 ph[8], pm[8], pl[8];   // the split goes ahead of the wait for the buffer
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 z = rz[c & 1][i];
+                    const int r = rb + 4 * i;
+                    f32x4 v;
+                    v[0] = fmaf(ca.x, z[0], r == ar.x ? bt.x : cb.x), v[1] = fmaf(ca.y, z[1], r == ar.y ? bt.y : cb.y);
+                    v[2] = fmaf(ca.z, z[2], r == ar.z ? bt.z : cb.z), v[3] = fmaf(ca.w, z[3], r == ar.w ? bt.w : cb.w);
+                    wd3_split4(v, ph[i], pm[i], pl[i]);
+                }
+                WD3_STAMP(0)   // dZ and its pieces
+                // this register set is free: the chunk two ahead goes out
+                if (c + 2 < NC) fetch_chunk(true, strip, c + 2);
+                else fetch_chunk(more, snext, c + 2 - NC);
+                if (kbase + c >= 2) timed_out |= !wd3_wait(f_done, kbase + c - 1);   // the partner has finished with this buffer
+                WD3_STAMP(1)   // wait for the buffer
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    unsigned char *dst = Ab + wofs[i & 3] + i * 512;
+                    *reinterpret_cast<uint2 *>(dst) = ph[i];
+                    *reinterpret_cast<uint2 *>(dst + APLANE) = pm[i];
+                    *reinterpret_cast<uint2 *>(dst + 2 * APLANE) = pl[i];
+                }
+                wd3_post(f_ready, kbase + c + 1);
+                WD3_STAMP(2)   // image written and published
+            }
+        }
+    } else {
+        // =========================== C: both products and the epilogue (matrix work) ===========================
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dw[i][r] = 0.f;
+        if constexpr (DW2) {
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dws[i][r] = 0.f;
+        }
+        const __amdgpu_buffer_rsrc_t resP = wd3_rsrc(E.zp), resC = wd3_rsrc(E.c);
+        // accumulator positions of a strip of layer l-1 (z_{l-1} in, dY_{l-1} out): row 4 lh + (r & 3) + 8 (r >> 2), column n0 + l31; the
+        // lane part is ONE register, the register part is uniform and rides in the instruction's scalar offset
+        const unsigned oq = 4u * ((unsigned)(4 * lh) * (unsigned)Nout + (unsigned)(n0 + l31));
+        auto quni = [&](int r) -> unsigned { return 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * Nout); };
+        const float e_sc = E.scale[n0 + l31], e_sh = E.shift[n0 + l31], e_mu = E.mu[n0 + l31], e_is = E.istd[n0 + l31];
+        float zq[16], zn[16];
+        {
+            const __amdgpu_buffer_rsrc_t rP = strip < nstrips ? resP : resNull;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zn[r] = wd3_load1(rP, oq, (unsigned)strip * (32u * (unsigned)Nout * 4u) + quni(r));
+        }
+        const unsigned arow = (unsigned)(l31 * 128);
+        const int ax = xs(l31);
+        const unsigned char *brow = Wp + l31 * WPITCH;
+        const int bx = xw(l31);
+        unsigned tofs[2][2][2];   // transposed reads [c-tile of the chunk][step s][block]: rows 16 s + 8 blk + 4 lh + qq, columns 32 it + l31
+        {
+            const int gi = lane & 15, qq = gi >> 2, pp = gi & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int r = 16 * s + 8 * b + 4 * lh + qq, ch = 4 * it + 2 * g1 + (pp >> 1);
+                        tofs[it][s][b] = (unsigned)(r * 128 + 16 * (ch ^ xs(r)) + 8 * (pp & 1));
+                    }
+        }
+        unsigned kbase = 0;
+        for (; strip < nstrips; strip += stride, kbase += NC) {
+            const bool more = strip + stride < nstrips;
+            // ---- relu(bn(z_{l-1})) of the strip: the dW product's B fragments straight from the registers, the mask bits; then the
+            // next strip's values are requested ----
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zq[r] = zn[r];
+            {
+                const __amdgpu_buffer_rsrc_t nP = more ? resP : resNull;
+                const unsigned sn_off = (unsigned)(strip + stride) * (32u * (unsigned)Nout * 4u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zn[r] = wd3_load1(nP, oq, sn_off + quni(r));
+            }
+            uint4 bfr[2][3];   // [step][piece]
+            unsigned maskb = 0u;
+            {
+                float act[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float a0 = fmaf(zq[r], e_sc, e_sh);
+                    maskb |= (a0 > 0.f ? 1u : 0u) << r;
+                    act[r] = fmaxf(a0, 0.f);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    f32x4 v0, v1;
+                    v0[0] = act[8 * s + 0], v0[1] = act[8 * s + 1], v0[2] = act[8 * s + 2], v0[3] = act[8 * s + 3];
+                    v1[0] = act[8 * s + 4], v1[1] = act[8 * s + 5], v1[2] = act[8 * s + 6], v1[3] = act[8 * s + 7];
+                    uint2 h0, m0, l0, h1, m1, l1;
+                    wd3_split4(v0, h0, m0, l0);
+                    wd3_split4(v1, h1, m1, l1);
+                    bfr[s][0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    bfr[s][1] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+                    bfr[s][2] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                }
+            }
+            f32x16 acc, accs;   // dA: the leading products and (ACC2) the small ones, added in the epilogue
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if constexpr (ACC2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[r] = 0.f;
+            }
+            WD3_STAMP(3)   // activation fragments
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const unsigned char *Ab = Ap + (c & 1) * ABUF;
+                timed_out |= !wd3_wait(f_ready, kbase + c + 1);
+                WD3_STAMP(4)   // wait for the chunk
+                // ---- dA += dZ_chunk W_chunk: step t covers k = 64 c + 16 t + 8 lh + (0 .. 7) ----
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int g = 2 * t + lh;
+                    uint4 fa[3], fb[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        fa[p] = *reinterpret_cast<const uint4 *>(Ab + p * APLANE + arow + 16 * (g ^ ax));
+                        fb[p] = *reinterpret_cast<const uint4 *>(brow + p * WPLANE + 16 * ((8 * c + g) ^ bx));
+                    }
+                    const wd3_bf16x8 ah = wd3_op(fa[0]), am = wd3_op(fa[1]), al = wd3_op(fa[2]);
+                    const wd3_bf16x8 bh = wd3_op(fb[0]), bm = wd3_op(fb[1]), bl = wd3_op(fb[2]);
+                    f32x16 d = ACC2 ? accs : acc;   // the small products first, the leading one last
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, d, 0, 0, 0);
+                    if constexpr (ACC2) {
+                        accs = d;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                    } else {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, d, 0, 0, 0);
+                    }
+                }
+                WD3_STAMP(5)   // dA product of the chunk
+                // ---- dW[64 c + 32 it + .][n] += dZ_chunk^T act: two steps of 16 rows ----
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        uint4 ta[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            const uint2 lo = wd3_tr(Ab + p * APLANE + tofs[it][s][0]), hi = wd3_tr(Ab + p * APLANE + tofs[it][s][1]);
+                            ta[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        }
+                        if (it == 1 && s == 1) wd3_post(f_done, kbase + c + 1);   // the last reads of this buffer have landed
+                        const wd3_bf16x8 ah = wd3_op(ta[0]), am = wd3_op(ta[1]), al = wd3_op(ta[2]);
+                        const wd3_bf16x8 bh = wd3_op(bfr[s][0]), bm = wd3_op(bfr[s][1]), bl = wd3_op(bfr[s][2]);
+                        f32x16 d = DW2 ? dws[DW2 ? 2 * c + it : 0] : dw[2 * c + it];
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, d, 0, 0, 0);
+                        if constexpr (DW2) {
+                            dws[DW2 ? 2 * c + it : 0] = d;
+                            dw[2 * c + it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, dw[2 * c + it], 0, 0, 0);
+                        } else {
+                            dw[2 * c + it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, d, 0, 0, 0);
+                        }
+                    }
+                WD3_STAMP(6)   // transposed reads + dW products of the chunk
+            }
+            // ---- epilogue: mask, store, BatchNorm-backward sums of layer l-1 ----
+            {
+                const unsigned sc_off = (unsigned)strip * (32u * (unsigned)Nout * 4u);
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = ((maskb >> r) & 1u) ? (ACC2 ? acc[r] + accs[r] : acc[r]) : 0.f;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), resC, (int)oq, (int)(sc_off + quni(r)), 0);
+                    t1 += v;
+                    t2 = fmaf(v, zq[r], t2);
+                }
+                const double d1 = (double)t1;   // sum v xhat = istd (sum v z - mu sum v), finished in float64
+                s1 += d1, s2 += (double)e_is * ((double)t2 - (double)e_mu * d1);
+            }
+            WD3_STAMP(7)   // epilogue
+        }
+    }
+#ifdef PNPP_STAMPS
+    if (st_on && lane == 0)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_wsd3_stamps[KD == 256][producer ? 0 : 1][i] += st_acc[i];
+#endif
+    if (timed_out && lane == 0) atomicExch(&g_wsd3_timeouts, 1);
+
+    // ---- tails: one dW partial per workgroup (the four C waves' tiles added through LDS), the column statistics ----
+    __syncthreads();   // every wave is done with the panel and the images
+    f32x4 *red = reinterpret_cast<f32x4 *>(lds3);                          // [tile][C wave][r4][lane]
+    double *dred = reinterpret_cast<double *>(lds3 + CT * 4 * 4 * 64 * 16);   // [C wave][2][BN]
+    if (!producer) {
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = DW2 ? dw[i][4 * r4 + e] + dws[DW2 ? i : 0][4 * r4 + e] : dw[i][4 * r4 + e];
+                red[((i * 4 + pair) * 4 + r4) * 64 + lane] = v;
+            }
+        const double a = s1 + shfl_xor_f64(s1, 32), b = s2 + shfl_xor_f64(s2, 32);
+        if (lh == 0) dred[(pair * 2 + 0) * BN + l31] = a, dred[(pair * 2 + 1) * BN + l31] = b;
+    }
+    __syncthreads();
+    {
+        float *wb = E.dwslab + (size_t)worker * KD * E.dw_ld + n0;
+        for (int t = wave; t < CT; t += 8) {   // c-tile t
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 a0 = red[((t * 4 + 0) * 4 + r4) * 64 + lane], a1 = red[((t * 4 + 1) * 4 + r4) * 64 + lane];
+                const f32x4 a2 = red[((t * 4 + 2) * 4 + r4) * 64 + lane], a3 = red[((t * 4 + 3) * 4 + r4) * 64 + lane];
+                const int c0 = t * 32 + 8 * r4 + 4 * lh;
+                float *o = wb + (size_t)c0 * E.dw_ld + l31;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[(size_t)e * E.dw_ld] = (a0[e] + a1[e]) + (a2[e] + a3[e]);
+            }
+        }
+        if (tid < 2 * BN) {
+            const int which = tid / BN, cl = tid % BN;
+            const double t = (dred[(0 * 2 + which) * BN + cl] + dred[(1 * 2 + which) * BN + cl]) +
+                             (dred[(2 * 2 + which) * BN + cl] + dred[(3 * 2 + which) * BN + cl]);
+            E.slab[((size_t)worker * 2 + which) * Nout + n0 + cl] = t;
+        }
+    }
+}
+
+template <int KD, int BN>
+static auto wsd3_kernel_of() {   // K = 256: form A; K = 128: form B (only these two are instantiated)
+    if constexpr (KD == 256) return gemm_wsd3a_kernel<KD, BN>;
+    else return gemm_wsd3_kernel<KD, BN>;
+}
+
 template <int KD, int BN>
 static void wsd3_launch(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int workers, int ncol, hipStream_t st) {
     constexpr size_t main_b = (size_t)3 * BN * KD * 2 + (size_t)4 * 2 * 3 * 32 * 128 + (size_t)3 * KD * 4 + 64;
     constexpr size_t red_b = (size_t)(KD / 32) * (BN / 32) * 4 * 4 * 64 * 16 + (size_t)4 * 2 * BN * 8;
     constexpr size_t lds = main_b > red_b ? main_b : red_b;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kfn = gemm_wsd3_kernel<KD, BN>;
+    auto kfn = wsd3_kernel_of<KD, BN>();
     static bool granted = false;
     if (!granted) {
         (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -512,14 +871,14 @@ bool try_launch_wsd3(const AOperand &A, const BOperand &B, int M, int Nout, int 
                      int *dw_slabs) {
     *rc = PNPP_OK;
     if (!dw_slabs || !wsd3_applies(A, B, M, Nout, Kd, E)) return false;
-    const int nstrips = M / 32, ncol = Kd == 128 ? Nout / 64 : Nout / 32;
+    const int nstrips = M / 32, ncol = Nout / 32;
     int workers = 256 / ncol;   // one workgroup of eight waves per CU
     if (workers * 4 > nstrips) workers = (nstrips + 3) / 4;
     if (workers > kMaxStatBlocks) workers = kMaxStatBlocks;
     if (nslab) *nslab = workers;
     *dw_slabs = workers;
-    ProfScope ps(st, "gemm_wsd3_kernel<%d,%d> M=%d N=%d K=%d grid=%dx1", Kd, Kd == 128 ? 64 : 32, M, Nout, Kd, workers * ncol);
-    if (Kd == 128) wsd3_launch<128, 64>(A, B, M, Nout, E, workers, ncol, st);
+    ProfScope ps(st, "gemm_wsd3_kernel<%d,32> M=%d N=%d K=%d grid=%dx1", Kd, M, Nout, Kd, workers * ncol);
+    if (Kd == 128) wsd3_launch<128, 32>(A, B, M, Nout, E, workers, ncol, st);
     else wsd3_launch<256, 32>(A, B, M, Nout, E, workers, ncol, st);
     if (hipGetLastError() != hipSuccess) {
         set_error("gemm_wsd3: launch failed");
