@@ -1854,8 +1854,7 @@ int launch_gemm(const AOperand &A, const BOperand &Bin, int M, int Nout, int Kd,
         if (try_launch_ws_bf16(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;   // only in the opt-in bf16-operand mode
         if (try_launch_wsf3(A, B, M, Nout, Kd, E, nslab, st, &rc)) return rc;  // the same products from exact bf16 splits (gemm_wsf3_kernels.hip)
         if (try_launch_wsf(A, B, M, Nout, Kd, E, nslab, st, &rc)) return rc;   // forward products: wave-private strips
-        if (try_launch_wsd3(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;  // a level's last layer backward, split products, wave pairs
-        if (try_launch_wsp3(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;  // fused backward products from exact bf16 splits
+        if (try_launch_wsd3(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;  // fused backward products of the grouped levels, split products, wave pairs
         if (try_launch_wsp(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;   // fused backward products, 64-channel input
         if (try_launch_wsq(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;   // the same for the 256-channel last layer
         if (try_launch_ws(A, B, M, Nout, Kd, E, nslab, st, &rc, dw_slabs)) return rc;

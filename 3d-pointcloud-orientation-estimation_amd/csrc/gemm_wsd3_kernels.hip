@@ -1,33 +1,39 @@
-// gemm_wsd3_kernels.hip -- the fused backward product of a grouped level's LAST layer (dA + ReLU mask + BatchNorm-backward sums + dW in
-// one launch) with the float32 products formed on the bf16 matrix pipe from exact three-way operand splits (gemm_wsf3_kernels.hip has
-// the arithmetic), as a PAIR of waves per 32-row strip: one wave builds dZ and multiplies it with the weights, its partner on the
-// same SIMD accumulates the weight gradient from the same LDS image.
+// gemm_wsd3_kernels.hip -- the fused backward products of the grouped levels (dA + ReLU mask + BatchNorm-backward sums + dW in one
+// launch) with the float32 products formed on the bf16 matrix pipe from exact three-way operand splits (gemm_wsf3_kernels.hip has the
+// arithmetic), as a PAIR of waves per 32-row strip on one SIMD: a producer that builds dZ and a consumer that multiplies.
 //
-// Reference: the autograd backward of conv -> BatchNorm -> ReLU -> max over the 32 neighbours (models/pointnet_pp_8dir.py:40-42):
-//   dZ_l     = BatchNorm-backward(dY_l, Z_l),  dY_l rebuilt from the pooled gradient and the arg-max rows (A_DZ_POOL)
+// Reference: the autograd backward of conv -> BatchNorm -> ReLU (-> max over the 32 neighbours) (models/pointnet_pp_8dir.py:40-42):
+//   dZ_l     = BatchNorm-backward(dY_l, Z_l)    A_DZ_POOL: dY_l rebuilt from the pooled gradient and the arg-max rows (a level's last
+//                                               layer); A_DZ: dY_l dense (a middle layer)
 //   dY_{l-1} = (dZ_l W_l) masked by ReLU'(layer l-1), + its BatchNorm-backward column sums
 //   dW_l     = dZ_l^T relu(bn(Z_{l-1}))
 //
 // Why pairs.  With split products a strip's two products are 2 x 96 bf16 MFMAs = 6,144 cycles of the matrix pipe, and building the
 // operands (BatchNorm-backward, three-way splits, ReLU mask, sums) is about as many cycles of vector issue.  A bf16 MFMA holds the
 // vector issue for 8 of its 32 cycles, so the two kinds of work CAN overlap on a SIMD -- but only from two waves: one wave per SIMD
-// (gemm_wsp_kernel's form: all dW accumulators of a strip owner are 128 registers) runs them back to back and waits out every LDS
-// latency alone (a first version of this kernel in that form ran 48.4 us against the float32 kernel's 50.4).  Two waves per SIMD
-// leave 256 registers each, which one wave's share of BOTH products does not fit.  So the products are split between two waves:
-//   P (waves 0-3): streams Z_l one strip ahead, computes dZ (one compare + select + FMA per element), splits it, writes the chunk
-//                  image (three bf16 planes of [32 rows][64 channels]) to LDS, multiplies it with the weight panel (dA), masks,
-//                  stores dY_{l-1} and collects the BatchNorm-backward sums;
-//   C (waves 4-7): takes relu(bn(z_{l-1})) of the strip from registers in accumulator layout (eight consecutive registers are one
-//                  32x32x16 operand), reads the SAME image transposed (ds_read_b64_tr_b16, rows in the accumulator layout's order)
-//                  and accumulates dW for the whole launch.
-// Wave w and wave w + 4 of a workgroup sit on the same SIMD and share two image buffers and two counters in LDS: `ready` (chunks P has
+// (gemm_wsp_kernel's form; the dW accumulators of a strip owner alone are 128 registers) runs them back to back and waits out every
+// LDS latency alone (a first version of this kernel in that form: 48.4 us against the float32 kernel's 50.4; for the dense gradient
+// 26.0 against 30.4).  Two waves per SIMD leave 256 registers each, which one wave's share of BOTH products and the operand stream
+// does not fit.  So the work is split between wave w (P, waves 0-3) and wave w + 4 (C) of a workgroup, which sit on the same SIMD
+// and share two chunk-image buffers (three bf16 planes of [32 rows][64 channels] each) and two counters in LDS: `ready` (chunks P has
 // published) and `done` (chunks C has finished reading).  P writes chunk k into buffer k & 1 once done >= k - 1; C reads it once
 // ready >= k + 1.  LDS operations of one wave complete in order and the counters only grow, so there is no cycle to wait in; the
-// polls are bounded all the same (a timed-out poll sets *err and goes on: wrong numbers, never a hang).
-// Image layout as gemm_wsp3: 16-byte group g of row r at g ^ x(r), x(r) = 4 bit1(r) + bits3:2(r): conflict-free row reads and
-// transposed reads.
-// Shapes: (K = C_l, N = C_{l-1}) = (128, 64) [SA1] and (256, 128) [SA2]; 64 or 32 output columns per workgroup so that the dW tiles of
-// the C wave are 128 registers either way.
+// polls are bounded all the same (a poll that gave up sets g_wsd3_timeouts and goes on: wrong numbers, never a hang; the tests check
+// the mark).  Every workgroup owns 32 output columns, so that the C wave's dW (K x 32) is 64 or 128 registers.
+//   form B (K = 128; SA1's last layer 128 -> 64 and SA2's middle layer 128 -> 128): P only builds the image -- streams Z (and dY) one
+//           strip ahead, computes dZ, splits it, writes it -- vector work and memory, no MFMA; C does ALL the matrix work: takes
+//           relu(bn(z_{l-1})) of the strip from registers in accumulator layout (eight consecutive registers are one 32x32x16 operand),
+//           multiplies the image rows with the weight panel (dA; the small products in an accumulator of their own), reads the SAME
+//           image transposed (ds_read_b64_tr_b16, rows in the accumulator layout's order) for dW, masks, stores, collects the sums.
+//           In-kernel stamps: C is the critical path (dA 30 %, dW 30 %, activation fragments 20 %, epilogue 13 %), P waits 43 %.
+//   form A (K = 256; SA2's last layer 256 -> 128): dW alone is 128 registers, the dA tile does not fit beside it: P also multiplies
+//           the image with the weight panel and runs the epilogue (and stages the next strip's first chunk BEFORE its epilogue: the
+//           partner multiplies while it stores, and behind the epilogue's 64 memory operations the compiler can no longer count vmcnt
+//           and waits for everything); C only accumulates dW.  Stamps: P is the critical path, C waits 51 %.
+// Image layout: 16-byte group g of row r at g ^ x(r), x(r) = 4 bit1(r) + bits3:2(r): conflict-free for the row reads (the four
+// 16-lane groups of a ds_read_b128 see eight different x per row parity) and for the transposed reads (rows r and r + 2 of a block
+// differ in x's bit 2).  Addresses: ONE lane-offset register per stream, everything uniform in the instructions' scalar offsets -- a
+// spilled address register is reloaded behind s_waitcnt vmcnt(0) and serialises every load behind it (measured: 74 % of a wave's time).
 #include <stdlib.h>
 
 #include "kernels.h"
@@ -485,7 +491,7 @@ gemm_wsd3a_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M,
 
 // ---- form B (K = 128): the producer wave only builds the image (vector work), the consumer wave multiplies (both products) and runs
 // the epilogue: dW is 128 x 32 = 64 registers, so the dA tile and a second accumulator for its small products fit beside it ----
-template <int KD, int BN>
+template <int KD, int BN, int AM>
 __global__ void __launch_bounds__(512, 1)
 gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, int Nout, int ncol, const Epilogue E) {
     constexpr int NC = KD / 64, CT = KD / 32;
@@ -564,16 +570,21 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
         const int q = lane & 15, q4 = 4 * q, rb = lane >> 4;   // staging map: channels 64 c + 4 q .. + 3, rows rb + 4 i
         const __amdgpu_buffer_rsrc_t resZ = wd3_rsrc(A.z), resY = wd3_rsrc(A.a), resI = wd3_rsrc(A.arg);
         const unsigned oa0 = 4u * ((unsigned)rb * (unsigned)KD + (unsigned)q4);
-        f32x4 rz[2][8], rdm[2];   // two chunk register sets in flight
+        f32x4 rz[2][8], ry[AM == A_DZ ? 2 : 1][8], rdm[2];   // two chunk register sets in flight (A_DZ: the dense gradient beside Z)
         int4 rarg[2];
         auto fetch_chunk = [&](bool have, int s, int c) {   // chunk c of strip s into register set c & 1
             const __amdgpu_buffer_rsrc_t rZ = have ? resZ : resNull, rY = have ? resY : resNull, rI = have ? resI : resNull;
             const unsigned so = (unsigned)s * (32u * KD * 4u) + 256u * (unsigned)c;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) rz[c & 1][i] = wd3_load4(rZ, oa0, so + (unsigned)i * (4u * KD * 4u));
-            const unsigned sg = (unsigned)s * (KD * 4u) + 256u * (unsigned)c;   // one row of the pooled tables per strip
-            rdm[c & 1] = wd3_load4(rY, 4u * (unsigned)q4, sg);
-            rarg[c & 1] = __builtin_bit_cast(int4, wd3_load4(rI, 4u * (unsigned)q4, sg));
+            for (int i = 0; i < 8; ++i) {
+                rz[c & 1][i] = wd3_load4(rZ, oa0, so + (unsigned)i * (4u * KD * 4u));
+                if constexpr (AM == A_DZ) ry[c & 1][i] = wd3_load4(rY, oa0, so + (unsigned)i * (4u * KD * 4u));
+            }
+            if constexpr (AM == A_DZ_POOL) {
+                const unsigned sg = (unsigned)s * (KD * 4u) + 256u * (unsigned)c;   // one row of the pooled tables per strip
+                rdm[c & 1] = wd3_load4(rY, 4u * (unsigned)q4, sg);
+                rarg[c & 1] = __builtin_bit_cast(int4, wd3_load4(rI, 4u * (unsigned)q4, sg));
+            }
         };
         {
             const bool have = strip < nstrips;
@@ -594,9 +605,10 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
                 unsigned char *Ab = Ap + (c & 1) * ABUF;
                 const float4 cg = *reinterpret_cast<const float4 *>(Tc + 64 * c + q4), ca = *reinterpret_cast<const float4 *>(Tc + KD + 64 * c + q4);
                 const float4 cb = *reinterpret_cast<const float4 *>(Tc + 2 * KD + 64 * c + q4);
-                const f32x4 dm = rdm[c & 1];
-                const int4 ar = rarg[c & 1];
-                float4 bt;   // b + g dm: what the arg-max row of a channel starts from
+                f32x4 dm = {0.f, 0.f, 0.f, 0.f};
+                int4 ar = make_int4(-1, -1, -1, -1);
+                if constexpr (AM == A_DZ_POOL) dm = rdm[c & 1], ar = rarg[c & 1];
+                float4 bt;   // A_DZ_POOL: b + g dm, what the arg-max row of a channel starts from
                 bt.x = fmaf(cg.x, dm[0], cb.x), bt.y = fmaf(cg.y, dm[1], cb.y), bt.z = fmaf(cg.z, dm[2], cb.z), bt.w = fmaf(cg.w, dm[3], cb.w);
                 uint2 ph[8], pm[8], pl[8];   // the split goes ahead of the wait for the buffer
 #pragma unroll
@@ -604,8 +616,14 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
                     const f32x4 z = rz[c & 1][i];
                     const int r = rb + 4 * i;
                     f32x4 v;
-                    v[0] = fmaf(ca.x, z[0], r == ar.x ? bt.x : cb.x), v[1] = fmaf(ca.y, z[1], r == ar.y ? bt.y : cb.y);
-                    v[2] = fmaf(ca.z, z[2], r == ar.z ? bt.z : cb.z), v[3] = fmaf(ca.w, z[3], r == ar.w ? bt.w : cb.w);
+                    if constexpr (AM == A_DZ) {
+                        const f32x4 dy = ry[c & 1][i];
+                        v[0] = fmaf(cg.x, dy[0], fmaf(ca.x, z[0], cb.x)), v[1] = fmaf(cg.y, dy[1], fmaf(ca.y, z[1], cb.y));
+                        v[2] = fmaf(cg.z, dy[2], fmaf(ca.z, z[2], cb.z)), v[3] = fmaf(cg.w, dy[3], fmaf(ca.w, z[3], cb.w));
+                    } else {
+                        v[0] = fmaf(ca.x, z[0], r == ar.x ? bt.x : cb.x), v[1] = fmaf(ca.y, z[1], r == ar.y ? bt.y : cb.y);
+                        v[2] = fmaf(ca.z, z[2], r == ar.z ? bt.z : cb.z), v[3] = fmaf(ca.w, z[3], r == ar.w ? bt.w : cb.w);
+                    }
                     wd3_split4(v, ph[i], pm[i], pl[i]);
                 }
                 WD3_STAMP(0)   // dZ and its pieces
@@ -680,15 +698,10 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
                 for (int r = 0; r < 16; ++r) zn[r] = wd3_load1(nP, oq, sn_off + quni(r));
             }
             uint4 bfr[2][3];   // [step][piece]
-            unsigned maskb = 0u;
             {
                 float act[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float a0 = fmaf(zq[r], e_sc, e_sh);
-                    maskb |= (a0 > 0.f ? 1u : 0u) << r;
-                    act[r] = fmaxf(a0, 0.f);
-                }
+                for (int r = 0; r < 16; ++r) act[r] = fmaxf(fmaf(zq[r], e_sc, e_sh), 0.f);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     f32x4 v0, v1;
@@ -776,7 +789,8 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
                 float t1 = 0.f, t2 = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = ((maskb >> r) & 1u) ? (ACC2 ? acc[r] + accs[r] : acc[r]) : 0.f;
+                    const float v = fmaf(zq[r], e_sc, e_sh) > 0.f ? (ACC2 ? acc[r] + accs[r] : acc[r]) : 0.f;   // (the mask is recomputed: a bit per row built
+                                                                                                           //  at the strip's start was a chain of 48 dependent instructions)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), resC, (int)oq, (int)(sc_off + quni(r)), 0);
                     t1 += v;
                     t2 = fmaf(v, zq[r], t2);
@@ -834,19 +848,19 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
     }
 }
 
-template <int KD, int BN>
-static auto wsd3_kernel_of() {   // K = 256: form A; K = 128: form B (only these two are instantiated)
+template <int KD, int BN, int AM>
+static auto wsd3_kernel_of() {   // K = 256: form A; K = 128: form B (only the forms that are launched are instantiated)
     if constexpr (KD == 256) return gemm_wsd3a_kernel<KD, BN>;
-    else return gemm_wsd3_kernel<KD, BN>;
+    else return gemm_wsd3_kernel<KD, BN, AM>;
 }
 
-template <int KD, int BN>
+template <int KD, int BN, int AM>
 static void wsd3_launch(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int workers, int ncol, hipStream_t st) {
     constexpr size_t main_b = (size_t)3 * BN * KD * 2 + (size_t)4 * 2 * 3 * 32 * 128 + (size_t)3 * KD * 4 + 64;
     constexpr size_t red_b = (size_t)(KD / 32) * (BN / 32) * 4 * 4 * 64 * 16 + (size_t)4 * 2 * BN * 8;
     constexpr size_t lds = main_b > red_b ? main_b : red_b;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kfn = wsd3_kernel_of<KD, BN>();
+    auto kfn = wsd3_kernel_of<KD, BN, AM>();
     static bool granted = false;
     if (!granted) {
         (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -857,12 +871,15 @@ static void wsd3_launch(const AOperand &A, const BOperand &B, int M, int Nout, c
 
 bool wsd3_applies(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E) {
     if (!split_products() || matmul_precision() != 0) return false;
-    if (M < 8192 || M % 32 != 0 || !((Kd == 128 && Nout == 64) || (Kd == 256 && Nout == 128))) return false;
-    if (A.mode != A_DZ_POOL || A.K != 32) return false;
+    // the last layer of a grouped level (pooled gradient): 128 -> 64 (SA1), 256 -> 128 (SA2); a middle layer with a dense gradient: 128 -> 128
+    const bool pooled = A.mode == A_DZ_POOL && A.K == 32 && ((Kd == 128 && Nout == 64) || (Kd == 256 && Nout == 128));
+    const bool dense = A.mode == A_DZ && Kd == 128 && Nout == 128 && A.a;
+    if (M < 8192 || M % 32 != 0 || !(pooled || dense)) return false;
     if (E.mode != E_MASK_STATS || !E.dwslab || E.dw_ld < Nout) return false;
     if (B.trans || B.perm_D >= 0 || (B.rows > 0 && B.rows != Kd) || B.ldb < Nout) return false;
     if (A.lda != Kd || A.C != Kd || E.ldc != Nout) return false;
-    if ((((uintptr_t)A.a | (uintptr_t)A.z | (uintptr_t)A.arg | (uintptr_t)E.zp | (uintptr_t)E.c | (uintptr_t)A.cst) & 15) != 0) return false;
+    if ((((uintptr_t)A.a | (uintptr_t)A.z | (uintptr_t)E.zp | (uintptr_t)E.c | (uintptr_t)A.cst) & 15) != 0) return false;
+    if (A.mode == A_DZ_POOL && (((uintptr_t)A.arg) & 15) != 0) return false;
     if ((unsigned long long)M * (unsigned)Kd * 4ull >= 0xfffffff0ull) return false;   // 32-bit buffer offsets
     return true;
 }
@@ -877,9 +894,10 @@ bool try_launch_wsd3(const AOperand &A, const BOperand &B, int M, int Nout, int 
     if (workers > kMaxStatBlocks) workers = kMaxStatBlocks;
     if (nslab) *nslab = workers;
     *dw_slabs = workers;
-    ProfScope ps(st, "gemm_wsd3_kernel<%d,32> M=%d N=%d K=%d grid=%dx1", Kd, M, Nout, Kd, workers * ncol);
-    if (Kd == 128) wsd3_launch<128, 32>(A, B, M, Nout, E, workers, ncol, st);
-    else wsd3_launch<256, 32>(A, B, M, Nout, E, workers, ncol, st);
+    ProfScope ps(st, "gemm_wsd3_kernel<%d,32,A%d> M=%d N=%d K=%d grid=%dx1", Kd, A.mode, M, Nout, Kd, workers * ncol);
+    if (Kd == 256) wsd3_launch<256, 32, A_DZ_POOL>(A, B, M, Nout, E, workers, ncol, st);
+    else if (A.mode == A_DZ_POOL) wsd3_launch<128, 32, A_DZ_POOL>(A, B, M, Nout, E, workers, ncol, st);
+    else wsd3_launch<128, 32, A_DZ>(A, B, M, Nout, E, workers, ncol, st);
     if (hipGetLastError() != hipSuccess) {
         set_error("gemm_wsd3: launch failed");
         *rc = PNPP_ERR_LAUNCH;

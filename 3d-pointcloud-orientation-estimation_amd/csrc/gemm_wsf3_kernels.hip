@@ -12,7 +12,9 @@
 // six products kept are exact in float32 (8 x 8 significand bits) and are accumulated in float32 by v_mfma_f32_32x32x16_bf16: six
 // instructions of 32 cycles for 16 reduction steps against eight of 64 cycles = 2.67 x the float32 MFMA rate.  The leading products go
 // to one accumulator and the five small ones to a second, added once per strip, so the rounding of the sum is that of a float32
-// accumulation of the leading products.  Not a reduced-precision mode: tests/test_gpu_levels_routed.py holds it to the same gates as the
+// accumulation of the leading products.  (Why two accumulators: v_mfma_f32_32x32x16_bf16 aligns its 16 products and the accumulator to
+// the largest exponent among them and drops what lies 2^-26 below it -- tools/mfma_round.hip -- so small addends must not meet the
+// large sum inside the instruction.)  Not a reduced-precision mode: tests/test_gpu_levels_routed.py holds it to the same gates as the
 // float32 MFMA form, and tests/test_gpu_split_products.py measures both against float64.  (Infinities do not survive the split:
 // inf - inf; the float32 form gives inf where this one gives NaN.  Operands below 2^-110 lose their low pieces to underflow.)
 //
@@ -270,7 +272,7 @@ gemm_wsf3_kernel(const float *__restrict__ A, int lda, const float *__restrict__
 }
 
 // 1 (default): the float32 products of the grouped layers' large GEMMs on v_mfma_f32_32x32x16_bf16 from exact three-way operand splits
-// (this file, gemm_wsp3_kernels.hip, gemm_wsd3_kernels.hip); 0: on v_mfma_f32_32x32x2_f32 (PNPP_SPLIT_PRODUCTS=0 / pnpp_set_split_products)
+// (this file, gemm_wsd3_kernels.hip); 0: on v_mfma_f32_32x32x2_f32 (PNPP_SPLIT_PRODUCTS=0 / pnpp_set_split_products)
 static int g_split_products = -1;
 int split_products() {
     if (g_split_products < 0) {

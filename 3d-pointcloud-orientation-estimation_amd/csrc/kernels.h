@@ -147,14 +147,11 @@ bool wsf_applies(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, 
 int split_products();
 void set_split_products(int on);
 bool try_launch_wsf3(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc);
-// gemm_wsd3_kernels.hip: the fused backward product of a level's last layer (pooled gradient), split products, a producer and a consumer
-// wave per strip
+// gemm_wsd3_kernels.hip: the fused backward products (dA + mask + sums + dW) of the grouped levels with split products, a producer and a
+// consumer wave per strip: a level's last layer (pooled gradient, 128 -> 64 and 256 -> 128) and a middle layer (dense gradient, 128 -> 128)
 bool try_launch_wsd3(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc,
                      int *dw_slabs);
 int wsd3_timeouts();
-// gemm_wsp3_kernels.hip: the fused backward product (dA + mask + sums + dW) of a grouped layer with 128 output channels, same arithmetic
-bool try_launch_wsp3(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc,
-                     int *dw_slabs);
 // gemm_wsp_kernels.hip: the fused backward product (dA + mask + sums + dW) of a grouped layer with a 64-channel input, wave-private strips
 bool try_launch_wsp(const AOperand &A, const BOperand &B, int M, int Nout, int Kd, const Epilogue &E, int *nslab, hipStream_t st, int *rc,
                     int *dw_slabs);

@@ -33,7 +33,6 @@ SOURCES = {
     "gemm_mid_kernels.hip": [],
     "gemm_wsf_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []) + ([f"-DWSF_EXP={os.environ['PNPP_WSF_EXP']}"] if os.environ.get("PNPP_WSF_EXP") else []),
     "gemm_wsf3_kernels.hip": _NOSLP,
-    "gemm_wsp3_kernels.hip": _NOSLP,
     "gemm_wsd3_kernels.hip": _NOSLP + (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_wsp_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_wsx_kernels.hip": [],

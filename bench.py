@@ -316,7 +316,7 @@ def kernel_cost(tag: str):
         m = re.search(pattern, text)
         return tuple(int(x) for x in m.groups()) if m else None
 
-    if tag.startswith("gemm_wsp3_kernel") and ",A4>" in tag:
+    if tag.startswith(("gemm_wsp3_kernel", "gemm_wsd3_kernel")) and ",A4>" in tag:
         # the same fused product with a DENSE upstream gradient (a grouped level's middle layer): dY_l and Z_l read once
         M, N, K = ints(r"M=(\d+) N=(\d+) K=(\d+)")
         return 4.0 * M * N * K, 4.0 * (2.0 * M * K + 2.0 * M * N + 2.0 * K * N)
