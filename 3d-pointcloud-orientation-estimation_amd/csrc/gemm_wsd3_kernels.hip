@@ -74,13 +74,14 @@ __device__ __forceinline__ float wd3_load1(__amdgpu_buffer_rsrc_t r, unsigned la
 }
 typedef __attribute__((address_space(3))) volatile unsigned wd3_flag;   // a counter in LDS (ds_read_b32 / ds_write_b32, never flat)
 __device__ int g_wsd3_timeouts;   // set by a poll that gave up (pnpp_debug_wsd3_timeouts)
-// waits until *f >= target (f: an LDS counter that only grows); false after ~2^20 polls
+// waits until *f >= target (f: an LDS counter that only grows); false after 2^16 polls (a few milliseconds: a legitimate wait is
+// tens of microseconds)
 __device__ __forceinline__ bool wd3_wait(wd3_flag *f, unsigned target) {
     bool ok = true;
     unsigned spins = 0;
     while ((unsigned)__builtin_amdgcn_readfirstlane((int)*f) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 20)) {
+        if (++spins > (1u << 16)) {
             ok = false;
             break;
         }
@@ -106,6 +107,16 @@ __device__ unsigned long long g_wsd3_stamps[2][2][8];   // [KD == 256][P, C][pha
 #define WD3_STAMP(i)
 #endif
 
+// LDS layout of both forms (bytes), ONE definition for the kernels and the launcher: weight panel (three planes of [BN][KD] bf16) |
+// four pairs x two chunk-image buffers (three planes of [32][64] bf16) | constant table [3][KD] floats | form B: four pairs' activation
+// fragments [2 steps][3 pieces][64 lanes] x 16 bytes | eight counters
+template <int KD, int BN, bool FORMB>
+struct Wsd3Lds {
+    static constexpr int WPLANE = BN * KD * 2, APLANE = 32 * 128, ABUF = 3 * APLANE, APAIR = 2 * ABUF, BFR = 2 * 3 * 64 * 16;
+    static constexpr int OFF_IMG = 3 * WPLANE, OFF_CST = OFF_IMG + 4 * APAIR, OFF_BFR = OFF_CST + 3 * KD * 4;
+    static constexpr int OFF_FLG = OFF_BFR + (FORMB ? 4 * BFR : 0), END = OFF_FLG + 64;
+};
+
 // ---- form A (K = 256): the producer wave also multiplies dZ with the weights (dA) and runs the epilogue; the consumer wave holds dW
 // (256 x 32 = 128 registers) and has no room for the dA tile beside it ----
 template <int KD, int BN>
@@ -115,7 +126,8 @@ gemm_wsd3a_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M,
     constexpr int WPITCH = KD * 2, WPLANE = BN * WPITCH;     // bytes: row and plane of the weight panel [n][k]
     constexpr int APLANE = 32 * 128, ABUF = 3 * APLANE;      // bytes: plane and buffer (three planes) of a dZ chunk image
     constexpr int APAIR = 2 * ABUF;                          // two buffers per wave pair
-    constexpr int OFF_IMG = 3 * WPLANE, OFF_CST = OFF_IMG + 4 * APAIR, OFF_FLG = OFF_CST + 3 * KD * 4;
+    using LY = Wsd3Lds<KD, BN, false>;
+    constexpr int OFF_IMG = LY::OFF_IMG, OFF_CST = LY::OFF_CST, OFF_FLG = LY::OFF_FLG;
     static_assert(NC % 2 == 0, "chunk k of a strip uses buffer k & 1");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
     unsigned char *Wp = lds3;
@@ -249,7 +261,7 @@ gemm_wsd3a_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M,
             float4 bt;   // b + g dm: what the arg-max row of a channel starts from
             bt.x = fmaf(cg.x, dm[0], cb.x), bt.y = fmaf(cg.y, dm[1], cb.y), bt.z = fmaf(cg.z, dm[2], cb.z), bt.w = fmaf(cg.w, dm[3], cb.w);
             WD3_STAMP(0)   // constants, pooled tables
-            if (k >= 2) timed_out |= !wd3_wait(f_done, k - 1);   // the partner has finished with this buffer
+            if (k >= 2) timed_out = timed_out || !wd3_wait(f_done, k - 1);   // the partner has finished with this buffer
             WD3_STAMP(1)   // wait for the buffer
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -404,7 +416,7 @@ gemm_wsd3a_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M,
             for (int c = 0; c < NC; ++c) {
                 const unsigned char *Ab = Ap + (c & 1) * ABUF;
                 WD3_STAMP(0)   // activation fragments (first chunk) / loop turn-around
-                timed_out |= !wd3_wait(f_ready, kbase + c + 1);
+                timed_out = timed_out || !wd3_wait(f_ready, kbase + c + 1);
                 WD3_STAMP(1)   // wait for the chunk
 #pragma unroll
                 for (int it = 0; it < 2; ++it)
@@ -496,12 +508,14 @@ __global__ void __launch_bounds__(512, 1)
 gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, int Nout, int ncol, const Epilogue E) {
     constexpr int NC = KD / 64, CT = KD / 32;
     static_assert(BN == 32, "one column tile per workgroup: the consumer wave holds dW (KD x 32) and the dA tile");
-    constexpr bool DW2 = false;                              // a second dW accumulator set (the small products): no registers for it
+    constexpr bool DW2 = CT <= 4;                            // a second dW accumulator set (the small products): where dW is 64 registers
     constexpr bool ACC2 = CT <= 4;                           // a second dA accumulator (the small products): where dW is 64 registers
     constexpr int WPITCH = KD * 2, WPLANE = BN * WPITCH;     // bytes: row and plane of the weight panel [n][k]
     constexpr int APLANE = 32 * 128, ABUF = 3 * APLANE;      // bytes: plane and buffer (three planes) of a dZ chunk image
     constexpr int APAIR = 2 * ABUF;                          // two buffers per wave pair
-    constexpr int OFF_IMG = 3 * WPLANE, OFF_CST = OFF_IMG + 4 * APAIR, OFF_FLG = OFF_CST + 3 * KD * 4;
+    using LY = Wsd3Lds<KD, BN, true>;
+    constexpr int BFR = LY::BFR;                             // bytes: the strip's activation fragments, [step][piece][lane] of 16 bytes
+    constexpr int OFF_IMG = LY::OFF_IMG, OFF_CST = LY::OFF_CST, OFF_BFR = LY::OFF_BFR, OFF_FLG = LY::OFF_FLG;
     static_assert(NC % 2 == 0, "chunk k of a strip uses buffer k & 1");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
     unsigned char *Wp = lds3;
@@ -510,6 +524,7 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
     const bool producer = wave < 4;
     const int pair = wave & 3;
     unsigned char *Ap = lds3 + OFF_IMG + pair * APAIR;
+    uint4 *Bf = reinterpret_cast<uint4 *>(lds3 + OFF_BFR + pair * BFR) + lane;   // this lane's slots: Bf[(2 step + piece... ) * 64]
     wd3_flag *f_ready = (wd3_flag *)(lds3 + OFF_FLG) + 2 * pair, *f_done = f_ready + 1;
     const int l31 = lane & 31, lh = lane >> 5;
     auto xs = [](int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); };   // chunk XOR of image row r
@@ -525,6 +540,12 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
     const int nstrips = M / 32, stride = nworkers * 4;
     int strip = worker * 4 + pair;
     const __amdgpu_buffer_rsrc_t resNull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A.z), (short)0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t resP = wd3_rsrc(E.zp);
+    // accumulator positions of a strip of layer l-1 (z_{l-1} in, dY_{l-1} out): row 4 lh + (r & 3) + 8 (r >> 2), column n0 + l31; the
+    // lane part is ONE register, the register part is uniform and rides in the instruction's scalar offset
+    const unsigned oq = 4u * ((unsigned)(4 * lh) * (unsigned)Nout + (unsigned)(n0 + l31));
+    auto quni = [&](int r) -> unsigned { return 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * Nout); };
+    const float e_sc = E.scale[n0 + l31], e_sh = E.shift[n0 + l31];
 
     // ---- prologue, all eight waves: counters, the constant table, the weight panel ----
     if (tid < 8) ((wd3_flag *)(lds3 + OFF_FLG))[tid] = 0u;
@@ -586,10 +607,14 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
                 rarg[c & 1] = __builtin_bit_cast(int4, wd3_load4(rI, 4u * (unsigned)q4, sg));
             }
         };
+        float zn[16];   // z_{l-1} of the next strip at this lane's accumulator positions (the consumer's dW operand is built here)
         {
             const bool have = strip < nstrips;
             fetch_chunk(have, strip, 0);
             fetch_chunk(have, strip, 1);
+            const __amdgpu_buffer_rsrc_t rP = have ? resP : resNull;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zn[r] = wd3_load1(rP, oq, (unsigned)strip * (32u * (unsigned)Nout * 4u) + quni(r));
         }
         // LDS offsets of this lane inside a chunk-image plane: row rb + 4 i: x(r) = 4 bit1(rb) + (i & 3)
         unsigned wofs[4];
@@ -599,6 +624,36 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
         for (; strip < nstrips; strip += stride, kbase += NC) {
             const bool more = strip + stride < nstrips;
             const int snext = strip + stride;
+            // ---- relu(bn(z_{l-1})) of the strip as the dW product's B fragments (eight consecutive accumulator-layout registers are one
+            // 32x32x16 operand), in pieces, written to LDS ahead of chunk 0.  The partner read the previous strip's fragments before it
+            // finished the chunk this wait is for (the one chunk 0's buffer waits for, too) ----
+            {
+                uint4 bfr[2][3];
+                float act[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) act[r] = fmaxf(fmaf(zn[r], e_sc, e_sh), 0.f);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    f32x4 v0, v1;
+                    v0[0] = act[8 * s + 0], v0[1] = act[8 * s + 1], v0[2] = act[8 * s + 2], v0[3] = act[8 * s + 3];
+                    v1[0] = act[8 * s + 4], v1[1] = act[8 * s + 5], v1[2] = act[8 * s + 6], v1[3] = act[8 * s + 7];
+                    uint2 h0, m0, l0, h1, m1, l1;
+                    wd3_split4(v0, h0, m0, l0);
+                    wd3_split4(v1, h1, m1, l1);
+                    bfr[s][0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    bfr[s][1] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+                    bfr[s][2] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                }
+                const __amdgpu_buffer_rsrc_t nP = more ? resP : resNull;
+                const unsigned sn_off = (unsigned)snext * (32u * (unsigned)Nout * 4u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zn[r] = wd3_load1(nP, oq, sn_off + quni(r));
+                if (kbase >= 2) timed_out = timed_out || !wd3_wait(f_done, kbase - 1);
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int p3 = 0; p3 < 3; ++p3) Bf[(s * 3 + p3) * 64] = bfr[s][p3];
+            }
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 // ---- stage chunk c (sequence number kbase + c) into buffer c & 1: dZ in registers, split, three 8-byte stores per group ----
@@ -610,9 +665,8 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
                 if constexpr (AM == A_DZ_POOL) dm = rdm[c & 1], ar = rarg[c & 1];
                 float4 bt;   // A_DZ_POOL: b + g dm, what the arg-max row of a channel starts from
                 bt.x = fmaf(cg.x, dm[0], cb.x), bt.y = fmaf(cg.y, dm[1], cb.y), bt.z = fmaf(cg.z, dm[2], cb.z), bt.w = fmaf(cg.w, dm[3], cb.w);
-                uint2 ph[8], pm[8], pl[8];   // the split goes ahead of the wait for the buffer
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                // the dZ elements of one 16-byte group of the chunk
+                auto dz4 = [&](int i) -> f32x4 {
                     const f32x4 z = rz[c & 1][i];
                     const int r = rb + 4 * i;
                     f32x4 v;
@@ -624,20 +678,40 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
                         v[0] = fmaf(ca.x, z[0], r == ar.x ? bt.x : cb.x), v[1] = fmaf(ca.y, z[1], r == ar.y ? bt.y : cb.y);
                         v[2] = fmaf(ca.z, z[2], r == ar.z ? bt.z : cb.z), v[3] = fmaf(ca.w, z[3], r == ar.w ? bt.w : cb.w);
                     }
-                    wd3_split4(v, ph[i], pm[i], pl[i]);
-                }
-                WD3_STAMP(0)   // dZ and its pieces
-                // this register set is free: the chunk two ahead goes out
-                if (c + 2 < NC) fetch_chunk(true, strip, c + 2);
-                else fetch_chunk(more, snext, c + 2 - NC);
-                if (kbase + c >= 2) timed_out |= !wd3_wait(f_done, kbase + c - 1);   // the partner has finished with this buffer
-                WD3_STAMP(1)   // wait for the buffer
+                    return v;
+                };
+                if constexpr (AM == A_DZ_POOL) {   // the split goes ahead of the wait for the buffer (48 registers the dense form lacks)
+                    uint2 ph[8], pm[8], pl[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    unsigned char *dst = Ab + wofs[i & 3] + i * 512;
-                    *reinterpret_cast<uint2 *>(dst) = ph[i];
-                    *reinterpret_cast<uint2 *>(dst + APLANE) = pm[i];
-                    *reinterpret_cast<uint2 *>(dst + 2 * APLANE) = pl[i];
+                    for (int i = 0; i < 8; ++i) wd3_split4(dz4(i), ph[i], pm[i], pl[i]);
+                    WD3_STAMP(0)   // dZ and its pieces
+                    // this register set is free: the chunk two ahead goes out
+                    if (c + 2 < NC) fetch_chunk(true, strip, c + 2);
+                    else fetch_chunk(more, snext, c + 2 - NC);
+                    if (kbase + c >= 2) timed_out = timed_out || !wd3_wait(f_done, kbase + c - 1);   // the partner has finished with this buffer
+                    WD3_STAMP(1)   // wait for the buffer
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        unsigned char *dst = Ab + wofs[i & 3] + i * 512;
+                        *reinterpret_cast<uint2 *>(dst) = ph[i];
+                        *reinterpret_cast<uint2 *>(dst + APLANE) = pm[i];
+                        *reinterpret_cast<uint2 *>(dst + 2 * APLANE) = pl[i];
+                    }
+                } else {
+                    if (kbase + c >= 2) timed_out = timed_out || !wd3_wait(f_done, kbase + c - 1);   // the partner has finished with this buffer
+                    WD3_STAMP(1)   // wait for the buffer
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        uint2 h, m, l;
+                        wd3_split4(dz4(i), h, m, l);
+                        unsigned char *dst = Ab + wofs[i & 3] + i * 512;
+                        *reinterpret_cast<uint2 *>(dst) = h;
+                        *reinterpret_cast<uint2 *>(dst + APLANE) = m;
+                        *reinterpret_cast<uint2 *>(dst + 2 * APLANE) = l;
+                    }
+                    WD3_STAMP(0)   // dZ, its pieces, the image
+                    if (c + 2 < NC) fetch_chunk(true, strip, c + 2);
+                    else fetch_chunk(more, snext, c + 2 - NC);
                 }
                 wd3_post(f_ready, kbase + c + 1);
                 WD3_STAMP(2)   // image written and published
@@ -655,66 +729,35 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dws[i][r] = 0.f;
         }
-        const __amdgpu_buffer_rsrc_t resP = wd3_rsrc(E.zp), resC = wd3_rsrc(E.c);
-        // accumulator positions of a strip of layer l-1 (z_{l-1} in, dY_{l-1} out): row 4 lh + (r & 3) + 8 (r >> 2), column n0 + l31; the
-        // lane part is ONE register, the register part is uniform and rides in the instruction's scalar offset
-        const unsigned oq = 4u * ((unsigned)(4 * lh) * (unsigned)Nout + (unsigned)(n0 + l31));
-        auto quni = [&](int r) -> unsigned { return 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * Nout); };
-        const float e_sc = E.scale[n0 + l31], e_sh = E.shift[n0 + l31], e_mu = E.mu[n0 + l31], e_is = E.istd[n0 + l31];
-        float zq[16], zn[16];
-        {
-            const __amdgpu_buffer_rsrc_t rP = strip < nstrips ? resP : resNull;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zn[r] = wd3_load1(rP, oq, (unsigned)strip * (32u * (unsigned)Nout * 4u) + quni(r));
-        }
+        const __amdgpu_buffer_rsrc_t resC = wd3_rsrc(E.c);
+        const float e_mu = E.mu[n0 + l31], e_is = E.istd[n0 + l31];
+        float zq[16];   // z_{l-1} of the strip: requested at its start, used in its epilogue (mask, sum v z)
         const unsigned arow = (unsigned)(l31 * 128);
         const int ax = xs(l31);
         const unsigned char *brow = Wp + l31 * WPITCH;
         const int bx = xw(l31);
-        unsigned tofs[2][2][2];   // transposed reads [c-tile of the chunk][step s][block]: rows 16 s + 8 blk + 4 lh + qq, columns 32 it + l31
+        // transposed reads [c-tile it of the chunk][step s][block b]: rows 16 s + 8 b + 4 lh + qq, columns 32 it + l31.  Two registers
+        // (b = 0, 1): step s adds 16 rows = 2,048 bytes (bit 4 of the row is not in x(r)), c-tile it adds 4 to the group index, which
+        // the XOR with x(r) turns into ^ 64 on the byte offset
+        unsigned tbase[2];
         {
             const int gi = lane & 15, qq = gi >> 2, pp = gi & 3, g1 = (lane >> 4) & 1;
 #pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const int r = 16 * s + 8 * b + 4 * lh + qq, ch = 4 * it + 2 * g1 + (pp >> 1);
-                        tofs[it][s][b] = (unsigned)(r * 128 + 16 * (ch ^ xs(r)) + 8 * (pp & 1));
-                    }
+            for (int b = 0; b < 2; ++b) {
+                const int r = 8 * b + 4 * lh + qq, ch = 2 * g1 + (pp >> 1);
+                tbase[b] = (unsigned)(r * 128 + 16 * (ch ^ xs(r)) + 8 * (pp & 1));
+            }
         }
+        auto tofs = [&](int it, int s, int b) -> unsigned { return (tbase[b] ^ (unsigned)(it * 64)) + (unsigned)(s * 2048); };
         unsigned kbase = 0;
         for (; strip < nstrips; strip += stride, kbase += NC) {
             const bool more = strip + stride < nstrips;
-            // ---- relu(bn(z_{l-1})) of the strip: the dW product's B fragments straight from the registers, the mask bits; then the
-            // next strip's values are requested ----
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zq[r] = zn[r];
             {
-                const __amdgpu_buffer_rsrc_t nP = more ? resP : resNull;
-                const unsigned sn_off = (unsigned)(strip + stride) * (32u * (unsigned)Nout * 4u);
+                const unsigned sq_off = (unsigned)strip * (32u * (unsigned)Nout * 4u);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) zn[r] = wd3_load1(nP, oq, sn_off + quni(r));
+                for (int r = 0; r < 16; ++r) zq[r] = wd3_load1(resP, oq, sq_off + quni(r));
             }
-            uint4 bfr[2][3];   // [step][piece]
-            {
-                float act[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) act[r] = fmaxf(fmaf(zq[r], e_sc, e_sh), 0.f);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    f32x4 v0, v1;
-                    v0[0] = act[8 * s + 0], v0[1] = act[8 * s + 1], v0[2] = act[8 * s + 2], v0[3] = act[8 * s + 3];
-                    v1[0] = act[8 * s + 4], v1[1] = act[8 * s + 5], v1[2] = act[8 * s + 6], v1[3] = act[8 * s + 7];
-                    uint2 h0, m0, l0, h1, m1, l1;
-                    wd3_split4(v0, h0, m0, l0);
-                    wd3_split4(v1, h1, m1, l1);
-                    bfr[s][0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-                    bfr[s][1] = make_uint4(m0.x, m0.y, m1.x, m1.y);
-                    bfr[s][2] = make_uint4(l0.x, l0.y, l1.x, l1.y);
-                }
-            }
+            uint4 bfr[2][3];   // [step][piece]: relu(bn(z_{l-1})) of the strip, built by the partner (read behind the wait for chunk 0)
             f32x16 acc, accs;   // dA: the leading products and (ACC2) the small ones, added in the epilogue
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -726,7 +769,13 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const unsigned char *Ab = Ap + (c & 1) * ABUF;
-                timed_out |= !wd3_wait(f_ready, kbase + c + 1);
+                timed_out = timed_out || !wd3_wait(f_ready, kbase + c + 1);
+                if (c == 0) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int p3 = 0; p3 < 3; ++p3) bfr[s][p3] = Bf[(s * 3 + p3) * 64];
+                }
                 WD3_STAMP(4)   // wait for the chunk
                 // ---- dA += dZ_chunk W_chunk: step t covers k = 64 c + 16 t + 8 lh + (0 .. 7) ----
 #pragma unroll
@@ -762,7 +811,7 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
                         uint4 ta[3];
 #pragma unroll
                         for (int p = 0; p < 3; ++p) {
-                            const uint2 lo = wd3_tr(Ab + p * APLANE + tofs[it][s][0]), hi = wd3_tr(Ab + p * APLANE + tofs[it][s][1]);
+                            const uint2 lo = wd3_tr(Ab + p * APLANE + tofs(it, s, 0)), hi = wd3_tr(Ab + p * APLANE + tofs(it, s, 1));
                             ta[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
                         }
                         if (it == 1 && s == 1) wd3_post(f_done, kbase + c + 1);   // the last reads of this buffer have landed
@@ -856,7 +905,9 @@ static auto wsd3_kernel_of() {   // K = 256: form A; K = 128: form B (only the f
 
 template <int KD, int BN, int AM>
 static void wsd3_launch(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int workers, int ncol, hipStream_t st) {
-    constexpr size_t main_b = (size_t)3 * BN * KD * 2 + (size_t)4 * 2 * 3 * 32 * 128 + (size_t)3 * KD * 4 + 64;
+    // (a first version of form B sized this by hand and forgot the fragments: its counters lay behind the end of the allocation, LDS
+    //  drops such writes without a fault, and every poll ran into its bound)
+    constexpr size_t main_b = Wsd3Lds<KD, BN, KD != 256>::END;
     constexpr size_t red_b = (size_t)(KD / 32) * (BN / 32) * 4 * 4 * 64 * 16 + (size_t)4 * 2 * BN * 8;
     constexpr size_t lds = main_b > red_b ? main_b : red_b;
     static_assert(lds <= 160 * 1024, "LDS budget");
