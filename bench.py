@@ -40,7 +40,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: BF16 dense (the opt-in bf16-operand variant's kernels)
 # float32 products formed as six exact bf16 x bf16 partial products (csrc/gemm_wsf3_kernels.hip): float32-equivalent FLOP/s of the bf16 pipe
 MFMA_SPLIT_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
-SPLIT_KERNELS = ("gemm_wsf3_kernel", "gemm_wsp3_kernel", "gemm_wsd3_kernel")
+SPLIT_KERNELS = ("gemm_wsf3_kernel", "gemm_wsd3_kernel")
 FLOPS_PER_CLOUD = 0.8542e9     # 3 x 2 x 142,369,280 MAC, forward + backward, independent of N
 BYTES_PER_CLOUD = 34.6e6       # 5 E + 3 G float32 words + xyz / indices
 
@@ -316,11 +316,11 @@ def kernel_cost(tag: str):
         m = re.search(pattern, text)
         return tuple(int(x) for x in m.groups()) if m else None
 
-    if tag.startswith(("gemm_wsp3_kernel", "gemm_wsd3_kernel")) and ",A4>" in tag:
+    if tag.startswith("gemm_wsd3_kernel") and ",A4>" in tag:
         # the same fused product with a DENSE upstream gradient (a grouped level's middle layer): dY_l and Z_l read once
         M, N, K = ints(r"M=(\d+) N=(\d+) K=(\d+)")
         return 4.0 * M * N * K, 4.0 * (2.0 * M * K + 2.0 * M * N + 2.0 * K * N)
-    if tag.startswith(("gemm_wsp_kernel", "gemm_wsq_kernel", "gemm_wsp3_kernel", "gemm_wsd3_kernel")):
+    if tag.startswith(("gemm_wsp_kernel", "gemm_wsq_kernel", "gemm_wsd3_kernel")):
         # the fused backward product of a level's last layer on gemm_wsp / gemm_wsq: dA (+ ReLU mask, sums) and dW in one launch;
         # Z_l and z_{l-1} read once, dY_{l-1} written once, the weights read and dW written once.  The kernel's own dW partial
         # slabs (one per workgroup) are NOT algorithmic bytes: they show up in `traffic` (round 3 counted them here and read 1.035 x;

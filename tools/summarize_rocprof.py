@@ -50,13 +50,10 @@ def tag_of(name, gx, gy, wg):
     m = re.search(r"gemm_wsf_kernel<(\d+), (\d+), (\d+), (\d+)>", name)
     if m:
         return f"gemm_wsf_kernel<{m.group(1)},{m.group(2)},A{m.group(3)},E{m.group(4)}> {g}"
-    # round 4: the split-product kernels (bench.py tags: gemm_wsf3_kernel<K,Aa,Ee>, gemm_wsp3_kernel<K,Aa>, gemm_wsd3_kernel<K,BN>)
+    # round 4: the split-product kernels (bench.py tags: gemm_wsf3_kernel<K,Aa,Ee>, gemm_wsd3_kernel<K,BN,Aa>)
     m = re.search(r"gemm_wsf3_kernel<(\d+), \d+, (\d+), (\d+)>", name)
     if m:
         return f"gemm_wsf3_kernel<{m.group(1)},A{m.group(2)},E{m.group(3)}> {g}"
-    m = re.search(r"gemm_wsp3_kernel<(\d+), (\d+)>", name)
-    if m:
-        return f"gemm_wsp3_kernel<{m.group(1)},A{m.group(2)}> {g}"
     m = re.search(r"gemm_wsd3_kernel<(\d+), (\d+), (\d+)>", name)   # form B (K = 128): <K, BN, A mode>
     if m:
         return f"gemm_wsd3_kernel<{m.group(1)},{m.group(2)},A{m.group(3)}> {g}"
