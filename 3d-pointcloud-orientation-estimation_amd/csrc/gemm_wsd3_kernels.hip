@@ -19,17 +19,19 @@
 // published) and `done` (chunks C has finished reading).  P writes chunk k into buffer k & 1 once done >= k - 1; C reads it once
 // ready >= k + 1.  LDS operations of one wave complete in order and the counters only grow, so there is no cycle to wait in; the
 // polls are bounded all the same (a poll that gave up sets g_wsd3_timeouts and goes on: wrong numbers, never a hang; the tests check
-// the mark).  Every workgroup owns 32 output columns, so that the C wave's dW (K x 32) is 64 or 128 registers.
-//   form B (K = 128; SA1's last layer 128 -> 64 and SA2's middle layer 128 -> 128): P only builds the image -- streams Z (and dY) one
-//           strip ahead, computes dZ, splits it, writes it -- vector work and memory, no MFMA; C does ALL the matrix work: takes
-//           relu(bn(z_{l-1})) of the strip from registers in accumulator layout (eight consecutive registers are one 32x32x16 operand),
-//           multiplies the image rows with the weight panel (dA; the small products in an accumulator of their own), reads the SAME
-//           image transposed (ds_read_b64_tr_b16, rows in the accumulator layout's order) for dW, masks, stores, collects the sums.
-//           In-kernel stamps: C is the critical path (dA 30 %, dW 30 %, activation fragments 20 %, epilogue 13 %), P waits 43 %.
-//   form A (K = 256; SA2's last layer 256 -> 128): dW alone is 128 registers, the dA tile does not fit beside it: P also multiplies
-//           the image with the weight panel and runs the epilogue (and stages the next strip's first chunk BEFORE its epilogue: the
-//           partner multiplies while it stores, and behind the epilogue's 64 memory operations the compiler can no longer count vmcnt
-//           and waits for everything); C only accumulates dW.  Stamps: P is the critical path, C waits 51 %.
+// the mark).  Every workgroup owns 32 output columns, so that dW (K x 32) is 64 registers per wave.
+//   P builds the image -- streams Z (and dY) one strip ahead, computes dZ (one compare + select + FMA per element), splits it, writes
+//     it: vector work and memory;
+//   C multiplies: dA from the image rows x the weight panel (small products in an accumulator of their own), dW with the activation
+//     operand relu(bn(z_{l-1})) as eight consecutive accumulator-layout registers per 32x32x16 operand and the dZ operand from the SAME
+//     image read transposed (ds_read_b64_tr_b16, rows in the accumulator layout's order: no second image), then mask, store, sums.
+//   K = 128 (SA1's last layer 128 -> 64, SA2's middle layer 128 -> 128): dW is 128 x 32 = 64 registers in C (and a second set for its
+//     small products); P also builds the strip's activation fragments and hands them to C through LDS.  Stamps: C is the critical
+//     path (dA 33 %, dW 26 %, fragments / turn-around 20 %), P waits 23 %.
+//   K = 256 (SA2's last layer 256 -> 128): dW is 128 registers -- the tiles of the chunks' second half live in P, which multiplies its
+//     own image for them (48 of a strip's 192 MFMAs); no LDS is left for the hand-off, both waves build the
+//     activation fragments.  Stamps: P 54 k ticks, C 57 k per launch -- balanced.  (A first arrangement for K = 256 had P multiply dA
+//     and run the epilogue and C hold all of dW: P was the critical path, C waited 48 %: 37.4 against 34.6 us on one box.)
 // Image layout: 16-byte group g of row r at g ^ x(r), x(r) = 4 bit1(r) + bits3:2(r): conflict-free for the row reads (the four
 // 16-lane groups of a ds_read_b128 see eight different x per row parity) and for the transposed reads (rows r and r + 2 of a block
 // differ in x's bit 2).  Addresses: ONE lane-offset register per stream, everything uniform in the instructions' scalar offsets -- a
@@ -108,412 +110,30 @@ __device__ unsigned long long g_wsd3_stamps[2][2][8];   // [KD == 256][P, C][pha
 #endif
 
 // LDS layout of both forms (bytes), ONE definition for the kernels and the launcher: weight panel (three planes of [BN][KD] bf16) |
-// four pairs x two chunk-image buffers (three planes of [32][64] bf16) | constant table [3][KD] floats | form B: four pairs' activation
+// four pairs x two chunk-image buffers (three planes of [32][64] bf16) | constant table [3][KD] floats | K = 128: four pairs' activation
 // fragments [2 steps][3 pieces][64 lanes] x 16 bytes | eight counters
-template <int KD, int BN, bool FORMB>
+template <int KD, int BN, bool HANDOFF>
 struct Wsd3Lds {
     static constexpr int WPLANE = BN * KD * 2, APLANE = 32 * 128, ABUF = 3 * APLANE, APAIR = 2 * ABUF, BFR = 2 * 3 * 64 * 16;
     static constexpr int OFF_IMG = 3 * WPLANE, OFF_CST = OFF_IMG + 4 * APAIR, OFF_BFR = OFF_CST + 3 * KD * 4;
-    static constexpr int OFF_FLG = OFF_BFR + (FORMB ? 4 * BFR : 0), END = OFF_FLG + 64;
+    static constexpr int OFF_FLG = OFF_BFR + (HANDOFF ? 4 * BFR : 0), END = OFF_FLG + 64;
 };
 
-// ---- form A (K = 256): the producer wave also multiplies dZ with the weights (dA) and runs the epilogue; the consumer wave holds dW
-// (256 x 32 = 128 registers) and has no room for the dA tile beside it ----
-template <int KD, int BN>
-__global__ void __launch_bounds__(512, 1)
-gemm_wsd3a_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, int Nout, int ncol, const Epilogue E) {
-    constexpr int NC = KD / 64, CT = KD / 32, NT = BN / 32;
-    constexpr int WPITCH = KD * 2, WPLANE = BN * WPITCH;     // bytes: row and plane of the weight panel [n][k]
-    constexpr int APLANE = 32 * 128, ABUF = 3 * APLANE;      // bytes: plane and buffer (three planes) of a dZ chunk image
-    constexpr int APAIR = 2 * ABUF;                          // two buffers per wave pair
-    using LY = Wsd3Lds<KD, BN, false>;
-    constexpr int OFF_IMG = LY::OFF_IMG, OFF_CST = LY::OFF_CST, OFF_FLG = LY::OFF_FLG;
-    static_assert(NC % 2 == 0, "chunk k of a strip uses buffer k & 1");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
-    unsigned char *Wp = lds3;
-    float *Tc = reinterpret_cast<float *>(lds3 + OFF_CST);   // [3][KD]: g, a, b of dZ = g dY + a Z + b
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wave < 4;
-    const int pair = wave & 3;
-    unsigned char *Ap = lds3 + OFF_IMG + pair * APAIR;
-    wd3_flag *f_ready = (wd3_flag *)(lds3 + OFF_FLG) + 2 * pair, *f_done = f_ready + 1;
-    const int l31 = lane & 31, lh = lane >> 5;
-    auto xs = [](int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); };   // chunk XOR of image row r
-    auto xw = [](int n) { return n & 15; };                                  // chunk XOR of panel row n
-
-    const int nworkers = gridDim.x / ncol;
-    int col_blk = blockIdx.x % ncol, worker = blockIdx.x / ncol;
-    if ((nworkers & 7) == 0) {   // XCD-aware: the column blocks of one worker share an L2
-        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        col_blk = i % ncol, worker = (i / ncol) * 8 + xcd;
-    }
-    const int n0 = col_blk * BN;
-    const int nstrips = M / 32, stride = nworkers * 4;
-    int strip = worker * 4 + pair;
-    const __amdgpu_buffer_rsrc_t resP = wd3_rsrc(E.zp);
-    const __amdgpu_buffer_rsrc_t resNull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A.z), (short)0, 0, 0x00020000);
-    // accumulator positions of a strip of layer l-1 (z_{l-1} in, dY_{l-1} out): row 4 lh + (r & 3) + 8 (r >> 2), column n0 + 32 j + l31
-    const unsigned oq = 4u * ((unsigned)(4 * lh) * (unsigned)Nout + (unsigned)(n0 + l31));
-    // (the lane part `oq` is ONE register; the (column tile, register) part is uniform and rides in the instruction's scalar offset --
-    //  32 per-position address registers were what this kernel spilled, and a spilled address serialises the loads behind vmcnt(0))
-    auto quni = [&](int j, int r) -> unsigned { return 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * Nout + 32 * j); };
-    float e_sc[NT], e_sh[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) e_sc[j] = E.scale[n0 + j * 32 + l31], e_sh[j] = E.shift[n0 + j * 32 + l31];
-
-    // ---- prologue, all eight waves: counters, the constant table, the weight panel ----
-    if (tid < 8) ((wd3_flag *)(lds3 + OFF_FLG))[tid] = 0u;
-    for (int c = tid; c < KD; c += 512) {
-        const float g = A.cst[c], mu = A.cst[A.C + c], is = A.cst[2 * A.C + c], c1 = A.cst[3 * A.C + c], c2 = A.cst[4 * A.C + c];
-        const float a = -g * is * c2;
-        Tc[c] = g, Tc[KD + c] = a, Tc[2 * KD + c] = -g * c1 - a * mu;
-    }
-    {   // W is (KD x Nout) row-major; image [n][k] of columns n0 .. n0 + BN - 1 in three bf16 planes (lane = column n: four dword loads
-        // of consecutive rows k, split, one 8-byte store per plane)
-        constexpr int NWF = (KD / 4) * BN / 512;
-        f32x4 tw[NWF];
-#pragma unroll
-        for (int j = 0; j < NWF; ++j) {
-            const int f = tid + 512 * j, nl = f % BN, k4 = 4 * (f / BN);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tw[j][e] = W[(size_t)(k4 + e) * ldw + n0 + nl];
-        }
-#pragma unroll
-        for (int j = 0; j < NWF; ++j) {
-            const int f = tid + 512 * j, nl = f % BN, k4 = 4 * (f / BN);
-            uint2 h, m, l;
-            wd3_split4(tw[j], h, m, l);
-            unsigned char *dst = Wp + nl * WPITCH + 16 * ((k4 >> 3) ^ xw(nl)) + 2 * (k4 & 7);
-            *reinterpret_cast<uint2 *>(dst) = h;
-            *reinterpret_cast<uint2 *>(dst + WPLANE) = m;
-            *reinterpret_cast<uint2 *>(dst + 2 * WPLANE) = l;
-        }
-    }
-    __syncthreads();
-
-#ifdef PNPP_STAMPS
-    const bool st_on = blockIdx.x == 8 && pair == 0;
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st_last = __builtin_amdgcn_s_memtime();
-#endif
-    f32x16 dw[CT][NT];            // C waves
-    double s1[NT], s2[NT];        // P waves
-    bool timed_out = false;
-
-    if (producer) {
-        // =========================== P: dZ image, dA, epilogue ===========================
-        const int q = lane & 15, q4 = 4 * q, rb = lane >> 4;   // staging map: channels 64 c + 4 q .. + 3, rows rb + 4 i
-        const __amdgpu_buffer_rsrc_t resZ = wd3_rsrc(A.z), resY = wd3_rsrc(A.a), resI = wd3_rsrc(A.arg), resC = wd3_rsrc(E.c);
-        const unsigned oa0 = 4u * ((unsigned)rb * (unsigned)KD + (unsigned)q4);
-        f32x4 rz[2][8], rdm[2];   // two chunk register sets in flight
-        int4 rarg[2];
-        float zq[NT][16];
-        auto fetch_chunk = [&](bool have, int s, int c) {   // chunk c of strip s into register set c & 1
-            const __amdgpu_buffer_rsrc_t rZ = have ? resZ : resNull, rY = have ? resY : resNull, rI = have ? resI : resNull;
-            const unsigned so = (unsigned)s * (32u * KD * 4u) + 256u * (unsigned)c;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) rz[c & 1][i] = wd3_load4(rZ, oa0, so + (unsigned)i * (4u * KD * 4u));
-            const unsigned sg = (unsigned)s * (KD * 4u) + 256u * (unsigned)c;   // one row of the pooled tables per strip
-            rdm[c & 1] = wd3_load4(rY, 4u * (unsigned)q4, sg);
-            rarg[c & 1] = __builtin_bit_cast(int4, wd3_load4(rI, 4u * (unsigned)q4, sg));
-        };
-        {
-            const bool have = strip < nstrips;
-            fetch_chunk(have, strip, 0);
-            fetch_chunk(have, strip, 1);
-            const __amdgpu_buffer_rsrc_t rP = have ? resP : resNull;
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) zq[j][r] = wd3_load1(rP, oq, (unsigned)strip * (32u * (unsigned)Nout * 4u) + quni(j, r));
-        }
-        double e_mu[NT], e_is[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            e_mu[j] = (double)E.mu[n0 + j * 32 + l31], e_is[j] = (double)E.istd[n0 + j * 32 + l31];
-            s1[j] = s2[j] = 0.0;
-        }
-        // LDS offsets of this lane inside a chunk-image plane: staging (row rb + 4 i: x(r) = 4 bit1(rb) + (i & 3)) and row reads
-        unsigned wofs[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wofs[i] = (unsigned)(rb * 128 + 16 * ((q >> 1) ^ (((rb >> 1) & 1) << 2 | i)) + 8 * (q & 1));
-        const unsigned arow = (unsigned)(l31 * 128);
-        const int ax = xs(l31);
-        const unsigned char *brow[NT];
-        int bx[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            brow[j] = Wp + (j * 32 + l31) * WPITCH;
-            bx[j] = xw(j * 32 + l31);
-        }
-#ifdef WD3_PRIO
-        __builtin_amdgcn_s_setprio(WD3_PRIO);
-#endif
-        unsigned kbase = 0;   // chunks of the strips before this one
-        // ---- stage chunk c of strip s (sequence number k) into buffer c & 1: dZ in registers, split, three 8-byte stores per group; then
-        // the register set is free and the chunk two ahead goes out ----
-        auto stage = [&](int c, unsigned k, int s, bool more2, int s2) {   // (more2, s2): the strip the chunk two ahead belongs to
-            unsigned char *Ab = Ap + (c & 1) * ABUF;
-            const float4 cg = *reinterpret_cast<const float4 *>(Tc + 64 * c + q4), ca = *reinterpret_cast<const float4 *>(Tc + KD + 64 * c + q4);
-            const float4 cb = *reinterpret_cast<const float4 *>(Tc + 2 * KD + 64 * c + q4);
-            const f32x4 dm = rdm[c & 1];
-            const int4 ar = rarg[c & 1];
-            float4 bt;   // b + g dm: what the arg-max row of a channel starts from
-            bt.x = fmaf(cg.x, dm[0], cb.x), bt.y = fmaf(cg.y, dm[1], cb.y), bt.z = fmaf(cg.z, dm[2], cb.z), bt.w = fmaf(cg.w, dm[3], cb.w);
-            WD3_STAMP(0)   // constants, pooled tables
-            if (k >= 2) timed_out = timed_out || !wd3_wait(f_done, k - 1);   // the partner has finished with this buffer
-            WD3_STAMP(1)   // wait for the buffer
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x4 z = rz[c & 1][i];
-                const int r = rb + 4 * i;
-                f32x4 v;
-                v[0] = fmaf(ca.x, z[0], r == ar.x ? bt.x : cb.x), v[1] = fmaf(ca.y, z[1], r == ar.y ? bt.y : cb.y);
-                v[2] = fmaf(ca.z, z[2], r == ar.z ? bt.z : cb.z), v[3] = fmaf(ca.w, z[3], r == ar.w ? bt.w : cb.w);
-                uint2 h, m, l;
-                wd3_split4(v, h, m, l);
-                unsigned char *dst = Ab + wofs[i & 3] + i * 512;
-                *reinterpret_cast<uint2 *>(dst) = h;
-                *reinterpret_cast<uint2 *>(dst + APLANE) = m;
-                *reinterpret_cast<uint2 *>(dst + 2 * APLANE) = l;
-            }
-            WD3_STAMP(2)   // staging
-            wd3_post(f_ready, k + 1);
-            if (c + 2 < NC) fetch_chunk(true, s, c + 2);
-            else fetch_chunk(more2, s2, c + 2 - NC);
-            WD3_STAMP(3)   // publish + next loads issued
-        };
-        if (strip < nstrips) stage(0, 0u, strip, strip + stride < nstrips, strip + stride);
-        for (; strip < nstrips; strip += stride, kbase += NC) {
-            const bool more = strip + stride < nstrips;
-            const int snext = strip + stride;
-            f32x16 acc[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const unsigned char *Ab = Ap + (c & 1) * ABUF;
-                if (c > 0) stage(c, kbase + c, strip, more, snext);
-                // ---- dA += dZ_chunk W_chunk: step t covers k = 64 c + 16 t + 8 lh + (0 .. 7) ----
-                // one fragment set: the partner wave covers this wave's LDS latency (and 256 registers do not hold two)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int g = 2 * t + lh;
-                    uint4 fa[3], fb[NT][3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) fa[p] = *reinterpret_cast<const uint4 *>(Ab + p * APLANE + arow + 16 * (g ^ ax));
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-#pragma unroll
-                        for (int p = 0; p < 3; ++p)
-                            fb[j][p] = *reinterpret_cast<const uint4 *>(brow[j] + p * WPLANE + 16 * ((8 * c + g) ^ bx[j]));
-                    const wd3_bf16x8 ah = wd3_op(fa[0]), am = wd3_op(fa[1]), al = wd3_op(fa[2]);
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const wd3_bf16x8 bh = wd3_op(fb[j][0]), bm = wd3_op(fb[j][1]), bl = wd3_op(fb[j][2]);
-                        f32x16 d = acc[j];   // the small products first, the leading one last
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, d, 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, d, 0, 0, 0);
-                    }
-                }
-                WD3_STAMP(4)   // dA product of the chunk (issue; the last MFMAs may still run)
-            }
-            // the next strip's first chunk goes to the partner BEFORE this strip's epilogue: the partner multiplies while this wave
-            // stores, and the wait for that chunk's operands has only the other chunk's loads behind it (behind the epilogue's 64 memory
-            // operations the compiler can no longer count and waits for everything)
-            if (more) stage(0, kbase + NC, snext, snext + stride < nstrips, snext + stride);
-            // ---- epilogue: mask, store, BatchNorm-backward sums of layer l-1; each z_{l-1} register is re-loaded for the next strip
-            // right behind its use ----
-            {
-                const unsigned sc_off = (unsigned)strip * (32u * (unsigned)Nout * 4u), sn_off = (unsigned)snext * (32u * (unsigned)Nout * 4u);
-                const __amdgpu_buffer_rsrc_t nP = more ? resP : resNull;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float z0 = zq[j][r];
-                        const float v = fmaf(z0, e_sc[j], e_sh[j]) > 0.f ? acc[j][r] : 0.f;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), resC, (int)oq, (int)(sc_off + quni(j, r)), 0);
-                        t1 += v;
-                        t2 = fmaf(v, z0, t2);
-                        zq[j][r] = wd3_load1(nP, oq, sn_off + quni(j, r));
-                    }
-                    const double d1 = (double)t1;   // sum v xhat = istd (sum v z - mu sum v), finished in float64
-                    s1[j] += d1, s2[j] += e_is[j] * ((double)t2 - e_mu[j] * d1);
-                }
-            }
-            WD3_STAMP(5)   // epilogue
-        }
-    } else {
-        // =========================== C: dW from the partner's image ===========================
-#pragma unroll
-        for (int i = 0; i < CT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dw[i][j][r] = 0.f;
-        float zq[NT][16];
-        {
-            const __amdgpu_buffer_rsrc_t rP = strip < nstrips ? resP : resNull;
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) zq[j][r] = wd3_load1(rP, oq, (unsigned)strip * (32u * (unsigned)Nout * 4u) + quni(j, r));
-        }
-        unsigned tofs[2][2][2];   // transposed reads [c-tile of the chunk][step s][block]: rows 16 s + 8 blk + 4 lh + qq, columns 32 it + l31
-        {
-            const int gi = lane & 15, qq = gi >> 2, pp = gi & 3, g1 = (lane >> 4) & 1;
-#pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const int r = 16 * s + 8 * b + 4 * lh + qq, ch = 4 * it + 2 * g1 + (pp >> 1);
-                        tofs[it][s][b] = (unsigned)(r * 128 + 16 * (ch ^ xs(r)) + 8 * (pp & 1));
-                    }
-        }
-        unsigned kbase = 0;
-        for (; strip < nstrips; strip += stride, kbase += NC) {
-            const bool more = strip + stride < nstrips;
-            // ---- relu(bn(z_{l-1})) of the strip: the dW product's B fragments straight from the registers; then the registers take the
-            // next strip's values ----
-            uint4 bfr[NT][2][3];   // [column tile][step][piece]
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                float act[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) act[r] = fmaxf(fmaf(zq[j][r], e_sc[j], e_sh[j]), 0.f);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    f32x4 v0, v1;
-                    v0[0] = act[8 * s + 0], v0[1] = act[8 * s + 1], v0[2] = act[8 * s + 2], v0[3] = act[8 * s + 3];
-                    v1[0] = act[8 * s + 4], v1[1] = act[8 * s + 5], v1[2] = act[8 * s + 6], v1[3] = act[8 * s + 7];
-                    uint2 h0, m0, l0, h1, m1, l1;
-                    wd3_split4(v0, h0, m0, l0);
-                    wd3_split4(v1, h1, m1, l1);
-                    bfr[j][s][0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-                    bfr[j][s][1] = make_uint4(m0.x, m0.y, m1.x, m1.y);
-                    bfr[j][s][2] = make_uint4(l0.x, l0.y, l1.x, l1.y);
-                }
-            }
-            {
-                const __amdgpu_buffer_rsrc_t nP = more ? resP : resNull;
-                const unsigned sn_off = (unsigned)(strip + stride) * (32u * (unsigned)Nout * 4u);
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) zq[j][r] = wd3_load1(nP, oq, sn_off + quni(j, r));
-            }
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const unsigned char *Ab = Ap + (c & 1) * ABUF;
-                WD3_STAMP(0)   // activation fragments (first chunk) / loop turn-around
-                timed_out = timed_out || !wd3_wait(f_ready, kbase + c + 1);
-                WD3_STAMP(1)   // wait for the chunk
-#pragma unroll
-                for (int it = 0; it < 2; ++it)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        uint4 ta[3];
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) {
-                            const uint2 lo = wd3_tr(Ab + p * APLANE + tofs[it][s][0]), hi = wd3_tr(Ab + p * APLANE + tofs[it][s][1]);
-                            ta[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                        }
-                        if (it == 1 && s == 1) wd3_post(f_done, kbase + c + 1);   // the last reads of this buffer have landed
-                        const wd3_bf16x8 ah = wd3_op(ta[0]), am = wd3_op(ta[1]), al = wd3_op(ta[2]);
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) {
-                            const wd3_bf16x8 bh = wd3_op(bfr[j][s][0]), bm = wd3_op(bfr[j][s][1]), bl = wd3_op(bfr[j][s][2]);
-                            f32x16 d = dw[2 * c + it][j];
-                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, d, 0, 0, 0);
-                            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, d, 0, 0, 0);
-                            dw[2 * c + it][j] = d;
-                        }
-                    }
-                WD3_STAMP(2)   // transposed reads + dW products of the chunk
-            }
-        }
-    }
-#ifdef PNPP_STAMPS
-    if (st_on && lane == 0)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) g_wsd3_stamps[KD == 256][producer ? 0 : 1][i] += st_acc[i];
-#endif
-    if (timed_out && lane == 0) atomicExch(&g_wsd3_timeouts, 1);
-
-    // ---- tails: one dW partial per workgroup (the four C waves' tiles added through LDS), the column statistics of the P waves ----
-    __syncthreads();   // every wave is done with the panel and the images
-    constexpr int NTILE = CT * NT;
-    f32x4 *red = reinterpret_cast<f32x4 *>(lds3);                    // [tile][C wave][r4][lane]
-    double *dred = reinterpret_cast<double *>(lds3 + NTILE * 4 * 4 * 64 * 16);   // [P wave][2][BN]
-    if (!producer) {
-#pragma unroll
-        for (int i = 0; i < CT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    f32x4 v;
-                    v[0] = dw[i][j][4 * r4], v[1] = dw[i][j][4 * r4 + 1], v[2] = dw[i][j][4 * r4 + 2], v[3] = dw[i][j][4 * r4 + 3];
-                    red[(((i * NT + j) * 4 + pair) * 4 + r4) * 64 + lane] = v;
-                }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const double a = s1[j] + shfl_xor_f64(s1[j], 32), b = s2[j] + shfl_xor_f64(s2[j], 32);
-            if (lh == 0) dred[(pair * 2 + 0) * BN + j * 32 + l31] = a, dred[(pair * 2 + 1) * BN + j * 32 + l31] = b;
-        }
-    }
-    __syncthreads();
-    {
-        float *wb = E.dwslab + (size_t)worker * KD * E.dw_ld + n0;
-        for (int t = wave; t < NTILE; t += 8) {   // tile t = (c-tile i, column tile j)
-            const int i = t / NT, j = t % NT;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4 a0 = red[((t * 4 + 0) * 4 + r4) * 64 + lane], a1 = red[((t * 4 + 1) * 4 + r4) * 64 + lane];
-                const f32x4 a2 = red[((t * 4 + 2) * 4 + r4) * 64 + lane], a3 = red[((t * 4 + 3) * 4 + r4) * 64 + lane];
-                const int c0 = i * 32 + 8 * r4 + 4 * lh;
-                float *o = wb + (size_t)c0 * E.dw_ld + j * 32 + l31;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[(size_t)e * E.dw_ld] = (a0[e] + a1[e]) + (a2[e] + a3[e]);
-            }
-        }
-        if (tid < 2 * BN) {
-            const int which = tid / BN, cl = tid % BN;
-            const double t = (dred[(0 * 2 + which) * BN + cl] + dred[(1 * 2 + which) * BN + cl]) +
-                             (dred[(2 * 2 + which) * BN + cl] + dred[(3 * 2 + which) * BN + cl]);
-            E.slab[((size_t)worker * 2 + which) * Nout + n0 + cl] = t;
-        }
-    }
-}
-
-// ---- form B (K = 128): the producer wave only builds the image (vector work), the consumer wave multiplies (both products) and runs
-// the epilogue: dW is 128 x 32 = 64 registers, so the dA tile and a second accumulator for its small products fit beside it ----
 template <int KD, int BN, int AM>
 __global__ void __launch_bounds__(512, 1)
 gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, int Nout, int ncol, const Epilogue E) {
     constexpr int NC = KD / 64, CT = KD / 32;
     static_assert(BN == 32, "one column tile per workgroup: the consumer wave holds dW (KD x 32) and the dA tile");
-    constexpr bool DW2 = CT <= 4;                            // a second dW accumulator set (the small products): where dW is 64 registers
-    constexpr bool ACC2 = CT <= 4;                           // a second dA accumulator (the small products): where dW is 64 registers
+    constexpr bool SPLITDW = CT > 4;                         // K = 256: the dW tiles of the chunks' second half live in the PRODUCER wave
+    constexpr int CTC = SPLITDW ? CT / 2 : CT;               // dW tiles (of 32 channels) the consumer wave holds
+    constexpr bool HANDOFF = !SPLITDW;                       // the producer hands the activation fragments over through LDS (K = 256: no LDS
+                                                             // left for them -- and the producer needs them itself: both waves build them)
+    constexpr bool DW2 = !SPLITDW;                           // a second dW accumulator set (the small products): where dW is 64 registers
+    constexpr bool ACC2 = true;                              // a second dA accumulator (the small products)
     constexpr int WPITCH = KD * 2, WPLANE = BN * WPITCH;     // bytes: row and plane of the weight panel [n][k]
     constexpr int APLANE = 32 * 128, ABUF = 3 * APLANE;      // bytes: plane and buffer (three planes) of a dZ chunk image
     constexpr int APAIR = 2 * ABUF;                          // two buffers per wave pair
-    using LY = Wsd3Lds<KD, BN, true>;
+    using LY = Wsd3Lds<KD, BN, HANDOFF>;
     constexpr int BFR = LY::BFR;                             // bytes: the strip's activation fragments, [step][piece][lane] of 16 bytes
     constexpr int OFF_IMG = LY::OFF_IMG, OFF_CST = LY::OFF_CST, OFF_BFR = LY::OFF_BFR, OFF_FLG = LY::OFF_FLG;
     static_assert(NC % 2 == 0, "chunk k of a strip uses buffer k & 1");
@@ -546,6 +166,65 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
     const unsigned oq = 4u * ((unsigned)(4 * lh) * (unsigned)Nout + (unsigned)(n0 + l31));
     auto quni = [&](int r) -> unsigned { return 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * Nout); };
     const float e_sc = E.scale[n0 + l31], e_sh = E.shift[n0 + l31];
+    // transposed reads [c-tile it of the chunk][step s][block b]: rows 16 s + 8 b + 4 lh + qq, columns 32 it + l31.  Two registers
+    // (b = 0, 1): step s adds 16 rows = 2,048 bytes (bit 4 of the row is not in x(r)), c-tile it adds 4 to the group index, which
+    // the XOR with x(r) turns into ^ 64 on the byte offset
+    unsigned tbase[2];
+    {
+        const int gi = lane & 15, qq = gi >> 2, pp = gi & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int r = 8 * b + 4 * lh + qq, ch = 2 * g1 + (pp >> 1);
+            tbase[b] = (unsigned)(r * 128 + 16 * (ch ^ xs(r)) + 8 * (pp & 1));
+        }
+    }
+    auto tofs = [&](int it, int s, int b) -> unsigned { return (tbase[b] ^ (unsigned)(it * 64)) + (unsigned)(s * 2048); };
+    // relu(bn(z_{l-1})) at this lane's 16 accumulator positions as the dW product's B fragments: eight consecutive registers are one
+    // 32x32x16 operand, in three pieces
+    auto act_fragments = [&](const float (&z)[16], uint4 (&bfr)[2][3]) {
+        float act[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) act[r] = fmaxf(fmaf(z[r], e_sc, e_sh), 0.f);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 v0, v1;
+            v0[0] = act[8 * s + 0], v0[1] = act[8 * s + 1], v0[2] = act[8 * s + 2], v0[3] = act[8 * s + 3];
+            v1[0] = act[8 * s + 4], v1[1] = act[8 * s + 5], v1[2] = act[8 * s + 6], v1[3] = act[8 * s + 7];
+            uint2 h0, m0, l0, h1, m1, l1;
+            wd3_split4(v0, h0, m0, l0);
+            wd3_split4(v1, h1, m1, l1);
+            bfr[s][0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            bfr[s][1] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+            bfr[s][2] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+    };
+    // one dW tile of a chunk: dw (+ dws) += dZ_chunk[:, 32 it ..]^T act, two steps of 16 rows; `last` runs behind the final read
+    auto dw_tile = [&](const unsigned char *Ab, int it, const uint4 (&bfr)[2][3], f32x16 &dwl, f32x16 &dwsm, auto last) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 ta[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const uint2 lo = wd3_tr(Ab + p * APLANE + tofs(it, s, 0)), hi = wd3_tr(Ab + p * APLANE + tofs(it, s, 1));
+                ta[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+            if (s == 1) last();
+            const wd3_bf16x8 ah = wd3_op(ta[0]), am = wd3_op(ta[1]), al = wd3_op(ta[2]);
+            const wd3_bf16x8 bh = wd3_op(bfr[s][0]), bm = wd3_op(bfr[s][1]), bl = wd3_op(bfr[s][2]);
+            f32x16 d = DW2 ? dwsm : dwl;   // the small products first, the leading one last
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, d, 0, 0, 0);
+            if constexpr (DW2) {
+                dwsm = d;
+                dwl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, dwl, 0, 0, 0);
+            } else {
+                dwl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, d, 0, 0, 0);
+            }
+        }
+    };
 
     // ---- prologue, all eight waves: counters, the constant table, the weight panel ----
     if (tid < 8) ((wd3_flag *)(lds3 + OFF_FLG))[tid] = 0u;
@@ -582,7 +261,8 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
-    f32x16 dw[CT], dws[DW2 ? CT : 1];   // C waves: the leading products' sums and (DW2) the small products' sums
+    f32x16 dw[CTC], dws[DW2 ? CTC : 1];   // dW tiles of this wave (C: tiles 0 .. CTC - 1; SPLITDW: P holds CTC .. CT - 1): the leading
+                                          // products' sums and (DW2) the small products' sums
     double s1 = 0.0, s2 = 0.0;          // C waves
     bool timed_out = false;
 
@@ -620,34 +300,28 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
         unsigned wofs[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) wofs[i] = (unsigned)(rb * 128 + 16 * ((q >> 1) ^ (((rb >> 1) & 1) << 2 | i)) + 8 * (q & 1));
+        if constexpr (SPLITDW) {
+#pragma unroll
+            for (int i = 0; i < CTC; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dw[i][r] = 0.f;
+        }
         unsigned kbase = 0;   // chunks of the strips before this one
         for (; strip < nstrips; strip += stride, kbase += NC) {
             const bool more = strip + stride < nstrips;
             const int snext = strip + stride;
-            // ---- relu(bn(z_{l-1})) of the strip as the dW product's B fragments (eight consecutive accumulator-layout registers are one
-            // 32x32x16 operand), in pieces, written to LDS ahead of chunk 0.  The partner read the previous strip's fragments before it
-            // finished the chunk this wait is for (the one chunk 0's buffer waits for, too) ----
+            // ---- relu(bn(z_{l-1})) of the strip as the dW product's B fragments.  HANDOFF: written to LDS ahead of chunk 0 for the partner
+            // (it read the previous strip's before it finished the chunk this wait is for -- the one chunk 0's buffer waits for, too);
+            // SPLITDW: kept, this wave multiplies with them itself ----
+            uint4 bfr[2][3];
+            act_fragments(zn, bfr);
             {
-                uint4 bfr[2][3];
-                float act[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) act[r] = fmaxf(fmaf(zn[r], e_sc, e_sh), 0.f);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    f32x4 v0, v1;
-                    v0[0] = act[8 * s + 0], v0[1] = act[8 * s + 1], v0[2] = act[8 * s + 2], v0[3] = act[8 * s + 3];
-                    v1[0] = act[8 * s + 4], v1[1] = act[8 * s + 5], v1[2] = act[8 * s + 6], v1[3] = act[8 * s + 7];
-                    uint2 h0, m0, l0, h1, m1, l1;
-                    wd3_split4(v0, h0, m0, l0);
-                    wd3_split4(v1, h1, m1, l1);
-                    bfr[s][0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-                    bfr[s][1] = make_uint4(m0.x, m0.y, m1.x, m1.y);
-                    bfr[s][2] = make_uint4(l0.x, l0.y, l1.x, l1.y);
-                }
                 const __amdgpu_buffer_rsrc_t nP = more ? resP : resNull;
                 const unsigned sn_off = (unsigned)snext * (32u * (unsigned)Nout * 4u);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zn[r] = wd3_load1(nP, oq, sn_off + quni(r));
+            }
+            if constexpr (HANDOFF) {
                 if (kbase >= 2) timed_out = timed_out || !wd3_wait(f_done, kbase - 1);
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
@@ -680,7 +354,7 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
                     }
                     return v;
                 };
-                if constexpr (AM == A_DZ_POOL) {   // the split goes ahead of the wait for the buffer (48 registers the dense form lacks)
+                if constexpr (AM == A_DZ_POOL && !SPLITDW) {   // the split goes ahead of the wait for the buffer (48 registers the other forms lack)
                     uint2 ph[8], pm[8], pl[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) wd3_split4(dz4(i), ph[i], pm[i], pl[i]);
@@ -715,17 +389,23 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
                 }
                 wd3_post(f_ready, kbase + c + 1);
                 WD3_STAMP(2)   // image written and published
+                if constexpr (SPLITDW) {   // this wave's share of dW: the chunks of the second half, from its own image (LDS is in order per wave)
+                    if (c >= NC / 2) {
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) dw_tile(Ab, it, bfr, dw[2 * c + it - CTC], dws[0], [] {});
+                    }
+                }
             }
         }
     } else {
         // =========================== C: both products and the epilogue (matrix work) ===========================
 #pragma unroll
-        for (int i = 0; i < CT; ++i)
+        for (int i = 0; i < CTC; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dw[i][r] = 0.f;
         if constexpr (DW2) {
 #pragma unroll
-            for (int i = 0; i < CT; ++i)
+            for (int i = 0; i < CTC; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dws[i][r] = 0.f;
         }
@@ -736,28 +416,29 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
         const int ax = xs(l31);
         const unsigned char *brow = Wp + l31 * WPITCH;
         const int bx = xw(l31);
-        // transposed reads [c-tile it of the chunk][step s][block b]: rows 16 s + 8 b + 4 lh + qq, columns 32 it + l31.  Two registers
-        // (b = 0, 1): step s adds 16 rows = 2,048 bytes (bit 4 of the row is not in x(r)), c-tile it adds 4 to the group index, which
-        // the XOR with x(r) turns into ^ 64 on the byte offset
-        unsigned tbase[2];
-        {
-            const int gi = lane & 15, qq = gi >> 2, pp = gi & 3, g1 = (lane >> 4) & 1;
+        float zn[16];   // (!HANDOFF) the next strip's z_{l-1}: this wave builds its fragments itself
+        if constexpr (!HANDOFF) {
+            const __amdgpu_buffer_rsrc_t rP = strip < nstrips ? resP : resNull;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int r = 8 * b + 4 * lh + qq, ch = 2 * g1 + (pp >> 1);
-                tbase[b] = (unsigned)(r * 128 + 16 * (ch ^ xs(r)) + 8 * (pp & 1));
-            }
+            for (int r = 0; r < 16; ++r) zn[r] = wd3_load1(rP, oq, (unsigned)strip * (32u * (unsigned)Nout * 4u) + quni(r));
         }
-        auto tofs = [&](int it, int s, int b) -> unsigned { return (tbase[b] ^ (unsigned)(it * 64)) + (unsigned)(s * 2048); };
         unsigned kbase = 0;
         for (; strip < nstrips; strip += stride, kbase += NC) {
             const bool more = strip + stride < nstrips;
-            {
+            uint4 bfr[2][3];   // [step][piece]: relu(bn(z_{l-1})) of the strip (HANDOFF: built by the partner, read behind the wait for chunk 0)
+            if constexpr (HANDOFF) {   // z_{l-1} is only needed in the epilogue: requested now
                 const unsigned sq_off = (unsigned)strip * (32u * (unsigned)Nout * 4u);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zq[r] = wd3_load1(resP, oq, sq_off + quni(r));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zq[r] = zn[r];
+                const __amdgpu_buffer_rsrc_t nP = more ? resP : resNull;
+                const unsigned sn_off = (unsigned)(strip + stride) * (32u * (unsigned)Nout * 4u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zn[r] = wd3_load1(nP, oq, sn_off + quni(r));
+                act_fragments(zq, bfr);
             }
-            uint4 bfr[2][3];   // [step][piece]: relu(bn(z_{l-1})) of the strip, built by the partner (read behind the wait for chunk 0)
             f32x16 acc, accs;   // dA: the leading products and (ACC2) the small ones, added in the epilogue
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -770,11 +451,13 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
             for (int c = 0; c < NC; ++c) {
                 const unsigned char *Ab = Ap + (c & 1) * ABUF;
                 timed_out = timed_out || !wd3_wait(f_ready, kbase + c + 1);
-                if (c == 0) {
+                if constexpr (HANDOFF) {
+                    if (c == 0) {
 #pragma unroll
-                    for (int s = 0; s < 2; ++s)
+                        for (int s = 0; s < 2; ++s)
 #pragma unroll
-                        for (int p3 = 0; p3 < 3; ++p3) bfr[s][p3] = Bf[(s * 3 + p3) * 64];
+                            for (int p3 = 0; p3 < 3; ++p3) bfr[s][p3] = Bf[(s * 3 + p3) * 64];
+                    }
                 }
                 WD3_STAMP(4)   // wait for the chunk
                 // ---- dA += dZ_chunk W_chunk: step t covers k = 64 c + 16 t + 8 lh + (0 .. 7) ----
@@ -803,33 +486,15 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
                     }
                 }
                 WD3_STAMP(5)   // dA product of the chunk
-                // ---- dW[64 c + 32 it + .][n] += dZ_chunk^T act: two steps of 16 rows ----
-#pragma unroll
-                for (int it = 0; it < 2; ++it)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        uint4 ta[3];
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) {
-                            const uint2 lo = wd3_tr(Ab + p * APLANE + tofs(it, s, 0)), hi = wd3_tr(Ab + p * APLANE + tofs(it, s, 1));
-                            ta[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                        }
-                        if (it == 1 && s == 1) wd3_post(f_done, kbase + c + 1);   // the last reads of this buffer have landed
-                        const wd3_bf16x8 ah = wd3_op(ta[0]), am = wd3_op(ta[1]), al = wd3_op(ta[2]);
-                        const wd3_bf16x8 bh = wd3_op(bfr[s][0]), bm = wd3_op(bfr[s][1]), bl = wd3_op(bfr[s][2]);
-                        f32x16 d = DW2 ? dws[DW2 ? 2 * c + it : 0] : dw[2 * c + it];
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, d, 0, 0, 0);
-                        if constexpr (DW2) {
-                            dws[DW2 ? 2 * c + it : 0] = d;
-                            dw[2 * c + it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, dw[2 * c + it], 0, 0, 0);
-                        } else {
-                            dw[2 * c + it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, d, 0, 0, 0);
-                        }
-                    }
+                // ---- dW[64 c + 32 it + .][n] += dZ_chunk^T act (SPLITDW: the chunks of the first half; the partner has the others); the
+                // buffer is released behind this wave's last read of it ----
+                if (!SPLITDW || c < NC / 2) {
+                    dw_tile(Ab, 0, bfr, dw[2 * c < CTC ? 2 * c : 0], dws[DW2 ? (2 * c < CTC ? 2 * c : 0) : 0], [] {});
+                    dw_tile(Ab, 1, bfr, dw[2 * c + 1 < CTC ? 2 * c + 1 : 0], dws[DW2 ? (2 * c + 1 < CTC ? 2 * c + 1 : 0) : 0],
+                            [&] { wd3_post(f_done, kbase + c + 1); });
+                } else {
+                    wd3_post(f_done, kbase + c + 1);   // (behind the dA product's reads: wd3_post waits for them)
+                }
                 WD3_STAMP(6)   // transposed reads + dW products of the chunk
             }
             // ---- epilogue: mask, store, BatchNorm-backward sums of layer l-1 ----
@@ -857,20 +522,23 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
 #endif
     if (timed_out && lane == 0) atomicExch(&g_wsd3_timeouts, 1);
 
-    // ---- tails: one dW partial per workgroup (the four C waves' tiles added through LDS), the column statistics ----
+    // ---- tails: one dW partial per workgroup (every tile's four copies -- one per pair -- added through LDS), the column statistics ----
     __syncthreads();   // every wave is done with the panel and the images
-    f32x4 *red = reinterpret_cast<f32x4 *>(lds3);                          // [tile][C wave][r4][lane]
-    double *dred = reinterpret_cast<double *>(lds3 + CT * 4 * 4 * 64 * 16);   // [C wave][2][BN]
-    if (!producer) {
+    f32x4 *red = reinterpret_cast<f32x4 *>(lds3);                          // [tile][pair][r4][lane]
+    double *dred = reinterpret_cast<double *>(lds3 + CT * 4 * 4 * 64 * 16);   // [pair][2][BN]
+    if (!producer || SPLITDW) {   // C: tiles 0 .. CTC - 1; P (SPLITDW): tiles CTC .. CT - 1
+        const int t0 = producer ? CTC : 0;
 #pragma unroll
-        for (int i = 0; i < CT; ++i)
+        for (int i = 0; i < CTC; ++i)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = DW2 ? dw[i][4 * r4 + e] + dws[DW2 ? i : 0][4 * r4 + e] : dw[i][4 * r4 + e];
-                red[((i * 4 + pair) * 4 + r4) * 64 + lane] = v;
+                red[(((t0 + i) * 4 + pair) * 4 + r4) * 64 + lane] = v;
             }
+    }
+    if (!producer) {
         const double a = s1 + shfl_xor_f64(s1, 32), b = s2 + shfl_xor_f64(s2, 32);
         if (lh == 0) dred[(pair * 2 + 0) * BN + l31] = a, dred[(pair * 2 + 1) * BN + l31] = b;
     }
@@ -898,20 +566,14 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
 }
 
 template <int KD, int BN, int AM>
-static auto wsd3_kernel_of() {   // K = 256: form A; K = 128: form B (only the forms that are launched are instantiated)
-    if constexpr (KD == 256) return gemm_wsd3a_kernel<KD, BN>;
-    else return gemm_wsd3_kernel<KD, BN, AM>;
-}
-
-template <int KD, int BN, int AM>
 static void wsd3_launch(const AOperand &A, const BOperand &B, int M, int Nout, const Epilogue &E, int workers, int ncol, hipStream_t st) {
-    // (a first version of form B sized this by hand and forgot the fragments: its counters lay behind the end of the allocation, LDS
+    // (a first version with the hand-off sized this by hand and forgot the fragments: its counters lay behind the end of the allocation, LDS
     //  drops such writes without a fault, and every poll ran into its bound)
-    constexpr size_t main_b = Wsd3Lds<KD, BN, KD != 256>::END;
+    constexpr size_t main_b = Wsd3Lds<KD, BN, KD != 256>::END;   // (the hand-off area exists for K = 128 only)
     constexpr size_t red_b = (size_t)(KD / 32) * (BN / 32) * 4 * 4 * 64 * 16 + (size_t)4 * 2 * BN * 8;
     constexpr size_t lds = main_b > red_b ? main_b : red_b;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kfn = wsd3_kernel_of<KD, BN, AM>();
+    auto kfn = gemm_wsd3_kernel<KD, BN, AM>;
     static bool granted = false;
     if (!granted) {
         (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

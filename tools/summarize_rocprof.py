@@ -54,12 +54,9 @@ def tag_of(name, gx, gy, wg):
     m = re.search(r"gemm_wsf3_kernel<(\d+), \d+, (\d+), (\d+)>", name)
     if m:
         return f"gemm_wsf3_kernel<{m.group(1)},A{m.group(2)},E{m.group(3)}> {g}"
-    m = re.search(r"gemm_wsd3_kernel<(\d+), (\d+), (\d+)>", name)   # form B (K = 128): <K, BN, A mode>
+    m = re.search(r"gemm_wsd3_kernel<(\d+), (\d+), (\d+)>", name)   # <K, BN, A mode>
     if m:
         return f"gemm_wsd3_kernel<{m.group(1)},{m.group(2)},A{m.group(3)}> {g}"
-    m = re.search(r"gemm_wsd3a_kernel<(\d+), (\d+)>", name)          # form A (K = 256, pooled gradient): same launch tag family
-    if m:
-        return f"gemm_wsd3_kernel<{m.group(1)},{m.group(2)},A5> {g}"
     m = re.search(r"gemm_wsf0_kernel<(\d+)>", name)
     if m:
         return f"gemm_wsf0_kernel<E{m.group(1)}> {g}"

@@ -21,13 +21,11 @@ N = 20
 for _ in range(N): step()
 buf = (ctypes.c_ulonglong * 32)()
 lib.pnpp_debug_wsd3_stamps(buf, 0)
-# form A (K = 256, SA2): the producer also multiplies (dA) and runs the epilogue
-pnA = ["constants + tables", "wait for the buffer (partner)", "staging: dZ, split, LDS writes", "publish + next strip's loads issued", "dA products", "epilogue"]
-cnA = ["activation fragments / turn-around", "wait for the chunk (partner)", "transposed reads + dW products"]
-# form B (K = 128, SA1): the producer only builds the image, the consumer does both products and the epilogue (phases 3 .. 7 of its row)
+# the producer builds the image (K = 256: and multiplies its share of dW behind `image written`, which lands in the next chunk's first
+# phase), the consumer does the products and the epilogue (phases 3 .. 7 of its row)
 pnB = ["dZ and its pieces (incl. the wait for the operands)", "wait for the buffer (partner)", "image written and published"]
 cnB = [None, None, None, "activation fragments", "wait for the chunk (partner)", "dA products", "transposed reads + dW products", "epilogue"]
-for k, tag, pn, cn in ((0, "<128,32> sa1 last layer (form B)", pnB, cnB), (1, "<256,32> sa2 last layer (form A)", pnA, cnA)):
+for k, tag, pn, cn in ((0, "<128,32> sa1 last layer + sa2 middle layer", pnB, cnB), (1, "<256,32> sa2 last layer (dW split between the waves)", pnB, cnB)):
     for role, names in ((0, pn), (1, cn)):
         row = [buf[(k * 2 + role) * 8 + i] for i in range(len(names))]
         tot = sum(r for r, n in zip(row, names) if n)
