@@ -11,7 +11,8 @@ and exits with its code (never an exec of a process that has touched the GPU).  
 
 One step = zero_grad + forward (device-side centre sampling, kNN grouping, fused MLP, head) + single-peak
 von-Mises KL + backward + [one flat-gradient all-reduce when N > 1] + fused Adam, on a batch of B=32 synthetic
-clouds per GPU that is already resident in HBM.  float32 end to end (exact-f32 MFMA), weak scaling.
+clouds per GPU that is already resident in HBM.  float32 end to end (the large products as six exact bf16 x bf16 partial products of
+three-way operand splits, float32 accumulate: --f32-products; `f32_mfma_variant` = the same step on v_mfma_f32_32x32x2_f32), weak scaling.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      -- the kernel that took the most time: achieved rate from HIP events recorded by the library
