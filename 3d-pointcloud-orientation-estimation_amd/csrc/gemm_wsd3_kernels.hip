@@ -19,19 +19,20 @@
 // published) and `done` (chunks C has finished reading).  P writes chunk k into buffer k & 1 once done >= k - 1; C reads it once
 // ready >= k + 1.  LDS operations of one wave complete in order and the counters only grow, so there is no cycle to wait in; the
 // polls are bounded all the same (a poll that gave up sets g_wsd3_timeouts and goes on: wrong numbers, never a hang; the tests check
-// the mark).  Every workgroup owns 32 output columns, so that dW (K x 32) is 64 registers per wave.
+// the mark).  Every workgroup owns 32 output columns: a wave's share of dW is 32 or 64 registers.
 //   P builds the image -- streams Z (and dY) one strip ahead, computes dZ (one compare + select + FMA per element), splits it, writes
 //     it: vector work and memory;
 //   C multiplies: dA from the image rows x the weight panel (small products in an accumulator of their own), dW with the activation
 //     operand relu(bn(z_{l-1})) as eight consecutive accumulator-layout registers per 32x32x16 operand and the dZ operand from the SAME
 //     image read transposed (ds_read_b64_tr_b16, rows in the accumulator layout's order: no second image), then mask, store, sums.
-//   K = 128 (SA1's last layer 128 -> 64, SA2's middle layer 128 -> 128): dW is 128 x 32 = 64 registers in C (and a second set for its
-//     small products); P also builds the strip's activation fragments and hands them to C through LDS.  Stamps: C is the critical
-//     path (dA 33 %, dW 26 %, fragments / turn-around 20 %), P waits 23 %.
-//   K = 256 (SA2's last layer 256 -> 128): dW is 128 registers -- the tiles of the chunks' second half live in P, which multiplies its
-//     own image for them (48 of a strip's 192 MFMAs); no LDS is left for the hand-off, both waves build the
-//     activation fragments.  Stamps: P 54 k ticks, C 57 k per launch -- balanced.  (A first arrangement for K = 256 had P multiply dA
-//     and run the epilogue and C hold all of dW: P was the critical path, C waited 48 %: 37.4 against 34.6 us on one box.)
+//   dW is split between the two waves: the tiles of a strip's first chunks accumulate in C, those of its second half in P, which
+//     multiplies its own image for them behind publishing it (a quarter of the strip's MFMAs; LDS is in order per wave) -- at K = 256
+//     because all of dW (128 registers) does not fit beside the dA tile, at K = 128 for balance (+0.9 % on the step, one box).
+//   K = 128 (SA1's last layer 128 -> 64, SA2's middle layer 128 -> 128): P also builds the strip's activation fragments for C and hands
+//     them over through LDS; a second accumulator set for dW's small products where the pooled-gradient form has the registers.
+//   K = 256 (SA2's last layer 256 -> 128): no LDS is left for the hand-off, both waves build the activation fragments.  Stamps: P 54 k
+//     ticks, C 57 k per launch -- balanced.  (A first arrangement for K = 256 had P multiply dA and run the epilogue and C hold all of
+//     dW: P was the critical path, C waited 48 %: 37.4 against 34.6 us on one box.)
 // Image layout: 16-byte group g of row r at g ^ x(r), x(r) = 4 bit1(r) + bits3:2(r): conflict-free for the row reads (the four
 // 16-lane groups of a ds_read_b128 see eight different x per row parity) and for the transposed reads (rows r and r + 2 of a block
 // differ in x's bit 2).  Addresses: ONE lane-offset register per stream, everything uniform in the instructions' scalar offsets -- a
@@ -124,11 +125,12 @@ __global__ void __launch_bounds__(512, 1)
 gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, int Nout, int ncol, const Epilogue E) {
     constexpr int NC = KD / 64, CT = KD / 32;
     static_assert(BN == 32, "one column tile per workgroup: the consumer wave holds dW (KD x 32) and the dA tile");
-    constexpr bool SPLITDW = CT > 4;                         // K = 256: the dW tiles of the chunks' second half live in the PRODUCER wave
+    constexpr bool SPLITDW = true;                           // the dW tiles of the chunks' second half live in the PRODUCER wave, which multiplies
+                                                             // its own image for them (K = 256: dW would not fit one wave; K = 128: balance)
     constexpr int CTC = SPLITDW ? CT / 2 : CT;               // dW tiles (of 32 channels) the consumer wave holds
-    constexpr bool HANDOFF = !SPLITDW;                       // the producer hands the activation fragments over through LDS (K = 256: no LDS
-                                                             // left for them -- and the producer needs them itself: both waves build them)
-    constexpr bool DW2 = !SPLITDW;                           // a second dW accumulator set (the small products): where dW is 64 registers
+    constexpr bool HANDOFF = KD == 128;                      // the producer hands the activation fragments over through LDS (K = 256: no LDS
+                                                             // left for them: both waves build them)
+    constexpr bool DW2 = KD == 128 && AM == A_DZ_POOL;      // a second dW accumulator set (the small products): where registers allow
     constexpr bool ACC2 = true;                              // a second dA accumulator (the small products)
     constexpr int WPITCH = KD * 2, WPLANE = BN * WPITCH;     // bytes: row and plane of the weight panel [n][k]
     constexpr int APLANE = 32 * 128, ABUF = 3 * APLANE;      // bytes: plane and buffer (three planes) of a dZ chunk image
@@ -305,6 +307,12 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
             for (int i = 0; i < CTC; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dw[i][r] = 0.f;
+            if constexpr (DW2) {
+#pragma unroll
+                for (int i = 0; i < CTC; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dws[i][r] = 0.f;
+            }
         }
         unsigned kbase = 0;   // chunks of the strips before this one
         for (; strip < nstrips; strip += stride, kbase += NC) {
@@ -392,7 +400,7 @@ gemm_wsd3_kernel(const AOperand A, const float *__restrict__ W, int ldw, int M, 
                 if constexpr (SPLITDW) {   // this wave's share of dW: the chunks of the second half, from its own image (LDS is in order per wave)
                     if (c >= NC / 2) {
 #pragma unroll
-                        for (int it = 0; it < 2; ++it) dw_tile(Ab, it, bfr, dw[2 * c + it - CTC], dws[0], [] {});
+                        for (int it = 0; it < 2; ++it) dw_tile(Ab, it, bfr, dw[2 * c + it - CTC], dws[DW2 ? 2 * c + it - CTC : 0], [] {});
                     }
                 }
             }
