@@ -76,19 +76,28 @@ def main():
     loss = lambda m, b: ops.vm_head_kl_loss(m.features(b[0]), b[1][:, 0].contiguous(), b[1][:, 1].contiguous(), reduction="none")
     hist, best, best_ep = trainer.fit(model, loss, loaders, args.epochs, 1e-3, dev, label="von Mises KL", log=lambda *_: None)
     model.eval()
-    errs, kaps = [], []
-    with torch.no_grad():
-        for i in range(0, 1024, args.batch):
-            mu, kappa = model(xyz_va[i:i + args.batch].to(dev))
-            errs.append(ang_err_deg(mu.cpu(), mu_va[i:i + args.batch]))
-            kaps.append(kappa.cpu())
-    e, k = torch.cat(errs), torch.cat(kaps)
+
+    def held_out():
+        errs, kaps = [], []
+        with torch.no_grad():
+            for i in range(0, 1024, args.batch):
+                mu, kappa = model(xyz_va[i:i + args.batch].to(dev))
+                errs.append(ang_err_deg(mu.cpu(), mu_va[i:i + args.batch]))
+                kaps.append(kappa.cpu())
+        return torch.cat(errs), torch.cat(kaps)
+
+    e, k = held_out()                 # the LAST epoch's model (its validation KL swings from epoch to epoch at this learning rate)
+    model.load_state_dict(best)       # the checkpoint of the best validation epoch (trainer.fit keeps a copy)
+    eb, kb = held_out()
     out["runs"]["single_peak_vonMises_KL"] = {
         "train_kl": [round(v, 4) for v in hist["train"]], "val_kl": [round(v, 4) for v in hist["val"]], "best_val_epoch": best_ep,
         "steps": hist["steps"], "train_seconds_per_epoch": round(sum(hist["seconds"]["train"]) / args.epochs, 3),
         "held_out_angular_error_deg": {"mean": round(float(e.mean()), 2), "median": round(float(e.median()), 2),
                                        "p90": round(float(e.kthvalue(int(0.9 * len(e))).values), 2)},
-        "held_out_mean_kappa": round(float(k.mean()), 2)}
+        "held_out_mean_kappa": round(float(k.mean()), 2),
+        "best_checkpoint": {"held_out_angular_error_deg": {"mean": round(float(eb.mean()), 2), "median": round(float(eb.median()), 2),
+                                                           "p90": round(float(eb.kthvalue(int(0.9 * len(eb))).values), 2)},
+                            "held_out_mean_kappa": round(float(kb.mean()), 2)}}
 
     # --- 8-direction soft-label cross entropy (train_8dir_KL.py's loss) ---
     torch.manual_seed(42)
@@ -98,17 +107,25 @@ def main():
     loaders = {"train": trainer.SyntheticLoader([xyz_tr, p_tr], args.batch, True, dev),
                "val": trainer.SyntheticLoader([xyz_va, p_va], args.batch, False, dev)}
     loss8 = lambda m, b: ops.soft_ce(m(b[0]), b[1])
-    hist8, _, best8 = trainer.fit(model8, loss8, loaders, args.epochs, 1e-3, dev, label="8-dir soft CE", log=lambda *_: None)
+    hist8, state8, best8 = trainer.fit(model8, loss8, loaders, args.epochs, 1e-3, dev, label="8-dir soft CE", log=lambda *_: None)
     model8.eval()
-    hit = 0
-    with torch.no_grad():
-        for i in range(0, 1024, args.batch):
-            logits = model8(xyz_va[i:i + args.batch].to(dev)).cpu()
-            hit += int((logits.argmax(1) == p_va[i:i + args.batch].argmax(1)).sum())
+
+    def top1():
+        hit = 0
+        with torch.no_grad():
+            for i in range(0, 1024, args.batch):
+                logits = model8(xyz_va[i:i + args.batch].to(dev)).cpu()
+                hit += int((logits.argmax(1) == p_va[i:i + args.batch].argmax(1)).sum())
+        return hit
+
+    hit = top1()
+    model8.load_state_dict(state8)
+    hit_best = top1()
     ent = float(-(p_va * torch.log(p_va.clamp_min(1e-12))).sum(1).mean())     # the soft labels' own entropy: the loss floor
     out["runs"]["8dir_soft_CE"] = {"train_ce": [round(v, 4) for v in hist8["train"]], "val_ce": [round(v, 4) for v in hist8["val"]],
                                    "best_val_epoch": best8, "label_entropy_floor": round(ent, 4),
-                                   "held_out_top1_direction_accuracy": round(hit / 1024, 4)}
+                                   "held_out_top1_direction_accuracy": round(hit / 1024, 4),
+                                   "best_checkpoint": {"held_out_top1_direction_accuracy": round(hit_best / 1024, 4)}}
     print(json.dumps(out))
 
 
