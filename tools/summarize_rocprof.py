@@ -51,7 +51,7 @@ def tag_of(name, gx, gy, wg):
     if m:
         return f"gemm_wsf_kernel<{m.group(1)},{m.group(2)},A{m.group(3)},E{m.group(4)}> {g}"
     # round 4: the split-product kernels (bench.py tags: gemm_wsf3_kernel<K,Aa,Ee>, gemm_wsd3_kernel<K,BN,Aa>)
-    m = re.search(r"gemm_wsf3_kernel<(\d+), \d+, (\d+), (\d+)>", name)
+    m = re.search(r"gemm_wsf3_kernel<(\d+), \d+, \d+, (\d+), (\d+)>", name)   # <K, waves, column tiles per wave, A mode, E mode>
     if m:
         return f"gemm_wsf3_kernel<{m.group(1)},A{m.group(2)},E{m.group(3)}> {g}"
     m = re.search(r"gemm_wsd3_kernel<(\d+), (\d+), (\d+)>", name)   # <K, BN, A mode>
