@@ -355,6 +355,200 @@ __global__ void __launch_bounds__(256) da_dw_mid_kernel(const MidGemm G, int til
     }
 }
 
+// ---- the forward product with split products (gemm_wsf3_kernels.hip has the arithmetic): 64 x 64 output tile, eight waves ---------
+// Waves 0-3 multiply (one 32 x 32 accumulator each, the leading products and the small ones apart), waves 4-7 -- one per SIMD beside
+// them -- stage: they stream the next 64-deep chunks of BOTH operands (a' rows and W rows: the weights are not stationary here), apply
+// BatchNorm + ReLU to a', split every element into its three bf16 pieces and write the chunk images ([64 rows][64 k], three planes,
+// 128-byte rows, 16-byte groups at g ^ x(r) as in gemm_wsd3_kernels.hip) of the OTHER stage while the multipliers work on this one.  The
+// vector work of the split (about as many cycles as the 24 bf16 MFMAs of a chunk) overlaps with the matrix work because it comes from
+// another wave; one s_barrier per chunk (no workgroup fence: the stagers' loads stay in flight across it).
+constexpr int MID3_PLANE = MID_T * 128, MID3_IMG = 3 * MID3_PLANE, MID3_STAGE = 2 * MID3_IMG;   // bytes: plane, image (A or W), stage
+constexpr size_t MID3_LDS_BYTES = (size_t)2 * MID3_STAGE;                                    // two stages: 98,304 bytes
+
+typedef __bf16 mid3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mid3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mid3_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned mid3_pk(float lo, float hi) {
+    const mid3_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mid3_bf16x2));
+}
+__device__ __forceinline__ void mid3_split4(const f32x4 v, uint2 &h, uint2 &m, uint2 &l) {
+    h.x = mid3_pk(v[0], v[1]), h.y = mid3_pk(v[2], v[3]);
+    float r0 = v[0] - __uint_as_float(h.x << 16), r1 = v[1] - __uint_as_float(h.x & 0xffff0000u);
+    float r2 = v[2] - __uint_as_float(h.y << 16), r3 = v[3] - __uint_as_float(h.y & 0xffff0000u);
+    m.x = mid3_pk(r0, r1), m.y = mid3_pk(r2, r3);
+    r0 -= __uint_as_float(m.x << 16), r1 -= __uint_as_float(m.x & 0xffff0000u), r2 -= __uint_as_float(m.y << 16), r3 -= __uint_as_float(m.y & 0xffff0000u);
+    l.x = mid3_pk(r0, r1), l.y = mid3_pk(r2, r3);
+}
+__device__ __forceinline__ mid3_bf16x8 mid3_op(uint4 v) { return __builtin_bit_cast(mid3_bf16x8, v); }
+__device__ __forceinline__ void mid3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // LDS only: no vmcnt wait
+
+template <int AX, int EM>
+__global__ void __launch_bounds__(512, 1) gemm_mid3_kernel(const MidGemm G, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    int tm, tn;
+    mid_tile_map(blockIdx.x, G.M / MID_T, tiles_n, tm, tn);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int m0 = tm * MID_T, n0 = tn * MID_T, nc = G.K / MID_T;
+    const Epilogue &E = G.E;
+    auto xs = [](int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); };   // group XOR of image row r (bits 1-3 of r)
+    const bool stager = wave >= 4;
+    const int wm = (wave >> 1) & 1, wn = wave & 1;   // multipliers: the wave's 32 x 32 tile
+    f32x16 acc, accs;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f, accs[r] = 0.f;
+
+    if (stager) {
+        const int t2 = tid - 256, q = t2 & 15, q4 = 4 * q, rb = t2 >> 4;   // k group 4 q .. + 3 of the chunk, rows rb + 16 i
+        const __amdgpu_buffer_rsrc_t resA = mid_rsrc(G.a + (size_t)m0 * G.lda), resW = mid_rsrc(G.b + (size_t)n0 * G.ldb);
+        const unsigned oa = 4u * ((unsigned)rb * (unsigned)G.lda + (unsigned)q4), ow = 4u * ((unsigned)rb * (unsigned)G.ldb + (unsigned)q4);
+        const unsigned wofs = (unsigned)(rb * 128 + 16 * ((q >> 1) ^ xs(rb)) + 8 * (q & 1));   // row rb + 16 i: + 2048 i (x ignores bit 4)
+        // four register sets, by chunk index mod 4, named apart (a set indexed by c & 3 would live in private memory): a chunk is requested
+        // four chunk times before it is staged -- with two sets the loop ran at the L2 round trip per chunk (13.8 us for 8 chunks)
+        f32x4 ra0[4], rw0[4], ra1[4], rw1[4], ra2[4], rw2[4], ra3[4], rw3[4];
+        f32x4 sc0, sh0, sc1, sh1, sc2, sh2, sc3, sh3;
+        auto gload = [&](int c, f32x4 (&ra)[4], f32x4 (&rw)[4], f32x4 &sc, f32x4 &sh) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = mid_load4(resA, oa, (unsigned)c * 256u + (unsigned)i * (64u * (unsigned)G.lda));
+                rw[i] = mid_load4(resW, ow, (unsigned)c * 256u + (unsigned)i * (64u * (unsigned)G.ldb));
+            }
+            if constexpr (AX == A_BNRELU) {
+                sc = *reinterpret_cast<const f32x4 *>(G.scale + c * MID_T + q4);
+                sh = *reinterpret_cast<const f32x4 *>(G.shift + c * MID_T + q4);
+            }
+        };
+        auto lstore = [&](int stage, const f32x4 (&ra)[4], const f32x4 (&rw)[4], const f32x4 &sc, const f32x4 &sh) {
+            unsigned char *As = lds3 + stage * MID3_STAGE, *Ws = As + MID3_IMG;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = ra[i];
+                if constexpr (AX == A_BNRELU) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = fmaxf(fmaf(v[u], sc[u], sh[u]), 0.f);
+                }
+                uint2 h, m, l;
+                mid3_split4(v, h, m, l);
+                unsigned char *d = As + wofs + i * 2048;
+                *reinterpret_cast<uint2 *>(d) = h, *reinterpret_cast<uint2 *>(d + MID3_PLANE) = m, *reinterpret_cast<uint2 *>(d + 2 * MID3_PLANE) = l;
+                mid3_split4(rw[i], h, m, l);
+                d = Ws + wofs + i * 2048;
+                *reinterpret_cast<uint2 *>(d) = h, *reinterpret_cast<uint2 *>(d + MID3_PLANE) = m, *reinterpret_cast<uint2 *>(d + 2 * MID3_PLANE) = l;
+            }
+        };
+        gload(0, ra0, rw0, sc0, sh0);
+        gload(1, ra1, rw1, sc1, sh1);
+        gload(2, ra2, rw2, sc2, sh2);
+        gload(3, ra3, rw3, sc3, sh3);
+        lstore(0, ra0, rw0, sc0, sh0);
+        gload(4, ra0, rw0, sc0, sh0);   // K / 64 is a multiple of 4 and at least 8
+        mid3_barrier();   // stage 0 is complete
+        // Four chunks per pass.  The multipliers are on chunk c (stage 0): the other stage, which they left at the previous barrier, takes
+        // chunk c + 1, and so on.  The last two passes are written out apart so that no request sits behind a branch: the compiler counts
+        // outstanding loads per path, and a conditional request in the loop made every wait behind it a wait for ALL loads.
+        auto pass = [&](const int c, const bool more, const bool more8) __attribute__((always_inline)) {
+            lstore(1, ra1, rw1, sc1, sh1);
+            if (more) gload(c + 5, ra1, rw1, sc1, sh1);
+            mid3_barrier();
+            lstore(0, ra2, rw2, sc2, sh2);
+            if (more) gload(c + 6, ra2, rw2, sc2, sh2);
+            mid3_barrier();
+            lstore(1, ra3, rw3, sc3, sh3);
+            if (more) gload(c + 7, ra3, rw3, sc3, sh3);
+            mid3_barrier();
+            if (more) lstore(0, ra0, rw0, sc0, sh0);
+            if (more8) gload(c + 8, ra0, rw0, sc0, sh0);
+            mid3_barrier();
+        };
+        for (int c = 0; c + 8 < nc; c += 4) pass(c, true, true);
+        pass(nc - 8, true, false);
+        pass(nc - 4, false, false);
+    } else {
+        const unsigned arow = (unsigned)((wm * 32 + l31) * 128), brow = (unsigned)((wn * 32 + l31) * 128);
+        const int ax = xs(l31);   // rows 32 wm + l31 and 32 wn + l31: x ignores bits 4, 5
+        mid3_barrier();   // stage 0 is complete
+        for (int c = 0; c < nc; ++c) {
+            const unsigned char *As = lds3 + (c & 1) * MID3_STAGE, *Ws = As + MID3_IMG;
+            uint4 fa[2][3], fb[2][3];
+            auto ld = [&](int buf, int t) {
+                const int g = (2 * t + lh) ^ ax;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    fa[buf][p] = *reinterpret_cast<const uint4 *>(As + p * MID3_PLANE + arow + 16 * g);
+                    fb[buf][p] = *reinterpret_cast<const uint4 *>(Ws + p * MID3_PLANE + brow + 16 * g);
+                }
+            };
+            auto mm = [&](int buf) {
+                const mid3_bf16x8 ah = mid3_op(fa[buf][0]), am = mid3_op(fa[buf][1]), al = mid3_op(fa[buf][2]);
+                const mid3_bf16x8 bh = mid3_op(fb[buf][0]), bm = mid3_op(fb[buf][1]), bl = mid3_op(fb[buf][2]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, accs, 0, 0, 0);
+                accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, accs, 0, 0, 0);
+                accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, accs, 0, 0, 0);
+                accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, accs, 0, 0, 0);
+                accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, accs, 0, 0, 0);
+            };
+            ld(0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; t += 2) {
+                ld(1, t + 1);
+                mm(0);
+                if (t + 2 < 4) ld(0, t + 2);
+                mm(1);
+            }
+            mid3_barrier();
+        }
+    }
+
+    // ---- epilogue (multiplier waves; the column sums need two more workgroup barriers, which every wave takes) ----
+    const int col = n0 + wn * 32 + l31;
+    float t1 = 0.f, t2 = 0.f;
+    if (!stager) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += accs[r];
+        if constexpr (EM == E_STORE_STATS) {
+            if (E.pool_ext) {   // (uniform) 32-row neighbourhoods: this wave's 32 x 32 tile is one of them -- its extreme row per column
+                const float sg = (E.pool_gamma ? E.pool_gamma[col] : 1.f) >= 0.f ? 1.f : -1.f;
+                float mx = sg * acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sg * acc[r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                int a = 64;
+#pragma unroll
+                for (int r = 15; r >= 0; --r) a = (sg * acc[r] == mx) ? (r & 3) + 8 * (r >> 2) + 4 * lh : a;
+                a = min(a, __shfl_xor(a, 32, 64));
+                if (lh == 0) {
+                    const size_t gi = (size_t)((m0 + wm * 32) >> 5) * E.ldc + col;
+                    E.pool_ext[gi] = sg * mx;
+                    E.pool_arg[gi] = a;
+                }
+            }
+        }
+        float *tb = E.c + (size_t)(m0 + wm * 32 + 4 * lh) * E.ldc + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r];
+            t1 += v;
+            t2 = fmaf(v, v, t2);
+            tb[(size_t)((r & 3) + 8 * (r >> 2)) * E.ldc] = v;
+        }
+    }
+    if constexpr (EM == E_STORE_STATS) {
+        __syncthreads();                                  // every operand read of the last chunk is done
+        double *red = reinterpret_cast<double *>(lds3);   // [2 wm][2][64]
+        if (!stager) {
+            const double a = (double)t1 + shfl_xor_f64((double)t1, 32), b = (double)t2 + shfl_xor_f64((double)t2, 32);
+            if (lh == 0) red[(wm * 2 + 0) * MID_T + wn * 32 + l31] = a, red[(wm * 2 + 1) * MID_T + wn * 32 + l31] = b;
+        }
+        __syncthreads();
+        if (tid < 2 * MID_T) {
+            const int which = tid >> 6, cl = tid & 63;
+            E.slab[((size_t)tm * 2 + which) * G.N + n0 + cl] = red[(0 * 2 + which) * MID_T + cl] + red[(1 * 2 + which) * MID_T + cl];
+        }
+    }
+}
+
 static bool mid_ptr_ok(const float *p, int ld) { return p && (ld & 3) == 0 && ((uintptr_t)p & 15) == 0; }
 
 template <typename K>
@@ -387,6 +581,28 @@ bool try_launch_mid_gemm(const AOperand &A, const BOperand &B, int M, int Nout, 
     MidGemm G{A.a, A.lda, A.scale, A.shift, B.b, B.ldb, M, Nout, Kd, E};
     if (nslab) *nslab = M / MID_T;
     const int tn = Nout / MID_T, grid = (M / MID_T) * tn;
+    static const bool mid3_on = !(getenv("PNPP_MID3") && atoi(getenv("PNPP_MID3")) == 0);   // PNPP_MID3=0: the float32-MFMA tile kernel (A/B runs)
+    if (mid3_on && split_products() && matmul_precision() == 0 && E.mode == E_STORE_STATS && Kd >= 512 && (Kd & 255) == 0 && (unsigned long long)M * (unsigned)A.lda * 4ull < 0x7ffffff0ull &&
+        (unsigned long long)Nout * (unsigned)B.ldb * 4ull < 0x7ffffff0ull) {   // float32 products from exact bf16 splits (the default)
+        ProfScope ps(st, "gemm_mid3_kernel<A%d,E%d> M=%d N=%d K=%d grid=%d", A.mode, E.mode, M, Nout, Kd, grid);
+#define PNPP_MID3(AX, EMV)                                                                                                       \
+    {                                                                                                                            \
+        static bool granted = false;                                                                                             \
+        if (!granted) {                                                                                                          \
+            (void)hipFuncSetAttribute((const void *)gemm_mid3_kernel<AX, EMV>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                      (int)MID3_LDS_BYTES);                                                                      \
+            granted = true;                                                                                                      \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((gemm_mid3_kernel<AX, EMV>), dim3(grid), dim3(512), MID3_LDS_BYTES, st, G, tn);                       \
+    }
+        if (A.mode == A_BNRELU) PNPP_MID3(A_BNRELU, E_STORE_STATS) else PNPP_MID3(A_PLAIN, E_STORE_STATS)
+#undef PNPP_MID3
+        if (hipGetLastError() != hipSuccess) {
+            set_error("gemm_mid3: launch failed");
+            *rc = PNPP_ERR_LAUNCH;
+        }
+        return true;
+    }
     ProfScope ps(st, "gemm_mid_kernel<A%d,E%d,T1> M=%d N=%d K=%d grid=%d", A.mode, E.mode, M, Nout, Kd, grid);
 #define PNPP_MID(AX, EMV)                                                                              \
     {                                                                                                  \
