@@ -41,7 +41,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: BF16 dense (the opt-in bf16-operand variant's kernels)
 # float32 products formed as six exact bf16 x bf16 partial products (csrc/gemm_wsf3_kernels.hip): float32-equivalent FLOP/s of the bf16 pipe
 MFMA_SPLIT_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
-SPLIT_KERNELS = ("gemm_wsf3_kernel", "gemm_wsd3_kernel")
+SPLIT_KERNELS = ("gemm_wsf3_kernel", "gemm_wsd3_kernel", "gemm_mid3_kernel")
 FLOPS_PER_CLOUD = 0.8542e9     # 3 x 2 x 142,369,280 MAC, forward + backward, independent of N
 BYTES_PER_CLOUD = 34.6e6       # 5 E + 3 G float32 words + xyz / indices
 
@@ -404,7 +404,7 @@ def kernel_cost(tag: str):
     M, N, K = mnk
     flops = 2.0 * M * N * K
     if tag.startswith(("gemm_kernel", "gemm_ws_kernel", "gemm_wsb_kernel", "gemm_wsf_kernel", "gemm_wsf3_kernel", "gemm_smallm_kernel",
-                       "gemm_mid_kernel")):
+                       "gemm_mid_kernel", "gemm_mid3_kernel")):
         a, e = ints(r"A(\d),E(\d)")
         byts = 4.0 * (M * N + K * N)                      # write C, read weights
         byts += 4.0 * M * K * (2 if a == 4 else 1)        # read A (dy and z for the BatchNorm-backward operand; A5: z only,

@@ -10,7 +10,8 @@ arithmetic of the kernels themselves -- held to 1e-5 of each tensor's max-abs (V
                                                           gemm_wsd3<256,32,A5> (L2), gemm_wsd3<128,32,A4> (L1), scatter_dz (L0) backward
   (split products, the default; with PNPP_SPLIT_PRODUCTS=0: gemm_wsf / gemm_wsp / gemm_wsq / gemm_ws<...,dW> on the float32 MFMA pipe --
    tests/test_gpu_split_products.py runs both forms side by side)
-  sa3 (group_all, 259 -> 256 -> 512 -> 1024):            gemm_smallm + gemm_mid forward; da_dw_mid + da_dw backward
+  sa3 (group_all, 259 -> 256 -> 512 -> 1024):            gemm_smallm + gemm_mid3 (split products; gemm_mid: float32 MFMA) forward;
+                                                         da_dw_mid + da_dw backward
   fc1 / fc2 (32 rows, BatchNorm1d + ReLU (+ dropout)):   gemm_smallm<E_BN_APPLY> forward; fc_bwd_fused backward
 
 Inputs of each level are the float32 oracle's own activations and upstream gradients of the synthetic batch (so |mean| / std of

@@ -1,12 +1,12 @@
 """The float32 products of the grouped levels' large GEMMs, formed two ways, against the float64 oracle (GPU).
 
-'split' (the default, csrc/gemm_wsf3_kernels.hip, gemm_wsd3_kernels.hip): every float32 operand is the exact sum
+'split' (the default, csrc/gemm_wsf3_kernels.hip, gemm_wsd3_kernels.hip, gemm_mid3_kernel in gemm_mid_kernels.hip): every float32 operand is the exact sum
 of three bfloat16 numbers; six of the nine bf16 x bf16 partial products -- each exact in float32 -- are accumulated in float32 on the bf16
 matrix pipe, the three dropped ones are below 2^-25 of the product.  'mfma': v_mfma_f32_32x32x2_f32.  The claim tested here is that the
 first is float32-class arithmetic -- inside the same gates -- not a reduced-precision mode (rounding ONE operand to bfloat16, the bf16 mode
 of tests/test_gpu_bf16.py, is off by five orders of magnitude: flat gradient rel-L2 0.44 against 1e-5 here):
 
-  * both forms of every grouped level of the BASELINE step (configs[1]: 32 clouds x 1024 points) are held to the SAME gate against the
+  * both forms of every level of the BASELINE step (configs[1]: 32 clouds x 1024 points) are held to the SAME gate against the
     float64 oracle with every discrete decision injected (1e-5 of each tensor's max-abs, tests/test_gpu_levels_routed.py);
   * what the split form costs is measured, not assumed: v_mfma_f32_32x32x16_bf16 aligns its 16 products and the accumulator to the largest
     exponent among them and DROPS what lies 2^-26 below it (tools/mfma_round.hip, profiles/round4_mfma_bf16_accumulation.txt: 1 + 12 x 2^-27
@@ -27,7 +27,7 @@ from test_gpu_levels_routed import B, GATE, _run_level, net  # noqa: F401  (net:
 
 pytestmark = pytest.mark.gpu
 
-LEVELS = {"sa1": ("xyz", None, 0, "d_l1"), "sa2": ("l1_xyz", "l1", 1, "d_l2")}
+LEVELS = {"sa1": ("xyz", None, 0, "d_l1"), "sa2": ("l1_xyz", "l1", 1, "d_l2"), "sa3": ("l2_xyz", "l2", None, "d_l3")}
 
 
 @pytest.fixture()
@@ -42,10 +42,11 @@ def _level(oracle, net, prefix, ops, mode):
     xyz_k, pts_k, ci, d_k = LEVELS[prefix]
     getattr(net["model"], prefix).load_state_dict({k[len(prefix) + 1:]: v for k, v in net["state"].items() if k.startswith(prefix + ".")})
     ops.set_float32_products(mode)
-    return _run_level(oracle, net, prefix, net[xyz_k], None if pts_k is None else net[pts_k], net["centres"][ci], net[d_k], False)
+    return _run_level(oracle, net, prefix, net[xyz_k], None if pts_k is None else net[pts_k], None if ci is None else net["centres"][ci],
+                      net[d_k], ci is None)   # sa3 is the group_all level (its 512 -> 1024 forward product: gemm_mid3 / gemm_mid)
 
 
-@pytest.mark.parametrize("prefix", ["sa1", "sa2"])
+@pytest.mark.parametrize("prefix", ["sa1", "sa2", "sa3"])
 def test_split_products_stay_inside_the_float32_gates(oracle, net, products, prefix):
     split = _level(oracle, net, prefix, products, "split")
     mfma = _level(oracle, net, prefix, products, "mfma")
