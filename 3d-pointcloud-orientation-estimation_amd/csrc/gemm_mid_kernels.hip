@@ -362,6 +362,18 @@ __global__ void __launch_bounds__(256) da_dw_mid_kernel(const MidGemm G, int til
 // 128-byte rows, 16-byte groups at g ^ x(r) as in gemm_wsd3_kernels.hip) of the OTHER stage while the multipliers work on this one.  The
 // vector work of the split (about as many cycles as the 24 bf16 MFMAs of a chunk) overlaps with the matrix work because it comes from
 // another wave; one s_barrier per chunk (no workgroup fence: the stagers' loads stay in flight across it).
+// In-kernel phase stamps (-DMID3_STAMPS, tools/mid3_stamps.py): s_memtime in one stager and one multiplier wave of workgroup 8.
+#ifdef MID3_STAMPS
+__device__ unsigned long long g_mid3_stamps[2][4];   // [stager, multiplier][prologue, work, barrier, epilogue]
+#define M3_STAMP(i)                                                    \
+    if (st_on) {                                                       \
+        const unsigned long long st_t = __builtin_amdgcn_s_memtime(); \
+        st_acc[i] += st_t - st_last;                                   \
+        st_last = st_t;                                                \
+    }
+#else
+#define M3_STAMP(i)
+#endif
 constexpr int MID3_PLANE = MID_T * 128, MID3_IMG = 3 * MID3_PLANE, MID3_STAGE = 2 * MID3_IMG;   // bytes: plane, image (A or W), stage
 constexpr size_t MID3_LDS_BYTES = (size_t)2 * MID3_STAGE;                                    // two stages: 98,304 bytes
 
@@ -399,6 +411,11 @@ __global__ void __launch_bounds__(512, 1) gemm_mid3_kernel(const MidGemm G, int 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f, accs[r] = 0.f;
 
+#ifdef MID3_STAMPS
+    const bool st_on = blockIdx.x == 8 && (wave == 0 || wave == 4);
+    unsigned long long st_acc[4] = {0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
     if (stager) {
         const int t2 = tid - 256, q = t2 & 15, q4 = 4 * q, rb = t2 >> 4;   // k group 4 q .. + 3 of the chunk, rows rb + 16 i
         const __amdgpu_buffer_rsrc_t resA = mid_rsrc(G.a + (size_t)m0 * G.lda), resW = mid_rsrc(G.b + (size_t)n0 * G.ldb);
@@ -443,23 +460,33 @@ __global__ void __launch_bounds__(512, 1) gemm_mid3_kernel(const MidGemm G, int 
         gload(3, ra3, rw3, sc3, sh3);
         lstore(0, ra0, rw0, sc0, sh0);
         gload(4, ra0, rw0, sc0, sh0);   // K / 64 is a multiple of 4 and at least 8
+        M3_STAMP(0)
         mid3_barrier();   // stage 0 is complete
+        M3_STAMP(2)
         // Four chunks per pass.  The multipliers are on chunk c (stage 0): the other stage, which they left at the previous barrier, takes
         // chunk c + 1, and so on.  The last two passes are written out apart so that no request sits behind a branch: the compiler counts
         // outstanding loads per path, and a conditional request in the loop made every wait behind it a wait for ALL loads.
         auto pass = [&](const int c, const bool more, const bool more8) __attribute__((always_inline)) {
             lstore(1, ra1, rw1, sc1, sh1);
             if (more) gload(c + 5, ra1, rw1, sc1, sh1);
+            M3_STAMP(1)
             mid3_barrier();
+            M3_STAMP(2)
             lstore(0, ra2, rw2, sc2, sh2);
             if (more) gload(c + 6, ra2, rw2, sc2, sh2);
+            M3_STAMP(1)
             mid3_barrier();
+            M3_STAMP(2)
             lstore(1, ra3, rw3, sc3, sh3);
             if (more) gload(c + 7, ra3, rw3, sc3, sh3);
+            M3_STAMP(1)
             mid3_barrier();
+            M3_STAMP(2)
             if (more) lstore(0, ra0, rw0, sc0, sh0);
             if (more8) gload(c + 8, ra0, rw0, sc0, sh0);
+            M3_STAMP(1)
             mid3_barrier();
+            M3_STAMP(2)
         };
         for (int c = 0; c + 8 < nc; c += 4) pass(c, true, true);
         pass(nc - 8, true, false);
@@ -467,7 +494,9 @@ __global__ void __launch_bounds__(512, 1) gemm_mid3_kernel(const MidGemm G, int 
     } else {
         const unsigned arow = (unsigned)((wm * 32 + l31) * 128), brow = (unsigned)((wn * 32 + l31) * 128);
         const int ax = xs(l31);   // rows 32 wm + l31 and 32 wn + l31: x ignores bits 4, 5
+        M3_STAMP(0)
         mid3_barrier();   // stage 0 is complete
+        M3_STAMP(2)
         for (int c = 0; c < nc; ++c) {
             const unsigned char *As = lds3 + (c & 1) * MID3_STAGE, *Ws = As + MID3_IMG;
             uint4 fa[2][3], fb[2][3];
@@ -497,7 +526,12 @@ __global__ void __launch_bounds__(512, 1) gemm_mid3_kernel(const MidGemm G, int 
                 if (t + 2 < 4) ld(0, t + 2);
                 mm(1);
             }
+#ifdef MID3_STAMPS
+            asm volatile("s_nop 0" ::"v"(acc), "v"(accs));   // the clock is read behind the last MFMA, not behind its issue
+#endif
+            M3_STAMP(1)
             mid3_barrier();
+            M3_STAMP(2)
         }
     }
 
@@ -547,6 +581,12 @@ __global__ void __launch_bounds__(512, 1) gemm_mid3_kernel(const MidGemm G, int 
             E.slab[((size_t)tm * 2 + which) * G.N + n0 + cl] = red[(0 * 2 + which) * MID_T + cl] + red[(1 * 2 + which) * MID_T + cl];
         }
     }
+#ifdef MID3_STAMPS
+    M3_STAMP(3)
+    if (st_on && lane == 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g_mid3_stamps[stager ? 0 : 1][i] += st_acc[i];
+#endif
 }
 
 static bool mid_ptr_ok(const float *p, int ld) { return p && (ld & 3) == 0 && ((uintptr_t)p & 15) == 0; }
@@ -672,4 +712,21 @@ bool try_launch_mid_da_dw(const AOperand &dz, const BOperand &W, int M, int Nout
     return true;
 }
 
+#ifdef MID3_STAMPS
+unsigned mid3_build_flags() { return 512u; }
+#else
+unsigned mid3_build_flags() { return 0u; }
+#endif
+
 }  // namespace pnpp
+
+#ifdef MID3_STAMPS
+extern "C" int pnpp_debug_mid3_stamps(unsigned long long *out8, int reset) {
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(pnpp::g_mid3_stamps), z, sizeof(z));
+    }
+    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(pnpp::g_mid3_stamps), 8 * sizeof(unsigned long long));
+    return 0;
+}
+#endif

@@ -184,6 +184,7 @@ int launch_xyz0_mask(const AOperand &geo, int M, const float *W0, int ldw0, cons
 unsigned wsx_build_flags();
 unsigned wsf_build_flags();
 unsigned wsd3_build_flags();
+unsigned mid3_build_flags();   // bit 9: gemm_mid3_kernel's phase stamps compiled in
 unsigned wsp_build_flags();
 unsigned wsq_build_flags();
 unsigned gemm_build_flags();

@@ -702,7 +702,8 @@ extern "C" int pnpp_sa_saved_relu_mask(const pnpp_sa_desc *d, const void *saved,
     return launch_relu_mask(sv.z[layer], sv.scale[layer], sv.shift[layer], (size_t)g.M * d->C[layer], d->C[layer], out, as_stream(stream));
 }
 extern "C" unsigned pnpp_build_flags(void) {
-    return gemm_build_flags() | wsp_build_flags() | wsx_build_flags() | wsq_build_flags() | fc_build_flags() | wsf_build_flags() | wsd3_build_flags();
+    return gemm_build_flags() | wsp_build_flags() | wsx_build_flags() | wsq_build_flags() | fc_build_flags() | wsf_build_flags() | wsd3_build_flags() |
+           mid3_build_flags();
 }
 extern "C" int pnpp_sa_group_pair(const pnpp_sa_desc *d1, const pnpp_sa_desc *d2, const float *xyz, const int32_t *centre1,
                                   const int32_t *centre2, void *saved1, float *new_xyz1, void *saved2, float *new_xyz2, void *stream) {

@@ -30,7 +30,7 @@ SOURCES = {
     "index_kernels.hip": ["-ffp-contract=off"],
     "gemm_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_bf16_kernels.hip": [],
-    "gemm_mid_kernels.hip": [],
+    "gemm_mid_kernels.hip": (["-DMID3_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_wsf_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []) + ([f"-DWSF_EXP={os.environ['PNPP_WSF_EXP']}"] if os.environ.get("PNPP_WSF_EXP") else []),
     "gemm_wsf3_kernels.hip": _NOSLP,
     "gemm_wsd3_kernels.hip": _NOSLP + (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
