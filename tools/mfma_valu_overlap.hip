@@ -19,27 +19,36 @@ __global__ void __launch_bounds__(512) k(float *out, unsigned long long *cyc, in
     for (int i = 0; i < 12; ++i) v[i] = 1.0f + threadIdx.x * 1e-3f + i;
     unsigned u[12];
     for (int i = 0; i < 12; ++i) u[i] = threadIdx.x + i;
-    const bool do_m = MODE == 0 || MODE == 2 || (MODE == 1 && wave < 4);
-    const bool do_v = MODE == 0 || MODE == 3 || (MODE == 1 && wave >= 4);
+    const int role = __builtin_amdgcn_readfirstlane(MODE == 1 ? (wave < 4 ? 2 : 3) : MODE);   // 0 both, 2 MFMA only, 3 vector only (uniform per wave)
     if (MODE != 1 && wave >= 4) return;
     __syncthreads();
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (int it = 0; it < iters; ++it) {
+    auto vec = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int rep = 0; rep < 8; ++rep) {
-            if (do_m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-            if (do_v) {
-#pragma unroll
-                for (int n = 0; n < N; ++n) {
-                    const int j = n % 12;
-                    if (KIND == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[j]) : "v"(v[(j + 5) % 12]));
-                    if (KIND == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u[j]) : "v"(v[j]), "v"(v[(j + 1) % 12]));
-                    if (KIND == 2) asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(u[j]));
-                    if (KIND == 3) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(u[j]) : "v"(u[(j + 3) % 12]));
-                    if (KIND == 4) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(*(f32x2 *)&v[2 * (j % 6)]) : "v"(*(f32x2 *)&v[2 * ((j + 2) % 6)]));
-                }
-            }
+        for (int n = 0; n < N; ++n) {
+            const int j = n % 12;
+            if (KIND == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[j]) : "v"(v[(j + 5) % 12]));
+            if (KIND == 1) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u[j]) : "v"(v[j]), "v"(v[(j + 1) % 12]));
+            if (KIND == 2) asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(u[j]));
+            if (KIND == 3) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(u[j]) : "v"(u[(j + 3) % 12]));
+            if (KIND == 4) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(*(f32x2 *)&v[2 * (j % 6)]) : "v"(*(f32x2 *)&v[2 * ((j + 2) % 6)]));
         }
+    };
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (role == 0) {   // (one loop per role: no branch inside the timed loops)
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int rep = 0; rep < 8; ++rep) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                vec();
+            }
+    } else if (role == 2) {
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int rep = 0; rep < 8; ++rep) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    } else {
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int rep = 0; rep < 8; ++rep) vec();
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.f;
