@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "kernels.h"
+#include "wsf0_args.h"
 
 namespace pnpp {
 
@@ -41,14 +42,8 @@ struct WsxArgs {
     double *xslab;               // [workers][kWsxSlab]
 };
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t wsx_rsrc(const void *base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), (short)0, 0xfffffffe, 0x00020000);
-}
 __device__ __forceinline__ f32x4 wsx_load4(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned s_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)s_off, 0));
-}
-__device__ __forceinline__ float wsx_load1(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned s_off) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)s_off, 0));
 }
 
 #ifndef WSX_EXP   // timing experiments (wrong results): 2 no dW loop, 4 no dA loop, 8 no epilogue arithmetic
@@ -526,7 +521,6 @@ __global__ void __launch_bounds__(256) xyz0_post_kernel(const Xyz0PostArgs P, in
 //                        E[z^2]_c = W_0[c]^T (R2 / M) W_0[c] in float64 from the few moment partials -- and workgroup 0 writes them
 //                        (and the running statistics) for the backward pass.  No layer-0 GEMM, no statistics launch, no Z_0.
 // Reference: models/pointnet_pp_8dir.py:31-41 (grouped_xyz - new_xyz, conv 3 -> 64, BatchNorm, ReLU, conv 64 -> 64).
-constexpr int kMomSlabs = 128, kMomPitch = 16;
 
 struct MomArgs {
     const float *xyz, *centres;
@@ -574,26 +568,6 @@ __global__ void __launch_bounds__(256) rel_moments_kernel(const MomArgs P) {
     __syncthreads();
     if (tid < 9) P.out[(size_t)blockIdx.x * kMomPitch + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
-
-struct Wsf0Args {
-    const float *xyz, *centres;
-    const int32_t *idx;
-    int M, N, S;
-    const float *W0;   // 64 x 3, pitch ldw0
-    int ldw0;
-    // layer 0's BatchNorm: train mode finishes the statistics from the moment partials (mom, nmom); eval mode reads scale0 / shift0
-    const double *mom;
-    int nmom, training;
-    const float *bias0, *gamma0, *beta0;
-    float *rm0, *rv0;
-    long long *nbt0;
-    float momentum, eps;
-    float *mean0, *istd0, *scale0, *shift0;
-    const float *W1;   // C_1 x 64 as stored (row = output channel)
-    int ldw1;
-    float *z1;         // M x 64
-    double *slab;      // [workers][2][64] (EM == E_STORE_STATS)
-};
 
 template <int EM>
 __global__ void __launch_bounds__(256, 2)
@@ -867,6 +841,14 @@ int launch_wsf0(const AOperand &geo, int M, const float *W0, int ldw0, const dou
     if (workers * 4 > nstrips) workers = (nstrips + 3) / 4;
     if (nslab) *nslab = workers;
     constexpr size_t lds = ((size_t)64 * 64 + 4 * 32 * 68 + 128) * sizeof(float) + (64 + 16) * sizeof(double);
+    {   // float32 products from exact bf16 splits (the default): gemm_wsf03_kernels.hip
+        if (wsf03_enabled()) {
+            ProfScope ps3(st, "gemm_wsf03_kernel<E%d> M=%d N=64 K=64 grid=%dx1", E.mode, M, workers);
+            launch_wsf03(P, workers, E.mode, st);
+            PNPP_CHECK_LAUNCH("gemm_wsf03");
+            return PNPP_OK;
+        }
+    }
     ProfScope ps(st, "gemm_wsf0_kernel<E%d> M=%d N=64 K=64 grid=%dx1", E.mode, M, workers);
     static bool granted[2] = {false, false};
     if (E.mode == E_STORE_STATS) {

@@ -36,6 +36,7 @@ SOURCES = {
     "gemm_wsd3_kernels.hip": _NOSLP + (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_wsp_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "gemm_wsx_kernels.hip": [],
+    "gemm_wsf03_kernels.hip": _NOSLP,
     "gemm_wsq_kernels.hip": [],
     "loss_kernels.hip": (["-DPNPP_STAMPS"] if os.environ.get("PNPP_STAMPS") else []),
     "sa_api.hip": [],
