@@ -41,7 +41,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: BF16 dense (the opt-in bf16-operand variant's kernels)
 # float32 products formed as six exact bf16 x bf16 partial products (csrc/gemm_wsf3_kernels.hip): float32-equivalent FLOP/s of the bf16 pipe
 MFMA_SPLIT_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
-SPLIT_KERNELS = ("gemm_wsf3_kernel", "gemm_wsd3_kernel", "gemm_mid3_kernel")
+SPLIT_KERNELS = ("gemm_wsf3_kernel", "gemm_wsd3_kernel", "gemm_mid3_kernel", "gemm_wsf03_kernel")
 FLOPS_PER_CLOUD = 0.8542e9     # 3 x 2 x 142,369,280 MAC, forward + backward, independent of N
 BYTES_PER_CLOUD = 34.6e6       # 5 E + 3 G float32 words + xyz / indices
 
@@ -333,7 +333,7 @@ def kernel_cost(tag: str):
         # tile), dY_0 is never written; weights read, dW written once (partial slabs are traffic, not algorithmic bytes)
         M, N, K = ints(r"M=(\d+) N=(\d+) K=(\d+)")
         return 4.0 * M * N * K + 8.0 * M * N, 4.0 * (2.0 * M * K + M + 2.0 * K * N)
-    if tag.startswith("gemm_wsf0_kernel"):
+    if tag.startswith(("gemm_wsf0_kernel", "gemm_wsf03_kernel")):
         M, N, K = ints(r"M=(\d+) N=(\d+) K=(\d+)")
         return 2.0 * M * N * K + 8.0 * M * K, 4.0 * (M * N + M + K * N)   # z_1 written once, neighbour indices read; no operand stream
     if tag.startswith("rel_moments_kernel"):

@@ -57,6 +57,9 @@ def tag_of(name, gx, gy, wg):
     m = re.search(r"gemm_wsd3_kernel<(\d+), (\d+), (\d+)>", name)   # <K, BN, A mode>
     if m:
         return f"gemm_wsd3_kernel<{m.group(1)},{m.group(2)},A{m.group(3)}> {g}"
+    m = re.search(r"gemm_wsf03_kernel<(\d+)>", name)
+    if m:
+        return f"gemm_wsf03_kernel<E{m.group(1)}> {g}"
     m = re.search(r"gemm_wsf0_kernel<(\d+)>", name)
     if m:
         return f"gemm_wsf0_kernel<E{m.group(1)}> {g}"
