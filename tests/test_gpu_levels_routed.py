@@ -4,7 +4,7 @@ the max-pool routing (pnpp_sa_saved_argmax) and the ReLU decisions of every laye
 float64 evaluation is a smooth function of rounding, no "an arg-max / ReLU flip explains it" remains, and what is left is the
 arithmetic of the kernels themselves -- held to 1e-5 of each tensor's max-abs (VERDICT round 3, item 1 asked for 1e-4):
 
-  sa1 (B 32, N 1024 -> 128 x 32, 3 -> 64 -> 64 -> 128):  rel_moments + gemm_wsf0 + gemm_wsf3<64> forward;
+  sa1 (B 32, N 1024 -> 128 x 32, 3 -> 64 -> 64 -> 128):  rel_moments + gemm_wsf03 (gemm_wsf0: float32 MFMA) + gemm_wsf3<64> forward;
                                                           gemm_wsd3<128,32,A5> (L2), gemm_wsx + xyz0_post (L1 + L0) backward
   sa2 (128 -> 32 x 32, 131 -> 128 -> 128 -> 256):        gather_rel_stats + gemm_wsf3<128> forward;
                                                           gemm_wsd3<256,32,A5> (L2), gemm_wsd3<128,32,A4> (L1), scatter_dz (L0) backward
