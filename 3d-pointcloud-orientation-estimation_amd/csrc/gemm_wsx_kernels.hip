@@ -51,21 +51,46 @@ __device__ __forceinline__ f32x4 wsx_load4(__amdgpu_buffer_rsrc_t r, unsigned la
 #endif
 
 // KD = C_1 (64); C_0 = 64.  One workgroup per CU or two (launch bounds 256 x WPC); a wave owns strips of 32 rows end to end.
-template <int KD, int WPC>
+// S3: the dA product (X W', 64 -> 64 per strip) from exact three-way bf16 splits on v_mfma_f32_32x32x16_bf16 (gemm_wsf3_kernels.hip has the
+// arithmetic): the weight panel is split once in the prologue (three bf16 planes, the k order of a 16-group laid out as the operand reads
+// it, as in gemm_wsf03_kernels.hip), a lane splits the 8 values of its row it multiplies per step in registers -- 48 MFMAs of 32 cycles per
+// strip instead of 64 of 64 for 2,048 split elements.  dW_1 stays on the float32 instruction: its operands would be 4,096 split elements per
+// strip for the same 2,560 cycles (a split element has to feed three tiles to earn its 29 cycles: DESIGN.md section 9).
+typedef __bf16 wsx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wsx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wsx_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned wsx_pk(float lo, float hi) {
+    const wsx_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wsx_bf16x2));
+}
+__device__ __forceinline__ void wsx_split2(float v0, float v1, unsigned &h, unsigned &m, unsigned &l) {
+    h = wsx_pk(v0, v1);
+    float r0 = v0 - __uint_as_float(h << 16), r1 = v1 - __uint_as_float(h & 0xffff0000u);
+    m = wsx_pk(r0, r1);
+    r0 -= __uint_as_float(m << 16), r1 -= __uint_as_float(m & 0xffff0000u);
+    l = wsx_pk(r0, r1);
+}
+__device__ __forceinline__ wsx_bf16x8 wsx_op(uint4 v) { return __builtin_bit_cast(wsx_bf16x8, v); }
+constexpr int WSX3_PLANE = 64 * 128;   // bytes: [64 columns n][64 k] bf16
+
+template <int KD, int WPC, bool S3>
 __global__ void __launch_bounds__(256, WPC)
 gemm_wsx_kernel(const WsxArgs P) {
     constexpr int BN = 64, NC = KD / 64, DP = KD + 4, CT = KD / 32;
-    constexpr int MAIN = BN * KD + 4 * 32 * DP, RED = CT * 2 * 4 * 4 * 64 * 4;
+    static_assert(!S3 || KD == 64, "split dA product: one 64-deep chunk");
+    constexpr int PANEL = S3 ? 3 * WSX3_PLANE / 4 : BN * KD;   // floats: three bf16 planes or the float32 image
+    constexpr int MAIN = PANEL + 4 * 32 * DP, RED = CT * 2 * 4 * 4 * 64 * 4;
     constexpr int TAB = MAIN > RED ? MAIN : RED;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Ws = lds;                                       // [BN][KD]: (diag(g) W_1)^T image, 16-byte groups swizzled by (n & 15)
     float *Tsc = lds + TAB, *Tb = Tsc + KD, *Tbw = Tb + KD, *Tred = Tbw + BN;   // g[KD], b[KD], (b W)[64], scratch [4][64] floats / doubles
     float *RlAll = Tred + 512;                             // [4 waves][32][4]: relative coordinates of the wave's strip
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *Dz = lds + BN * KD + wave * (32 * DP);          // this wave's dZ_1 strip image [32][DP]
+    float *Dz = lds + PANEL + wave * (32 * DP);            // this wave's dZ_1 strip image [32][DP]
     float *Rl = RlAll + wave * 128;
     const int l31 = lane & 31, lh = lane >> 5;
     auto swz = [](int r) { return (r & 15) << 2; };
+    auto xs3 = [](int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); };   // group XOR of a plane row (conflict-free ds_read_b128 row reads)
     const int worker = blockIdx.x, nworkers = gridDim.x;
 
     const int q4 = 4 * (lane & 15), rb = lane >> 4;        // staging map of a strip: column group lane % 16, rows lane / 16 + 4 i
@@ -147,7 +172,18 @@ gemm_wsx_kernel(const WsxArgs P) {
             bwp = fmaf(bb[0], tw[j][0], fmaf(bb[1], tw[j][1], fmaf(bb[2], tw[j][2], fmaf(bb[3], tw[j][3], bwp))));
             f32x4 t;
             t[0] = sc[0] * tw[j][0], t[1] = sc[1] * tw[j][1], t[2] = sc[2] * tw[j][2], t[3] = sc[3] * tw[j][3];
-            *reinterpret_cast<f32x4 *>(Ws + nl * KD + (k4 ^ swz(nl))) = t;
+            if constexpr (S3) {   // row n = 128 bytes; the four k go to the 16-byte group of the lane half that reads them (gemm_wsf03_kernels.hip)
+                const int kq = k4 >> 2, g = 2 * (kq >> 2) + (kq & 1), sub = (kq >> 1) & 1;
+                unsigned h0, m0, l0, h1, m1, l1;
+                wsx_split2(t[0], t[1], h0, m0, l0);
+                wsx_split2(t[2], t[3], h1, m1, l1);
+                unsigned char *d = reinterpret_cast<unsigned char *>(Ws) + nl * 128 + 16 * (g ^ xs3(nl)) + 8 * sub;
+                *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2 *>(d + WSX3_PLANE) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2 *>(d + 2 * WSX3_PLANE) = make_uint2(l0, l1);
+            } else {
+                *reinterpret_cast<f32x4 *>(Ws + nl * KD + (k4 ^ swz(nl))) = t;
+            }
         }
         Tred[wave * BN + lane] = bwp;   // nl == lane for every group of this thread
     }
@@ -219,6 +255,54 @@ gemm_wsx_kernel(const WsxArgs P) {
         f32x16 acc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = bw0, acc[1][r] = bw1;
+        if constexpr (S3) {
+            if (!(WSX_EXP & 4)) {
+                f32x16 accs[2];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[0][r] = 0.f, accs[1][r] = 0.f;
+                const unsigned char *bpl = reinterpret_cast<const unsigned char *>(Ws) + l31 * 128;   // column 32 j + l31: + 4096 j
+                const int bx = xs3(l31);
+                float4 fa[2][2];
+                uint4 fb[2][2][3];
+                auto ld = [&](int buf, int st) {   // step st: k = 16 st + 4 lh + {0..3}, 16 st + 8 + 4 lh + {0..3}
+                    fa[buf][0] = *reinterpret_cast<const float4 *>(arow + 16 * st);
+                    fa[buf][1] = *reinterpret_cast<const float4 *>(arow + 16 * st + 8);
+                    const int g = (2 * st + lh) ^ bx;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) fb[buf][j][p] = *reinterpret_cast<const uint4 *>(bpl + j * 4096 + p * WSX3_PLANE + 16 * g);
+                };
+                auto mm = [&](int buf) {
+                    unsigned h[4], m[4], l[4];
+                    wsx_split2(fa[buf][0].x, fa[buf][0].y, h[0], m[0], l[0]);
+                    wsx_split2(fa[buf][0].z, fa[buf][0].w, h[1], m[1], l[1]);
+                    wsx_split2(fa[buf][1].x, fa[buf][1].y, h[2], m[2], l[2]);
+                    wsx_split2(fa[buf][1].z, fa[buf][1].w, h[3], m[3], l[3]);
+                    const wsx_bf16x8 a_h = wsx_op(make_uint4(h[0], h[1], h[2], h[3])), a_m = wsx_op(make_uint4(m[0], m[1], m[2], m[3])),
+                                     a_l = wsx_op(make_uint4(l[0], l[1], l[2], l[3]));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const wsx_bf16x8 b_h = wsx_op(fb[buf][j][0]), b_m = wsx_op(fb[buf][j][1]), b_l = wsx_op(fb[buf][j][2]);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc[j], 0, 0, 0);
+                        accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, accs[j], 0, 0, 0);
+                        accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, accs[j], 0, 0, 0);
+                        accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, b_m, accs[j], 0, 0, 0);
+                        accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, b_h, accs[j], 0, 0, 0);
+                        accs[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_m, accs[j], 0, 0, 0);
+                    }
+                };
+                ld(0, 0);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    fetch_z(nZ, nY, snext, 0, 2 * st), fetch_z(nZ, nY, snext, 0, 2 * st + 1);   // the next strip's dense streams (staged above)
+                    if (st + 1 < 4) ld((st + 1) & 1, st + 1);
+                    mm(st & 1);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] += accs[0][r], acc[1][r] += accs[1][r];
+            }
+        } else
         if (!(WSX_EXP & 4)) {
             float4 fa[2], fb[2][2];
             auto ld = [&](int buf, int t) {
@@ -864,12 +948,12 @@ int launch_wsf0(const AOperand &geo, int M, const float *W0, int ldw0, const dou
     return PNPP_OK;
 }
 
-template <int KD, int WPC>
+template <int KD, int WPC, bool S3>
 static void wsx_launch(const WsxArgs &P, int workers, hipStream_t st) {
-    constexpr size_t main_f = (size_t)64 * KD + 4 * 32 * (KD + 4), red_f = (size_t)(KD / 32) * 2 * 4 * 4 * 64 * 4;
+    constexpr size_t main_f = (size_t)(S3 ? 3 * WSX3_PLANE / 4 : 64 * KD) + 4 * 32 * (KD + 4), red_f = (size_t)(KD / 32) * 2 * 4 * 4 * 64 * 4;
     constexpr size_t lds = ((main_f > red_f ? main_f : red_f) + 2 * KD + 64 + 512 + 512) * sizeof(float);
     static_assert(lds * WPC <= 160 * 1024, "LDS budget");
-    auto kfn = gemm_wsx_kernel<KD, WPC>;
+    auto kfn = gemm_wsx_kernel<KD, WPC, S3>;
     static bool granted = false;
     if (lds > 48 * 1024 && !granted) {
         (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -893,9 +977,15 @@ bool try_launch_wsx(const AOperand &dz, const BOperand &W, int M, int C1, int C0
     P.dy = dz.a, P.z = dz.z, P.cst = dz.cst, P.W = W.b, P.ldw = W.ldb, P.M = M;
     P.xyz = geo.xyz, P.centres = geo.new_xyz, P.idx = geo.idx, P.N = geo.N, P.S = geo.S;
     P.W0 = W0, P.ldw0 = ldw0, P.scale0 = scale0, P.shift0 = shift0, P.dwslab = dwslab, P.xslab = stat;
-    ProfScope ps(st, "gemm_wsx_kernel<%d,%d> M=%d N=%d K=%d grid=%dx1", C1, wpc, M, C0, C1, workers);
-    if (wpc == 2) wsx_launch<64, 2>(P, workers, st);
-    else wsx_launch<64, 1>(P, workers, st);
+    static const bool s3_on = !(getenv("PNPP_WSX3") && atoi(getenv("PNPP_WSX3")) == 0);   // PNPP_WSX3=0: the dA product on the float32 instruction (A/B runs)
+    const bool s3 = s3_on && split_products() && wpc == 1;   // (two workgroups per CU leave the split form 74 registers short)
+    ProfScope ps(st, "gemm_wsx_kernel<%d,%d%s> M=%d N=%d K=%d grid=%dx1", C1, wpc, s3 ? ",S3" : "", M, C0, C1, workers);
+    if (wpc == 2) {
+        wsx_launch<64, 2, false>(P, workers, st);
+    } else {
+        if (s3) wsx_launch<64, 1, true>(P, workers, st);
+        else wsx_launch<64, 1, false>(P, workers, st);
+    }
     if (hipGetLastError() != hipSuccess) {
         set_error("gemm_wsx: launch failed");
         *rc = PNPP_ERR_LAUNCH;
