@@ -1,5 +1,5 @@
 #!/bin/bash
-# gemm_wsx3_kernel against gemm_wsx_kernel on ONE box: the level tests with the new kernel, then the step both ways (PNPP_WSX3=0: the float32-MFMA form)
+# gemm_wsx_kernel with the split dA product (<64,1,S3>) against the float32 form on ONE box: the level tests, then the step both ways (PNPP_WSX3=0: float32 MFMA)
 set -e -o pipefail
 mkdir -p gpurun_out/wx3
 timeout -k 10 500 python -m pytest tests/test_gpu_levels_routed.py tests/test_gpu_split_products.py tests/test_gpu_sa.py -x -q -m gpu > gpurun_out/wx3/tests.log 2>&1 || { tail -40 gpurun_out/wx3/tests.log; exit 1; }
