@@ -73,20 +73,34 @@ __device__ __forceinline__ void wsx_split2(float v0, float v1, unsigned &h, unsi
 __device__ __forceinline__ wsx_bf16x8 wsx_op(uint4 v) { return __builtin_bit_cast(wsx_bf16x8, v); }
 constexpr int WSX3_PLANE = 64 * 128;   // bytes: [64 columns n][64 k] bf16
 
-template <int KD, int WPC, bool S3>
+// D3 (with S3): the dW_1 product on the bf16 pipe too.  dZ_1 is split ONCE, when the strip is staged: the strip image is three bf16 planes
+// ([32 rows][64 channels], 128-byte rows, 16-byte group g of row r at g ^ x(r) as in gemm_wsd3_kernels.hip), read back by rows for dA
+// (ds_read_b128) and transposed for dW (ds_read_b64_tr_b16: lane = channel, eight rows per lane half); the activation operand of dW is the
+// layer-0 tile's accumulator registers (eight consecutive ones = one 32x32x16 operand), ReLU'd and split in registers.
+typedef short wsx_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 wsx_tr(const unsigned char *p) {   // ds_read_b64_tr_b16: 4 rows x 16 columns per 16 lanes, transposed
+    const wsx_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wsx_s16x4 *)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+
+template <int KD, int WPC, bool S3, bool D3>
 __global__ void __launch_bounds__(256, WPC)
 gemm_wsx_kernel(const WsxArgs P) {
     constexpr int BN = 64, NC = KD / 64, DP = KD + 4, CT = KD / 32;
     static_assert(!S3 || KD == 64, "split dA product: one 64-deep chunk");
+    static_assert(!D3 || S3, "split dW product: with the split dA product");
     constexpr int PANEL = S3 ? 3 * WSX3_PLANE / 4 : BN * KD;   // floats: three bf16 planes or the float32 image
-    constexpr int MAIN = PANEL + 4 * 32 * DP, RED = CT * 2 * 4 * 4 * 64 * 4;
+    constexpr int STRIPF = D3 ? 3 * 32 * 128 / 4 : 32 * DP;    // floats per wave: three bf16 planes of the strip or its float32 image
+    constexpr int SPLANE = 32 * 128;                           // bytes of a strip plane
+    constexpr int MAIN = PANEL + 4 * STRIPF, RED = CT * 2 * 4 * 4 * 64 * 4;
     constexpr int TAB = MAIN > RED ? MAIN : RED;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Ws = lds;                                       // [BN][KD]: (diag(g) W_1)^T image, 16-byte groups swizzled by (n & 15)
     float *Tsc = lds + TAB, *Tb = Tsc + KD, *Tbw = Tb + KD, *Tred = Tbw + BN;   // g[KD], b[KD], (b W)[64], scratch [4][64] floats / doubles
     float *RlAll = Tred + 512;                             // [4 waves][32][4]: relative coordinates of the wave's strip
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *Dz = lds + PANEL + wave * (32 * DP);            // this wave's dZ_1 strip image [32][DP]
+    float *Dz = lds + PANEL + wave * STRIPF;               // this wave's dZ_1 strip image [32][DP] (D3: three bf16 planes)
+    unsigned char *Dzp = reinterpret_cast<unsigned char *>(Dz);
     float *Rl = RlAll + wave * 128;
     const int l31 = lane & 31, lh = lane >> 5;
     auto swz = [](int r) { return (r & 15) << 2; };
@@ -173,7 +187,8 @@ gemm_wsx_kernel(const WsxArgs P) {
             f32x4 t;
             t[0] = sc[0] * tw[j][0], t[1] = sc[1] * tw[j][1], t[2] = sc[2] * tw[j][2], t[3] = sc[3] * tw[j][3];
             if constexpr (S3) {   // row n = 128 bytes; the four k go to the 16-byte group of the lane half that reads them (gemm_wsf03_kernels.hip)
-                const int kq = k4 >> 2, g = 2 * (kq >> 2) + (kq & 1), sub = (kq >> 1) & 1;
+                const int kq = k4 >> 2;   // D3: plain k order (the strip rows come from the planes); else the order a register-split row has
+                const int g = D3 ? (kq >> 1) : 2 * (kq >> 2) + (kq & 1), sub = D3 ? (kq & 1) : (kq >> 1) & 1;
                 unsigned h0, m0, l0, h1, m1, l1;
                 wsx_split2(t[0], t[1], h0, m0, l0);
                 wsx_split2(t[2], t[3], h1, m1, l1);
@@ -191,13 +206,16 @@ gemm_wsx_kernel(const WsxArgs P) {
     __syncthreads();
     if (tid < BN) Tbw[tid] = (Tred[tid] + Tred[BN + tid]) + (Tred[2 * BN + tid] + Tred[3 * BN + tid]);
 
-    f32x16 dw[CT][2];
+    f32x16 dw[CT][2], dws[D3 ? CT : 1][2];   // D3: the small products of dW in accumulators of their own
 #pragma unroll
     for (int i = 0; i < CT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dw[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                dw[i][j][r] = 0.f;
+                if (D3 || i == 0) dws[D3 ? i : 0][j][r] = 0.f;
+            }
     double s1[2] = {0.0, 0.0}, sX[2] = {0.0, 0.0}, sY[2] = {0.0, 0.0}, sZ[2] = {0.0, 0.0}, sa[2] = {0.0, 0.0};
     double mom[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     __syncthreads();   // the panel and (b W) are complete; from here on the waves run on their own
@@ -208,8 +226,30 @@ gemm_wsx_kernel(const WsxArgs P) {
         const f32x4 dy = ry[c][i];
         v[0] = fmaf(kq[c].x, v[0], dy[0]), v[1] = fmaf(kq[c].y, v[1], dy[1]);
         v[2] = fmaf(kq[c].z, v[2], dy[2]), v[3] = fmaf(kq[c].w, v[3], dy[3]);
-        *reinterpret_cast<f32x4 *>(Dz + (rb + 4 * i) * DP + 64 * c + q4) = v;
+        if constexpr (D3) {   // the strip is split here, once for both products
+            const int r = rb + 4 * i, q = q4 >> 2;
+            unsigned h0, m0, l0, h1, m1, l1;
+            wsx_split2(v[0], v[1], h0, m0, l0);
+            wsx_split2(v[2], v[3], h1, m1, l1);
+            unsigned char *d = Dzp + r * 128 + 16 * ((q >> 1) ^ xs3(r)) + 8 * (q & 1);
+            *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(d + SPLANE) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2 *>(d + 2 * SPLANE) = make_uint2(l0, l1);
+        } else {
+            *reinterpret_cast<f32x4 *>(Dz + (rb + 4 * i) * DP + 64 * c + q4) = v;
+        }
     };
+    // D3: transposed reads [c-tile it][step s][block b]: rows 16 s + 8 b + 4 lh + qq, channels 32 it + l31 (gemm_wsd3_kernels.hip)
+    unsigned tbase[2] = {0u, 0u};
+    if constexpr (D3) {
+        const int gi = lane & 15, qq = gi >> 2, pp = gi & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int r = 8 * b + 4 * lh + qq, ch = 2 * g1 + (pp >> 1);
+            tbase[b] = (unsigned)(r * 128 + 16 * (ch ^ xs3(r)) + 8 * (pp & 1));
+        }
+    }
+    auto tofs = [&](int it, int st, int b) -> unsigned { return (tbase[b] ^ (unsigned)(it * 64)) + (unsigned)(st * 2048); };
     const float *arow = Dz + l31 * DP + 4 * lh;
     const float *brow[2];
     int gb[2];
@@ -263,10 +303,17 @@ gemm_wsx_kernel(const WsxArgs P) {
                 const unsigned char *bpl = reinterpret_cast<const unsigned char *>(Ws) + l31 * 128;   // column 32 j + l31: + 4096 j
                 const int bx = xs3(l31);
                 float4 fa[2][2];
+                uint4 fap[2][3];
                 uint4 fb[2][2][3];
-                auto ld = [&](int buf, int st) {   // step st: k = 16 st + 4 lh + {0..3}, 16 st + 8 + 4 lh + {0..3}
-                    fa[buf][0] = *reinterpret_cast<const float4 *>(arow + 16 * st);
-                    fa[buf][1] = *reinterpret_cast<const float4 *>(arow + 16 * st + 8);
+                auto ld = [&](int buf, int st) {   // step st: k = 16 st + 4 lh + {0..3}, 16 st + 8 + 4 lh + {0..3} (D3: 16 st + 8 lh + {0..7})
+                    if constexpr (D3) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            fap[buf][p] = *reinterpret_cast<const uint4 *>(Dzp + p * SPLANE + l31 * 128 + 16 * ((2 * st + lh) ^ bx));
+                    } else {
+                        fa[buf][0] = *reinterpret_cast<const float4 *>(arow + 16 * st);
+                        fa[buf][1] = *reinterpret_cast<const float4 *>(arow + 16 * st + 8);
+                    }
                     const int g = (2 * st + lh) ^ bx;
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
@@ -274,13 +321,18 @@ gemm_wsx_kernel(const WsxArgs P) {
                         for (int p = 0; p < 3; ++p) fb[buf][j][p] = *reinterpret_cast<const uint4 *>(bpl + j * 4096 + p * WSX3_PLANE + 16 * g);
                 };
                 auto mm = [&](int buf) {
-                    unsigned h[4], m[4], l[4];
-                    wsx_split2(fa[buf][0].x, fa[buf][0].y, h[0], m[0], l[0]);
-                    wsx_split2(fa[buf][0].z, fa[buf][0].w, h[1], m[1], l[1]);
-                    wsx_split2(fa[buf][1].x, fa[buf][1].y, h[2], m[2], l[2]);
-                    wsx_split2(fa[buf][1].z, fa[buf][1].w, h[3], m[3], l[3]);
-                    const wsx_bf16x8 a_h = wsx_op(make_uint4(h[0], h[1], h[2], h[3])), a_m = wsx_op(make_uint4(m[0], m[1], m[2], m[3])),
-                                     a_l = wsx_op(make_uint4(l[0], l[1], l[2], l[3]));
+                    wsx_bf16x8 a_h, a_m, a_l;
+                    if constexpr (D3) {
+                        a_h = wsx_op(fap[buf][0]), a_m = wsx_op(fap[buf][1]), a_l = wsx_op(fap[buf][2]);
+                    } else {
+                        unsigned h[4], m[4], l[4];
+                        wsx_split2(fa[buf][0].x, fa[buf][0].y, h[0], m[0], l[0]);
+                        wsx_split2(fa[buf][0].z, fa[buf][0].w, h[1], m[1], l[1]);
+                        wsx_split2(fa[buf][1].x, fa[buf][1].y, h[2], m[2], l[2]);
+                        wsx_split2(fa[buf][1].z, fa[buf][1].w, h[3], m[3], l[3]);
+                        a_h = wsx_op(make_uint4(h[0], h[1], h[2], h[3])), a_m = wsx_op(make_uint4(m[0], m[1], m[2], m[3]));
+                        a_l = wsx_op(make_uint4(l[0], l[1], l[2], l[3]));
+                    }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const wsx_bf16x8 b_h = wsx_op(fb[buf][j][0]), b_m = wsx_op(fb[buf][j][1]), b_l = wsx_op(fb[buf][j][2]);
@@ -340,14 +392,55 @@ gemm_wsx_kernel(const WsxArgs P) {
         fetch_geo(nX, nC, snext);
         // ---- dW_1 += X^T a_0 with the epilogue of the dA product: the activation of step s IS the value whose sign masks accumulator s.
         // Mask; sums of v, v rel, a_0 ----
+        if constexpr (D3) {
+            if (!(WSX_EXP & 2)) {
+                // the activation fragments: relu of the layer-0 tile, registers 8 u .. 8 u + 7 = rows 16 u + 8 (e >> 2) + 4 lh + (e & 3)
+                uint4 bfr[2][2][3];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        unsigned h[4], m[4], l[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            wsx_split2(fmaxf(zt[j][8 * u + 2 * e], 0.f), fmaxf(zt[j][8 * u + 2 * e + 1], 0.f), h[e], m[e], l[e]);
+                        bfr[j][u][0] = make_uint4(h[0], h[1], h[2], h[3]), bfr[j][u][1] = make_uint4(m[0], m[1], m[2], m[3]);
+                        bfr[j][u][2] = make_uint4(l[0], l[1], l[2], l[3]);
+                    }
+#pragma unroll
+                for (int i = 0; i < CT; ++i)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        uint4 ta[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            const uint2 lo = wsx_tr(Dzp + p * SPLANE + tofs(i, u, 0)), hi = wsx_tr(Dzp + p * SPLANE + tofs(i, u, 1));
+                            ta[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        }
+                        const wsx_bf16x8 a_h = wsx_op(ta[0]), a_m = wsx_op(ta[1]), a_l = wsx_op(ta[2]);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const wsx_bf16x8 b_h = wsx_op(bfr[j][u][0]), b_m = wsx_op(bfr[j][u][1]), b_l = wsx_op(bfr[j][u][2]);
+                            dw[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, dw[i][j], 0, 0, 0);
+                            dws[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, dws[i][j], 0, 0, 0);
+                            dws[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, dws[i][j], 0, 0, 0);
+                            dws[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, b_m, dws[i][j], 0, 0, 0);
+                            dws[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, b_h, dws[i][j], 0, 0, 0);
+                            dws[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_m, dws[i][j], 0, 0, 0);
+                        }
+                    }
+            }
+        }
         {
             float t1[2] = {0.f, 0.f}, tx[2] = {0.f, 0.f}, ty[2] = {0.f, 0.f}, tz[2] = {0.f, 0.f}, ta[2] = {0.f, 0.f};
             float fd[2][CT];
             float4 rr[2];
             auto ldw = [&](int buf, int s) {
                 const int ro = (s & 3) + 8 * (s >> 2);
+                if constexpr (!D3) {
 #pragma unroll
-                for (int i = 0; i < CT; ++i) fd[buf][i] = dcol[ro * DP + 32 * i];
+                    for (int i = 0; i < CT; ++i) fd[buf][i] = dcol[ro * DP + 32 * i];
+                }
                 rr[buf] = *reinterpret_cast<const float4 *>(rrow + 4 * ro);
             };
             ldw(0, 0);
@@ -367,11 +460,13 @@ gemm_wsx_kernel(const WsxArgs P) {
                     }
                 }
                 if (s + 1 < 16) ldw((s + 1) & 1, s + 1);
-                if (!(WSX_EXP & 2)) {
+                if constexpr (!D3) {
+                    if (!(WSX_EXP & 2)) {
 #pragma unroll
-                    for (int i = 0; i < CT; ++i) {
-                        dw[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[s & 1][i], bact[0], dw[i][0], 0, 0, 0);
-                        dw[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[s & 1][i], bact[1], dw[i][1], 0, 0, 0);
+                        for (int i = 0; i < CT; ++i) {
+                            dw[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[s & 1][i], bact[0], dw[i][0], 0, 0, 0);
+                            dw[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[s & 1][i], bact[1], dw[i][1], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -397,6 +492,10 @@ gemm_wsx_kernel(const WsxArgs P) {
                 for (int r4 = 0; r4 < 4; ++r4) {
                     f32x4 v;
                     v[0] = dw[i][j][4 * r4], v[1] = dw[i][j][4 * r4 + 1], v[2] = dw[i][j][4 * r4 + 2], v[3] = dw[i][j][4 * r4 + 3];
+                    if constexpr (D3) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += dws[i][j][4 * r4 + e];
+                    }
                     red[(((i * 2 + j) * 4 + wave) * 4 + r4) * 64 + lane] = v;
                 }
         double *ared = reinterpret_cast<double *>(Tred);   // [4 waves][64] doubles
@@ -948,12 +1047,13 @@ int launch_wsf0(const AOperand &geo, int M, const float *W0, int ldw0, const dou
     return PNPP_OK;
 }
 
-template <int KD, int WPC, bool S3>
+template <int KD, int WPC, bool S3, bool D3>
 static void wsx_launch(const WsxArgs &P, int workers, hipStream_t st) {
-    constexpr size_t main_f = (size_t)(S3 ? 3 * WSX3_PLANE / 4 : 64 * KD) + 4 * 32 * (KD + 4), red_f = (size_t)(KD / 32) * 2 * 4 * 4 * 64 * 4;
+    constexpr size_t main_f = (size_t)(S3 ? 3 * WSX3_PLANE / 4 : 64 * KD) + 4 * (D3 ? 3 * 32 * 128 / 4 : 32 * (KD + 4)),
+                     red_f = (size_t)(KD / 32) * 2 * 4 * 4 * 64 * 4;
     constexpr size_t lds = ((main_f > red_f ? main_f : red_f) + 2 * KD + 64 + 512 + 512) * sizeof(float);
     static_assert(lds * WPC <= 160 * 1024, "LDS budget");
-    auto kfn = gemm_wsx_kernel<KD, WPC, S3>;
+    auto kfn = gemm_wsx_kernel<KD, WPC, S3, D3>;
     static bool granted = false;
     if (lds > 48 * 1024 && !granted) {
         (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -979,12 +1079,15 @@ bool try_launch_wsx(const AOperand &dz, const BOperand &W, int M, int C1, int C0
     P.W0 = W0, P.ldw0 = ldw0, P.scale0 = scale0, P.shift0 = shift0, P.dwslab = dwslab, P.xslab = stat;
     static const bool s3_on = !(getenv("PNPP_WSX3") && atoi(getenv("PNPP_WSX3")) == 0);   // PNPP_WSX3=0: the dA product on the float32 instruction (A/B runs)
     const bool s3 = s3_on && split_products() && wpc == 1;   // (two workgroups per CU leave the split form 74 registers short)
-    ProfScope ps(st, "gemm_wsx_kernel<%d,%d%s> M=%d N=%d K=%d grid=%dx1", C1, wpc, s3 ? ",S3" : "", M, C0, C1, workers);
+    static const bool d3_on = getenv("PNPP_WSX3") && atoi(getenv("PNPP_WSX3")) == 2;   // PNPP_WSX3=2: the dW_1 product on the bf16 pipe too
+    const bool d3 = s3 && d3_on;
+    ProfScope ps(st, "gemm_wsx_kernel<%d,%d%s> M=%d N=%d K=%d grid=%dx1", C1, wpc, d3 ? ",S3,D3" : s3 ? ",S3" : "", M, C0, C1, workers);
     if (wpc == 2) {
-        wsx_launch<64, 2, false>(P, workers, st);
+        wsx_launch<64, 2, false, false>(P, workers, st);
     } else {
-        if (s3) wsx_launch<64, 1, true>(P, workers, st);
-        else wsx_launch<64, 1, false>(P, workers, st);
+        if (d3) wsx_launch<64, 1, true, true>(P, workers, st);
+        else if (s3) wsx_launch<64, 1, true, false>(P, workers, st);
+        else wsx_launch<64, 1, false, false>(P, workers, st);
     }
     if (hipGetLastError() != hipSuccess) {
         set_error("gemm_wsx: launch failed");
