@@ -44,9 +44,9 @@ def tag_of(name, gx, gy, wg):
     m = re.search(r"gemm_wsq_kernel<(\d+), \d+>", name)
     if m:
         return f"gemm_wsq_kernel<{m.group(1)},A5> {g}"
-    m = re.search(r"gemm_wsx_kernel<(\d+), (\d+)(?:, (true|false))?>", name)   # <K, workgroups per CU, split dA product>
+    m = re.search(r"gemm_wsx_kernel<(\d+), (\d+)(?:, (true|false))?(?:, (true|false))?>", name)   # <K, workgroups per CU, split dA, split dW>
     if m:
-        return f"gemm_wsx_kernel<{m.group(1)},{m.group(2)}{',S3' if m.group(3) == 'true' else ''}> {g}"
+        return f"gemm_wsx_kernel<{m.group(1)},{m.group(2)}{',S3' if m.group(3) == 'true' else ''}{',D3' if m.group(4) == 'true' else ''}> {g}"
     m = re.search(r"gemm_wsf_kernel<(\d+), (\d+), (\d+), (\d+)>", name)
     if m:
         return f"gemm_wsf_kernel<{m.group(1)},{m.group(2)},A{m.group(3)},E{m.group(4)}> {g}"
